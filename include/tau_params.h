@@ -1,0 +1,103 @@
+/* tau_params.h — plain-C parameter blocks shared by the engine (libtaueng), the
+ * thin C drivers and the CPU oracle.
+ *
+ * Every struct mirrors, field for field, the parameter block the reference
+ * program keeps for the same simulator, so a reference `main` can hand its own
+ * values across the C-ABI unchanged.  Citations are file:line in the reference
+ * tree (seanwevans/fluid-sims).
+ */
+#ifndef TAU_PARAMS_H
+#define TAU_PARAMS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 3D two-temperature hypersonic Euler (tau_hypersonic_3d_cuda.cu:21-42) ---- */
+typedef struct tau3d_params {
+  int32_t nx, ny, nz;          /* GLOBAL grid (all ranks together)            */
+  float dx, dy, dz;            /* 1/nx, 1/ny, 1/nz in the reference (:1535-1537) */
+  float cfl;                   /* 0.3333 */
+  float u_ref;                 /* asinh velocity scale, 10 */
+  float R;                     /* gas constant, 10 */
+  float gamma_floor;           /* 1.1 */
+  float Twall;                 /* 0.02 */
+  float tau_vib;               /* 2e-4 */
+  float theta_v;               /* 0.2 */
+  float sdf_cx, sdf_cy, sdf_cz;/* sphere centre, 0.5 */
+  float sdf_r;                 /* 0.25 */
+  float inflow_r, inflow_p;    /* 0.02, 0.02 */
+  float inflow_u, inflow_v, inflow_w; /* 100, 0, 0 */
+  int32_t sponge_n;            /* 24 */
+  float sponge_strength;       /* 0.05 */
+  int32_t sponge_out_n;        /* 24 */
+  float sponge_out_strength;   /* 0.05 */
+} tau3d_params;
+
+/* Log-time clock of the 3D solver (tau_hypersonic_3d_cuda.cu:1635-1636, 1680-1704).
+ * `t`,`d_tau` are the controller state BEFORE the next step; `dt`,`gain`,`maxs`
+ * describe the step that was just taken. */
+typedef struct tau3d_clock {
+  float t;
+  float d_tau;
+  float dt;
+  float gain;
+  float maxs;
+  int32_t step;
+} tau3d_clock;
+
+/* ---- Gray-Scott (tau_gray_scott.cu:43-61) ---- */
+typedef struct taugs_params {
+  int32_t nx, ny;
+  float dx, dt;
+  float Du, Dv, feed, kill;
+} taugs_params;
+
+/* ---- 5-point Laplacian viscosity passes ----
+ * Burgers: tau_burgers.cu:490-525 (fields are asinh-encoded, u = u0*sinh(phi))
+ * Shallow water: tau_shallow_water.cu:516-547 (plain u, v) */
+typedef struct taulap_params {
+  int32_t nx, ny;
+  float dx, dy;
+  float nu;
+  float dt;
+  float u0;      /* Burgers only: velocity scale of the asinh encoding */
+} taulap_params;
+
+/* ---- 2D hypersonic Euler, GPU scheme (tau_hypersonic_cuda.cu:37-50, 1394-1409) ---- */
+typedef struct tauh2_params {
+  int32_t W, H;              /* compile-time 8192 x 1024 in the reference (:28-29) */
+  double gamma;              /* 1.1 */
+  double cfl;                /* 0.25 */
+  double visc_nu;            /* 0.05 momentum */
+  double visc_rho;           /* 0.05 */
+  double visc_e;             /* 0.02 */
+  double mach;               /* 25 */
+  double geom_x0;            /* 125 */
+  double geom_cy;            /* H/2 */
+  double geom_rb;            /* H/12 */
+  double geom_rn;            /* H/24 */
+  double geom_theta;         /* pi/4 */
+} tauh2_params;
+
+/* ---- 2D WCSPH (tau_sph.cu:49-85) ---- */
+typedef struct tausph_params {
+  int32_t n;            /* particles */
+  float boxX, boxY;
+  float rho0;
+  float c0;
+  float gamma;
+  float hMul;
+  float alpha;          /* Monaghan viscosity */
+  float gx, gy;         /* gravity */
+  float cfl;
+  float dTau;
+  float restitution;    /* 0.2 in k_integrate (:324-355) */
+} tausph_params;
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAU_PARAMS_H */
