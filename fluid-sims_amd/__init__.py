@@ -1,0 +1,9 @@
+"""fluid-sims_amd — MI355X-native explicit time-stepping engine (libtaueng) and its host mirror.
+
+The directory name carries a hyphen (it is the name the project was given); import it through
+the ``fluid_sims_amd`` shim at the repository root, or load this package by path.
+"""
+from . import taueng  # noqa: F401
+from .taueng import (  # noqa: F401
+    TauError, lib_path, load, Tau3D, GrayScott, Laplacian2D, Tau3DParams, Tau3DClock,
+)

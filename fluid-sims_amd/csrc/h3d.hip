@@ -1,0 +1,880 @@
+// h3d.hip — 3D two-temperature hypersonic Euler step for gfx950 (MI355X).
+//
+// What it computes: one k_step of the reference (tau_hypersonic_3d_cuda.cu:987-1359):
+// decode the log/asinh-encoded state, WENO5 + blended HLLC/HLL face fluxes, conservative
+// update, Landau-Teller relaxation, sponges, max wavespeed, re-encode.
+//
+// How it is laid out for CDNA4 (nothing here follows the reference's launch shape):
+//   * one 256-thread workgroup owns a 32x8 (x,y) column and MARCHES along z through a chunk
+//     of planes.  Each thread keeps its own column's 6-plane z-window of primitives in
+//     VGPRs, so only the CURRENT plane (plus its 3-cell x/y halo) lives in LDS: 13 KB
+//     instead of the reference's 49 KB 3-D tile, and every cell is decoded ~2x per step
+//     instead of 7.7x.
+//   * every face flux is computed ONCE (the reference computes each face from both
+//     sides): a thread computes the low-x and low-y face of its cell and the high-z face;
+//     the high-x / high-y fluxes come from the neighbour thread through a small LDS flux
+//     tile; the low-z flux is carried in registers from the previous plane.  The 40 faces
+//     on the far edges of the tile are done by one extra round of the last wave.
+//   * lanes run along x (32 consecutive floats = one 128-B segment per row), a wave64
+//     covers two rows.
+//   * divisions are v_rcp_f32, exp/log are v_exp_f32/v_log_f32 (the reference uses
+//     __expf/__logf too); sinh uses a series below |x|<0.5 so small transverse velocities
+//     keep their relative accuracy.
+//   * dt / inflow gain are read from a device-side clock block, the max wavespeed goes
+//     back through one atomicMax per workgroup: the d_tau controller never leaves the GPU.
+//
+// Bound: this kernel is FP32-VALU bound (≈2.6 k VALU instr per cell), not HBM bound —
+// algorithmic traffic is 49 B/cell (6 fp32 in + 1 u8 + 6 fp32 out).
+
+#include "../../include/taueng.h"
+#include "tau_common.h"
+#include <cmath>
+#include <cstdlib>
+#include <new>
+
+namespace h3d {
+
+constexpr int HALO = 3;            // WENO_HALO, tau_hypersonic_3d_cuda.cu:58
+constexpr int TX = 32, TY = 8;     // workgroup tile in (x, y)
+constexpr int NT = TX * TY;        // 256 threads = 4 waves
+constexpr int PX = TX + 2 * HALO;  // 38
+constexpr int PY = TY + 2 * HALO;  // 14
+constexpr int PXS = 40;            // padded LDS row stride (floats)
+constexpr int PLANE = PY * PXS;    // floats per variable per plane
+
+constexpr float RHO_P_FLOOR = 1e-30f;          // :52
+constexpr float THERMAL_ENERGY_FLOOR = 1e-12f; // :53
+constexpr float DENOM_EPS = 1e-12f;            // :54
+constexpr float NEWTON_TEMP_FLOOR = 1e-6f;     // :55
+constexpr float WENO_EPS = 1e-6f;              // :56
+constexpr float TAU_VIB_MIN = 1e-9f;           // :57
+
+enum { IR = 0, IU = 1, IV = 2, IW = 3, IP = 4, IE = 5 };
+
+struct Prim { float q[6]; };   // r, u, v, w, p, ev
+struct Cons { float c[6]; };   // r, mx, my, mz, Et, Ev
+
+// device-side clock block (one per handle)
+struct DevClock {
+  float t, d_tau, dt, gain, maxs_last;
+  int step;
+  unsigned maxs_bits;   // max wavespeed of the step in flight, as float bits (>0 floats order as uints)
+  float cfl;
+};
+
+// kernel arguments (by value -> SGPRs)
+struct Args {
+  const float *in[6];
+  float *out[6];
+  const uint8_t *solid;      // halo layout, plane -3 first
+  DevClock *clk;
+  int nx, ny, nz;            // global
+  int nzl, z0;               // local planes, global index of local plane 0
+  int zl_lo, zl_hi;          // local plane range to update
+  int zchunk;                // planes marched by one workgroup
+  int ntx, nty, nzc;         // tiles in x, y; chunks in z
+  float dx, dy, dz, inv_dx, inv_dy, inv_dz;
+  float u_ref, inv_u_ref, R, gamma, gm1, Twall, theta_v, Rtheta, inv_tau_vib;
+  float sdf_cx, sdf_cy, sdf_cz, sdf_r;
+  float in_r, in_u, in_v, in_w, in_p, in_ev;   // inflow_prim(), :611-622 (ev from host expf)
+  int sponge_n, sponge_out_n;
+  float sponge_strength, sponge_out_strength;
+};
+
+// ---------------------------------------------------------------- fast math
+__device__ __forceinline__ float rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896341f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
+__device__ __forceinline__ float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
+__device__ __forceinline__ float denom_guard(float x) { return copysignf(fmaxf(fabsf(x), DENOM_EPS), x); } // :147-150
+
+// sinh with full relative accuracy for small arguments (the reference calls sinhf, :119)
+__device__ __forceinline__ float fsinh(float x) {
+  float ax = fabsf(x);
+  float x2 = x * x;
+  float series = x * (1.f + x2 * (1.f / 6.f) * (1.f + x2 * (1.f / 20.f) * (1.f + x2 * (1.f / 42.f))));
+  float e = fexp(ax);
+  float big = copysignf(0.5f * (e - rcp(e)), x);
+  return (ax < 0.5f) ? series : big;
+}
+// asinh as the reference writes it, :121-125
+__device__ __forceinline__ float fasinh(float x) {
+  float ax = fabsf(x);
+  float t = flog(ax + fsqrt(ax * ax + 1.0f));
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float evib_eq(const Args &A, float T) { // :206-211
+  float a = A.theta_v * rcp(fmaxf(T, NEWTON_TEMP_FLOOR));
+  float ea = fexp(a);
+  float denom = fmaxf(ea - 1.f, NEWTON_TEMP_FLOOR);
+  return A.Rtheta * rcp(denom);
+}
+
+__device__ __forceinline__ Prim decode(const Args &A, size_t gi) { // log_to_prim_fast, :213-225
+  Prim q;
+  q.q[IR] = fexp(A.in[0][gi]);
+  q.q[IU] = A.u_ref * fsinh(A.in[1][gi]);
+  q.q[IV] = A.u_ref * fsinh(A.in[2][gi]);
+  q.q[IW] = A.u_ref * fsinh(A.in[3][gi]);
+  q.q[IP] = fexp(A.in[4][gi]);
+  q.q[IE] = fexp(A.in[5][gi]);
+  return q;
+}
+
+__device__ __forceinline__ Prim inflow_prim(const Args &A) {
+  Prim q;
+  q.q[IR] = A.in_r; q.q[IU] = A.in_u; q.q[IV] = A.in_v; q.q[IW] = A.in_w; q.q[IP] = A.in_p; q.q[IE] = A.in_ev;
+  return q;
+}
+
+__device__ __forceinline__ float soundspeed(const Args &A, float p, float r) { // :264-266
+  return fsqrt(fmaxf(A.gamma * p * rcp(r), DENOM_EPS));
+}
+
+// ghost state right of the last interior cell, :691-722
+__device__ __forceinline__ Prim outflow_prim(const Args &A, Prim qR) {
+  Prim q = qR;
+  float aR = soundspeed(A, qR.q[IP], qR.q[IR]);
+  float un = qR.q[IU];
+  if (un < aR) q.q[IP] = fmaxf(q.q[IP] + 0.05f * (A.in_p - q.q[IP]), RHO_P_FLOOR);
+  q.q[IR] = fmaxf(q.q[IR], RHO_P_FLOOR);
+  q.q[IP] = fmaxf(q.q[IP], RHO_P_FLOOR);
+  q.q[IE] = fmaxf(q.q[IE], 0.f);
+  if (un < 0.0f) q = inflow_prim(A);
+  return q;
+}
+
+__device__ __forceinline__ bool sdf_solid(const Args &A, int x, int y, int zg) { // :173-189
+  float X = (x + 0.5f) * A.dx, Y = (y + 0.5f) * A.dy, Z = (zg + 0.5f) * A.dz;
+  float ddx = X - A.sdf_cx, ddy = Y - A.sdf_cy, ddz = Z - A.sdf_cz;
+  return (sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) - A.sdf_r) < 0.f;
+}
+
+__device__ __forceinline__ int wrapi(int i, int n) { i %= n; return (i < 0) ? i + n : i; }
+
+// ---------------------------------------------------------------- WENO5, :534-558
+__device__ __forceinline__ float weno5(float v0, float v1, float v2, float v3, float v4) {
+  float p0 = 2.f * v0 - 7.f * v1 + 11.f * v2;
+  float p1 = -v1 + 5.f * v2 + 2.f * v3;
+  float p2 = 2.f * v2 + 5.f * v3 - v4;
+  float d0 = v0 - 2.f * v1 + v2, e0 = v0 - 4.f * v1 + 3.f * v2;
+  float d1 = v1 - 2.f * v2 + v3, e1 = v1 - v3;
+  float d2 = v2 - 2.f * v3 + v4, e2 = 3.f * v2 - 4.f * v3 + v4;
+  float b0 = (13.f / 12.f) * d0 * d0 + 0.25f * e0 * e0;
+  float b1 = (13.f / 12.f) * d1 * d1 + 0.25f * e1 * e1;
+  float b2 = (13.f / 12.f) * d2 * d2 + 0.25f * e2 * e2;
+  float t0 = WENO_EPS + b0, t1 = WENO_EPS + b1, t2 = WENO_EPS + b2;
+  float a0 = 0.1f * rcp(t0 * t0);
+  float a1 = 0.6f * rcp(t1 * t1);
+  float a2 = 0.3f * rcp(t2 * t2);
+  float s = a0 + a1 + a2;
+  return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(s) * (1.f / 6.f));
+}
+
+__device__ __forceinline__ void prim_floor(Prim &q) { // :565-571
+  q.q[IR] = fmaxf(q.q[IR], RHO_P_FLOOR);
+  q.q[IP] = fmaxf(q.q[IP], RHO_P_FLOOR);
+  q.q[IE] = fmaxf(q.q[IE], 0.f);
+}
+
+// ---------------------------------------------------------------- HLLC blended with HLL, :383-460
+// axis may be a literal (specialised after inlining) or a lane-varying value in {0,1}.
+__device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R, int axis) {
+  const float rL = L.q[IR], rR = R.q[IR], pL = L.q[IP], pR = R.q[IP];
+  const float irL = rcp(rL), irR = rcp(rR);
+  const float aL = fsqrt(fmaxf(A.gamma * pL * irL, DENOM_EPS));
+  const float aR = fsqrt(fmaxf(A.gamma * pR * irR, DENOM_EPS));
+  const float unL = (axis == 0) ? L.q[IU] : (axis == 1) ? L.q[IV] : L.q[IW];
+  const float unR = (axis == 0) ? R.q[IU] : (axis == 1) ? R.q[IV] : R.q[IW];
+  float sL = fminf(unL - aL, unR - aR);
+  float sR = fmaxf(unL + aL, unR + aR);
+  const float aRef = fmaxf(aL, aR);
+  { // entropy_fix_speed, :366-374
+    float d = 0.1f * aRef, id = rcp(fmaxf(d, DENOM_EPS));
+    float asl = fabsf(sL), asr = fabsf(sR);
+    float fl = 0.5f * (asl * asl * id + d), fr = 0.5f * (asr * asr * id + d);
+    sL = (asl >= d) ? sL : ((sL >= 0.f) ? fl : -fl);
+    sR = (asr >= d) ? sR : ((sR >= 0.f) ? fr : -fr);
+  }
+  // conserved states and physical fluxes, :234-245, 268-308
+  const float keL = 0.5f * (L.q[IU] * L.q[IU] + L.q[IV] * L.q[IV] + L.q[IW] * L.q[IW]);
+  const float keR = 0.5f * (R.q[IU] * R.q[IU] + R.q[IV] * R.q[IV] + R.q[IW] * R.q[IW]);
+  const float ethL = pL * rcp(fmaxf(A.gm1 * rL, RHO_P_FLOOR));
+  const float ethR = pR * rcp(fmaxf(A.gm1 * rR, RHO_P_FLOOR));
+  Cons UL, UR, FL, FR;
+  UL.c[0] = rL; UL.c[1] = rL * L.q[IU]; UL.c[2] = rL * L.q[IV]; UL.c[3] = rL * L.q[IW];
+  UL.c[4] = rL * (keL + ethL + L.q[IE]); UL.c[5] = rL * L.q[IE];
+  UR.c[0] = rR; UR.c[1] = rR * R.q[IU]; UR.c[2] = rR * R.q[IV]; UR.c[3] = rR * R.q[IW];
+  UR.c[4] = rR * (keR + ethR + R.q[IE]); UR.c[5] = rR * R.q[IE];
+  const float HL = pL * irL + (keL + L.q[IE]) + ethL;
+  const float HR = pR * irR + (keR + R.q[IE]) + ethR;
+  FL.c[0] = rL * unL; FL.c[1] = UL.c[1] * unL; FL.c[2] = UL.c[2] * unL; FL.c[3] = UL.c[3] * unL;
+  FL.c[4] = rL * HL * unL; FL.c[5] = UL.c[5] * unL;
+  FR.c[0] = rR * unR; FR.c[1] = UR.c[1] * unR; FR.c[2] = UR.c[2] * unR; FR.c[3] = UR.c[3] * unR;
+  FR.c[4] = rR * HR * unR; FR.c[5] = UR.c[5] * unR;
+  if (axis == 0) { FL.c[1] += pL; FR.c[1] += pR; }
+  else if (axis == 1) { FL.c[2] += pL; FR.c[2] += pR; }
+  else { FL.c[3] += pL; FR.c[3] += pR; }
+
+  if (sL >= 0.f) return FL;
+  if (sR <= 0.f) return FR;
+
+  const float denom = denom_guard(rL * (sL - unL) - rR * (sR - unR));
+  const float sM = (pR - pL + rL * unL * (sL - unL) - rR * unR * (sR - unR)) * rcp(denom);
+  const float pStarL = pL + rL * (sL - unL) * (sM - unL);
+  const float pStarR = pR + rR * (sR - unR) * (sM - unR);
+  const float pStar = 0.5f * (pStarL + pStarR);
+
+  float vc; // axis_crossflow_speed, :318-325
+  if (axis == 0) vc = (fabsf(L.q[IV]) + fabsf(R.q[IV]) + fabsf(L.q[IW]) + fabsf(R.q[IW])) * 0.5f;
+  else if (axis == 1) vc = (fabsf(L.q[IU]) + fabsf(R.q[IU]) + fabsf(L.q[IW]) + fabsf(R.q[IW])) * 0.5f;
+  else vc = (fabsf(L.q[IU]) + fabsf(R.q[IU]) + fabsf(L.q[IV]) + fabsf(R.q[IV])) * 0.5f;
+  const float align = clampf(1.f - vc * rcp(fmaxf(aRef, DENOM_EPS)), 0.f, 1.f);
+  float alpha;
+  { // shock_sensor, :376-381
+    float dp = fabsf(pR - pL) * rcp(fmaxf(pR + pL, DENOM_EPS));
+    float dr = fabsf(rR - rL) * rcp(fmaxf(rR + rL, DENOM_EPS));
+    alpha = clampf(5.f * (0.5f * (dp + dr)), 0.f, 1.f) * align;
+  }
+  const float ihll = rcp(denom_guard(sR - sL));
+  const float sLR = sL * sR;
+
+  const bool left = (sM >= 0.f);
+  const float sK = left ? sL : sR, unK = left ? unL : unR, rK = left ? rL : rR, pK = left ? pL : pR;
+  const float iden = rcp(denom_guard(sK - sM));
+  const float fac = (sK - unK) * iden;
+  const float rStar = rK * fac;
+  Cons US;
+  US.c[0] = rStar;
+  const float uK = left ? L.q[IU] : R.q[IU], vK = left ? L.q[IV] : R.q[IV], wK = left ? L.q[IW] : R.q[IW];
+  US.c[1] = rStar * ((axis == 0) ? sM : uK);   // fill_star_momentum, :335-350
+  US.c[2] = rStar * ((axis == 1) ? sM : vK);
+  US.c[3] = rStar * ((axis == 2) ? sM : wK);
+  const float EK = left ? UL.c[4] : UR.c[4], EvK = left ? UL.c[5] : UR.c[5];
+  US.c[4] = ((sK - unK) * EK - pK * unK + pStar * sM) * iden;
+  US.c[5] = EvK * fac;
+  Cons F;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    float UK = left ? UL.c[k] : UR.c[k];
+    float FK = left ? FL.c[k] : FR.c[k];
+    float fhllc = FK + (US.c[k] - UK) * sK;
+    float fhll = (FL.c[k] * sR - FR.c[k] * sL + (UR.c[k] - UL.c[k]) * sLR) * ihll;
+    F.c[k] = fhllc * (1.f - alpha) + fhll * alpha;
+  }
+  return F;
+}
+
+// Face between line cells c2 | c3 of the six cells v[0..5][var]; s = solid bits of the six
+// cells (bit k = cell k).  Branch structure of :1125-1143: solid face -> mirrored ghost,
+// solid anywhere in the stencil -> first order, else WENO5 on the six primitives.
+__device__ __forceinline__ Cons face_flux(const Args &A, const float (&v)[6][6], unsigned s, int axis) {
+  Prim L, R;
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    L.q[m] = weno5(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m]);
+    R.q[m] = weno5(v[5][m], v[4][m], v[3][m], v[2][m], v[1][m]);
+  }
+  if (s != 0u) {
+    const bool s2 = (s >> 2) & 1u, s3 = (s >> 3) & 1u;
+#pragma unroll
+    for (int m = 0; m < 6; m++) { L.q[m] = v[2][m]; R.q[m] = v[3][m]; }
+    const int un = (axis == 0) ? IU : (axis == 1) ? IV : IW;
+    if (s2 && !s3) { // low side solid: L = mirror(R)
+#pragma unroll
+      for (int m = 0; m < 6; m++) L.q[m] = R.q[m];
+      if (axis == 0) L.q[IU] = -L.q[IU]; else if (axis == 1) L.q[IV] = -L.q[IV]; else L.q[IW] = -L.q[IW];
+    } else if (s3 && !s2) { // high side solid: R = mirror(L)
+#pragma unroll
+      for (int m = 0; m < 6; m++) R.q[m] = L.q[m];
+      if (axis == 0) R.q[IU] = -R.q[IU]; else if (axis == 1) R.q[IV] = -R.q[IV]; else R.q[IW] = -R.q[IW];
+    }
+    (void)un;
+  }
+  prim_floor(L);
+  prim_floor(R);
+  return hllc(A, L, R, axis);
+}
+
+// ---------------------------------------------------------------- the step kernel
+__global__ __launch_bounds__(NT) void k_step(const Args A) {
+  __shared__ float sP[6][PLANE];            // current plane, primitives, x/y halo 3
+  __shared__ uint8_t sS[PLANE];             // solid flags of the same cells
+  __shared__ float sFx[6][TY][TX + 1];      // low-x face flux of cell (y, x); column TX = far edge
+  __shared__ float sFy[6][TY + 1][TX];      // low-y face flux of cell (y, x); row TY = far edge
+  __shared__ float sRed[NT / 64];
+
+  const int tid = threadIdx.x;
+  const int tx = tid & (TX - 1), ty = tid >> 5;
+  const int lane = tid & 63, wave = tid >> 6;
+
+  // linear block id -> (tile x, tile y, z chunk), XCD-contiguous
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
+  const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
+  const int by = (int)(b % (unsigned)A.nty);
+  const int bz = (int)(b / (unsigned)A.nty);
+  const int bx0 = bx * TX, by0 = by * TY;
+  const int zc_lo = A.zl_lo + bz * A.zchunk;
+  const int zc_hi = min(zc_lo + A.zchunk, A.zl_hi);
+
+  const int x = bx0 + tx, y = by0 + ty;
+  const bool in_xy = (x < A.nx) && (y < A.ny);
+  const int xo = min(x, A.nx - 1), yo = min(y, A.ny - 1);
+  const size_t plane_n = (size_t)A.nx * A.ny;
+  const size_t col = (size_t)yo * A.nx + xo;
+
+  const float dt = A.clk->dt;
+  const float gain = A.clk->gain;
+
+  // z-window of the own column: planes z-2 .. z+3 around the current plane z
+  float W[6][6];
+  unsigned ws = 0; // solid bits of the window, bit k = W[k]
+  auto load_own = [&](int zl, float (&dst)[6], unsigned &bit) {
+    size_t gi = (size_t)(zl + HALO) * plane_n + col;
+    Prim q = decode(A, gi);
+#pragma unroll
+    for (int m = 0; m < 6; m++) dst[m] = q.q[m];
+    bit = A.solid[gi] ? 1u : 0u;
+  };
+
+  // prologue: planes zc_lo-3 .. zc_lo+2 -> flux through the low-z face of plane zc_lo
+  float Fz_lo[6];
+  {
+    unsigned bit;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { load_own(zc_lo - 3 + k, W[k], bit); ws |= bit << k; }
+    Cons F = face_flux(A, W, ws, 2);
+#pragma unroll
+    for (int m = 0; m < 6; m++) Fz_lo[m] = F.c[m];
+  }
+
+  float smax = 0.f;
+
+  for (int z = zc_lo; z < zc_hi; z++) {
+    // ---- slide the window to planes z-2 .. z+3
+    {
+#pragma unroll
+      for (int k = 0; k < 5; k++)
+#pragma unroll
+        for (int m = 0; m < 6; m++) W[k][m] = W[k + 1][m];
+      unsigned bit;
+      load_own(z + 3, W[5], bit);
+      ws = (ws >> 1) | (bit << 5);
+    }
+    // ---- stage plane z (with x/y halo) into LDS
+    {
+      const int zh = z + HALO;
+      const int zg = wrapi(A.z0 + z, A.nz);
+      for (int p = tid; p < PY * PX; p += NT) {
+        const int ly = p / PX, lx = p - ly * PX;
+        const int gx = bx0 + lx - HALO;
+        const int gy = wrapi(by0 + ly - HALO, A.ny);
+        Prim q;
+        bool sol;
+        if (gx < 0) {
+          q = inflow_prim(A);
+          sol = sdf_solid(A, gx, gy, zg);
+        } else if (gx >= A.nx) {
+          size_t gi = ((size_t)zh * A.ny + gy) * A.nx + (A.nx - 1);
+          q = outflow_prim(A, decode(A, gi));
+          sol = sdf_solid(A, gx, gy, zg);
+        } else {
+          size_t gi = ((size_t)zh * A.ny + gy) * A.nx + gx;
+          q = decode(A, gi);
+          sol = A.solid[gi] != 0;
+        }
+        const int li = ly * PXS + lx;
+#pragma unroll
+        for (int m = 0; m < 6; m++) sP[m][li] = q.q[m];
+        sS[li] = sol ? 1 : 0;
+      }
+    }
+    __syncthreads();
+
+    // ---- face fluxes: low-x, low-y of the own cell; high-z of the own cell
+    const int lc = (ty + HALO) * PXS + (tx + HALO);
+    {
+      float v[6][6];
+      unsigned s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3)];
+        s |= (unsigned)sS[lc + (k - 3)] << k;
+      }
+      Cons F = face_flux(A, v, s, 0);
+#pragma unroll
+      for (int m = 0; m < 6; m++) sFx[m][ty][tx] = F.c[m];
+    }
+    {
+      float v[6][6];
+      unsigned s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3) * PXS];
+        s |= (unsigned)sS[lc + (k - 3) * PXS] << k;
+      }
+      Cons F = face_flux(A, v, s, 1);
+#pragma unroll
+      for (int m = 0; m < 6; m++) sFy[m][ty][tx] = F.c[m];
+    }
+    // far-edge faces of the tile: 8 x-faces at column TX, 32 y-faces at row TY — one extra
+    // round of the last wave, axis is lane-varying
+    if (wave == NT / 64 - 1 && lane < TY + TX) {
+      const bool isx = lane < TY;
+      const int ey = isx ? lane : TY;
+      const int ex = isx ? TX : (lane - TY);
+      const int st = isx ? 1 : PXS;
+      const int c0 = (ey + HALO) * PXS + (ex + HALO);
+      float v[6][6];
+      unsigned s = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) v[k][m] = sP[m][c0 + (k - 3) * st];
+        s |= (unsigned)sS[c0 + (k - 3) * st] << k;
+      }
+      Cons F = face_flux(A, v, s, isx ? 0 : 1);
+      if (isx) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) sFx[m][ey][TX] = F.c[m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < 6; m++) sFy[m][TY][ex] = F.c[m];
+      }
+    }
+    float Fz_hi[6];
+    {
+      Cons F = face_flux(A, W, ws, 2);
+#pragma unroll
+      for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
+    }
+    __syncthreads();
+
+    // ---- conservative update of cell (x, y, z), :1266-1358
+    const bool own_solid = (ws >> 2) & 1u;
+    if (in_xy) {
+      const size_t gi = (size_t)(z + HALO) * plane_n + col;
+      if (own_solid) { // :1063-1072 copy-through
+#pragma unroll
+        for (int m = 0; m < 6; m++) A.out[m][gi] = A.in[m][gi];
+      } else {
+        const float r0 = W[2][IR], u0 = W[2][IU], v0 = W[2][IV], w0 = W[2][IW], p0 = W[2][IP], e0 = W[2][IE];
+        float U0[6];
+        U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
+        {
+          float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
+          float eth = p0 * rcp(fmaxf(A.gm1 * r0, RHO_P_FLOOR));
+          U0[4] = r0 * (ke + eth + e0);
+          U0[5] = r0 * e0;
+        }
+        float U1[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          float dU = -((sFx[m][ty][tx + 1] - sFx[m][ty][tx]) * A.inv_dx +
+                       (sFy[m][ty + 1][tx] - sFy[m][ty][tx]) * A.inv_dy + (Fz_hi[m] - Fz_lo[m]) * A.inv_dz);
+          U1[m] = U0[m] + dU * dt;
+        }
+        // cons_to_prim, :247-262
+        float r1 = fmaxf(U1[0], RHO_P_FLOOR);
+        float ir1 = rcp(r1);
+        float u1 = U1[1] * ir1, v1 = U1[2] * ir1, w1 = U1[3] * ir1;
+        float ke = 0.5f * (u1 * u1 + v1 * v1 + w1 * w1);
+        float ev1 = fmaxf(U1[5] * ir1, 0.f);
+        float e_th = fmaxf(U1[4] * ir1 - ke - ev1, THERMAL_ENERGY_FLOOR);
+        float p1 = fmaxf(A.gm1 * r1 * e_th, RHO_P_FLOOR);
+        const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
+                           __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
+                         r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
+        if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; } // :1284-1289
+        float T1 = p1 * rcp(r1 * A.R);
+        ev1 = fmaxf(ev1 + (evib_eq(A, T1) - ev1) * (dt * A.inv_tau_vib), 0.f); // :1290-1292
+
+        if (A.sponge_n > 0 && x < A.sponge_n) { // :1295-1319
+          float s = 1.0f - (float)x / (float)A.sponge_n;
+          s = fminf(fmaxf(s, 0.0f), 1.0f);
+          float k = A.sponge_strength * (s * s);
+          r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
+          p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
+          u1 = u1 + k * (gain * A.in_u - u1);
+          v1 = v1 + k * (gain * A.in_v - v1);
+          w1 = w1 + k * (gain * A.in_w - w1);
+          ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+        }
+        if (A.sponge_out_n > 0 && x >= (A.nx - A.sponge_out_n)) { // :1320-1344
+          int xo2 = x - (A.nx - A.sponge_out_n);
+          float s = (float)xo2 / (float)A.sponge_out_n;
+          s = fminf(fmaxf(s, 0.0f), 1.0f);
+          float k = A.sponge_out_strength * (s * s);
+          r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
+          p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
+          u1 = u1 + k * (0.0f - u1);
+          v1 = v1 + k * (0.0f - v1);
+          w1 = w1 + k * (0.0f - w1);
+          ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+        }
+        float a = soundspeed(A, p1, r1); // :1345-1351
+        float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
+        if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
+
+        A.out[0][gi] = flog(fmaxf(r1, RHO_P_FLOOR)); // :1353-1358
+        A.out[1][gi] = fasinh(u1 * A.inv_u_ref);
+        A.out[2][gi] = fasinh(v1 * A.inv_u_ref);
+        A.out[3][gi] = fasinh(w1 * A.inv_u_ref);
+        A.out[4][gi] = flog(fmaxf(p1, RHO_P_FLOOR));
+        A.out[5][gi] = flog(fmaxf(ev1, RHO_P_FLOOR));
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+  }
+
+  // ---- max wavespeed: wave64 butterfly, then one atomic per workgroup
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  if (lane == 0) sRed[wave] = smax;
+  __syncthreads();
+  if (tid == 0) {
+    float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+    if (m > 0.f) atomicMax(&A.clk->maxs_bits, __float_as_uint(m));
+  }
+}
+
+// ---------------------------------------------------------------- small kernels
+__global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes included
+  size_t n = (size_t)A.nx * A.ny * (A.nzl + 2 * HALO);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int x = (int)(i % A.nx);
+    size_t r = i / A.nx;
+    int y = (int)(r % A.ny);
+    int zh = (int)(r / A.ny);
+    int zg = wrapi(A.z0 + zh - HALO, A.nz);
+    solid[i] = sdf_solid(A, x, y, zg) ? 1 : 0;
+  }
+}
+
+struct InitVals { float f[6]; float s[6]; }; // encoded fluid / solid cell values (host-computed, libm)
+__global__ void k_init(Args A, float *const st0, float *const st1, float *const st2, float *const st3,
+                       float *const st4, float *const st5, const uint8_t *solid, InitVals iv) { // :939-985
+  size_t n = (size_t)A.nx * A.ny * (A.nzl + 2 * HALO);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float *v = solid[i] ? iv.s : iv.f;
+    st0[i] = v[0]; st1[i] = v[1]; st2[i] = v[2]; st3[i] = v[3]; st4[i] = v[4]; st5[i] = v[5];
+  }
+}
+
+// periodic halo of a single domain: planes [nzl, nzl+3) -> low halo, planes [3, 6) -> high halo
+struct HaloArgs { float *f[6]; size_t plane_n; int nzl; };
+__global__ void k_halo_periodic(HaloArgs H) {
+  const size_t n4 = (size_t)HALO * H.plane_n; // floats per halo block
+  const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
+  float *base = H.f[f];
+  const float *src = side == 0 ? base + (size_t)H.nzl * H.plane_n : base + (size_t)HALO * H.plane_n;
+  float *dst = side == 0 ? base : base + (size_t)(H.nzl + HALO) * H.plane_n;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+// log-time clock, :1680-1683 — runs before the step
+__global__ void k_clock_begin(DevClock *c) {
+  c->t *= expf(c->d_tau);
+  c->dt = c->t * c->d_tau;
+  float ramp = c->t / 0.02f;
+  c->gain = fminf(fmaxf(ramp, 0.f), 1.f);
+  c->maxs_bits = 0u;
+}
+// d_tau controller, :1697-1704 — runs after the step (and after the max all-reduce)
+__global__ void k_clock_end(DevClock *c) {
+  float maxs = __uint_as_float(c->maxs_bits);
+  float dt_cfl = c->cfl / fmaxf(maxs, 1e-9f);
+  if (c->dt > 1.10f * dt_cfl) c->d_tau *= 0.80f;
+  else if (c->dt < 0.85f * dt_cfl) c->d_tau *= 1.10f;
+  c->d_tau = fminf(fmaxf(c->d_tau, 1e-7f), 5e-2f);
+  c->maxs_last = maxs;
+  c->step += 1;
+}
+__global__ void k_clock_set_explicit(DevClock *c, float dt, float gain) {
+  c->dt = dt; c->gain = gain; c->maxs_bits = 0u;
+}
+
+} // namespace h3d
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+struct tau3d {
+  tau3d_params p;
+  int z0, nzl, device;
+  hipStream_t stream;
+  bool own_stream;
+  size_t plane_n, field_n;  // floats per plane, floats per field incl. halo
+  float *buf[2][6];         // ping-pong, halo layout
+  uint8_t *solid;
+  h3d::DevClock *clk;
+  int cur;                  // which side holds the current state
+  h3d::Args base;           // constants, pointers filled per launch
+  int zchunk;
+};
+
+static float host_evib_eq(const tau3d_params &P, float T) { // tau_hypersonic_3d_cuda.cu:206-211
+  float a = P.theta_v / fmaxf(T, 1e-6f);
+  float ea = expf(a);
+  float denom = fmaxf(ea - 1.f, 1e-6f);
+  return (P.R * P.theta_v) / denom;
+}
+static float host_asinh(float x) { // :121-125
+  float ax = fabsf(x);
+  float t = logf(ax + sqrtf(ax * ax + 1.0f));
+  return copysignf(t, x);
+}
+
+extern "C" void tau3d_params_default(tau3d_params *hp, int nx, int ny, int nz) {
+  hp->nx = nx; hp->ny = ny; hp->nz = nz;
+  hp->dx = 1.f / nx; hp->dy = 1.f / ny; hp->dz = 1.f / nz;
+  hp->cfl = 0.3333f; hp->u_ref = 10.f; hp->R = 10.f; hp->gamma_floor = 1.1f;
+  hp->Twall = 0.02f; hp->tau_vib = 2e-4f; hp->theta_v = 0.2f;
+  hp->sdf_cx = 0.5f; hp->sdf_cy = 0.5f; hp->sdf_cz = 0.5f; hp->sdf_r = 0.25f;
+  hp->inflow_r = 0.02f; hp->inflow_p = 0.02f;
+  hp->inflow_u = 100.0f; hp->inflow_v = 0.0f; hp->inflow_w = 0.0f;
+  hp->sponge_n = 24; hp->sponge_strength = 0.05f;
+  hp->sponge_out_n = 24; hp->sponge_out_strength = 0.05f;
+}
+
+static void fill_consts(tau3d *h) {
+  const tau3d_params &P = h->p;
+  h3d::Args &A = h->base;
+  memset(&A, 0, sizeof(A));
+  A.nx = P.nx; A.ny = P.ny; A.nz = P.nz; A.nzl = h->nzl; A.z0 = h->z0;
+  A.dx = P.dx; A.dy = P.dy; A.dz = P.dz;
+  A.inv_dx = 1.f / P.dx; A.inv_dy = 1.f / P.dy; A.inv_dz = 1.f / P.dz;
+  A.u_ref = P.u_ref; A.inv_u_ref = 1.f / P.u_ref; A.R = P.R; A.gamma = P.gamma_floor;
+  A.gm1 = P.gamma_floor - 1.f; A.Twall = P.Twall; A.theta_v = P.theta_v; A.Rtheta = P.R * P.theta_v;
+  A.inv_tau_vib = 1.f / fmaxf(P.tau_vib, 1e-9f);
+  A.sdf_cx = P.sdf_cx; A.sdf_cy = P.sdf_cy; A.sdf_cz = P.sdf_cz; A.sdf_r = P.sdf_r;
+  A.in_r = fmaxf(P.inflow_r, 1e-30f); A.in_p = fmaxf(P.inflow_p, 1e-30f);
+  A.in_u = P.inflow_u; A.in_v = P.inflow_v; A.in_w = P.inflow_w;
+  A.in_ev = host_evib_eq(P, A.in_p / (A.in_r * P.R));
+  A.sponge_n = P.sponge_n > 0 ? P.sponge_n : 0; A.sponge_out_n = P.sponge_out_n > 0 ? P.sponge_out_n : 0;
+  A.sponge_strength = P.sponge_strength; A.sponge_out_strength = P.sponge_out_strength;
+  A.solid = h->solid; A.clk = h->clk;
+  A.ntx = (P.nx + h3d::TX - 1) / h3d::TX; A.nty = (P.ny + h3d::TY - 1) / h3d::TY;
+}
+
+extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nzl, int device, void *stream) {
+  if (!out || !p) return tau::fail("tau3d_create: null argument");
+  if (p->nx < 8 || p->ny < 8 || p->nz < 8) return tau::fail("tau3d_create: grid must be at least 8^3");
+  if (nzl < 2 * h3d::HALO || z0 < 0 || z0 + nzl > p->nz)
+    return tau::fail("tau3d_create: slab [%d,%d) invalid for nz=%d (need >= 6 planes)", z0, z0 + nzl, p->nz);
+  TAU_HIP(hipSetDevice(device));
+  tau3d *h = new (std::nothrow) tau3d();
+  if (!h) return tau::fail("tau3d_create: out of host memory");
+  h->p = *p; h->z0 = z0; h->nzl = nzl; h->device = device; h->cur = 0;
+  h->plane_n = (size_t)p->nx * p->ny;
+  h->field_n = h->plane_n * (size_t)(nzl + 2 * h3d::HALO);
+  h->own_stream = (stream == nullptr);
+  if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  else h->stream = (hipStream_t)stream;
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < 6; f++) TAU_HIP(hipMalloc(&h->buf[s][f], h->field_n * sizeof(float)));
+  TAU_HIP(hipMalloc(&h->solid, h->field_n));
+  TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
+  h->zchunk = 32;
+  fill_consts(h);
+  tau3d_clock c = {1e-5f, 1e-3f, 0.f, 0.f, 0.f, 0};
+  *out = h;
+  return tau3d_set_clock(h, &c);
+}
+
+extern "C" void tau3d_destroy(tau3d_t *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < 6; f++) hipFree(h->buf[s][f]);
+  hipFree(h->solid);
+  hipFree(h->clk);
+  if (h->own_stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in) {
+  h3d::DevClock c;
+  c.t = in->t; c.d_tau = in->d_tau; c.dt = in->dt; c.gain = in->gain; c.maxs_last = in->maxs;
+  c.step = in->step; c.maxs_bits = 0u; c.cfl = h->p.cfl;
+  TAU_HIP(hipMemcpyAsync(h->clk, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int tau3d_get_clock(tau3d_t *h, tau3d_clock *out) {
+  h3d::DevClock c;
+  TAU_HIP(hipMemcpyAsync(&c, h->clk, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  out->t = c.t; out->d_tau = c.d_tau; out->dt = c.dt; out->gain = c.gain; out->maxs = c.maxs_last; out->step = c.step;
+  return 0;
+}
+
+extern "C" int tau3d_init(tau3d_t *h, int mode) {
+  TAU_HIP(hipSetDevice(h->device));
+  const tau3d_params &P = h->p;
+  hipLaunchKernelGGL(h3d::k_build_solid, dim3(1024), dim3(256), 0, h->stream, h->solid, h->base);
+  TAU_LAUNCH_CHECK("k_build_solid");
+  // encoded cell values with host libm (identical to what the reference's k_init encodes up to
+  // __logf vs logf): fluid = inflow rho,p at rest (mode 0) or full inflow state (mode 1)
+  h3d::InitVals iv;
+  float r = fmaxf(P.inflow_r, 1e-30f), p = fmaxf(P.inflow_p, 1e-30f);
+  float ev = host_evib_eq(P, p / (r * P.R));
+  float u = mode ? P.inflow_u : 0.f, v = mode ? P.inflow_v : 0.f, w = mode ? P.inflow_w : 0.f;
+  iv.f[0] = logf(fmaxf(r, 1e-30f)); iv.f[1] = host_asinh(u / P.u_ref); iv.f[2] = host_asinh(v / P.u_ref);
+  iv.f[3] = host_asinh(w / P.u_ref); iv.f[4] = logf(fmaxf(p, 1e-30f)); iv.f[5] = logf(fmaxf(ev, 1e-30f));
+  float rs = fmaxf(p / (P.R * fmaxf(P.Twall, 1e-6f)), 1e-30f);
+  float evs = host_evib_eq(P, P.Twall);
+  iv.s[0] = logf(fmaxf(rs, 1e-30f)); iv.s[1] = host_asinh(0.f); iv.s[2] = host_asinh(0.f); iv.s[3] = host_asinh(0.f);
+  iv.s[4] = logf(fmaxf(p, 1e-30f)); iv.s[5] = logf(fmaxf(evs, 1e-30f));
+  float **b = h->buf[h->cur];
+  hipLaunchKernelGGL(h3d::k_init, dim3(2048), dim3(256), 0, h->stream, h->base, b[0], b[1], b[2], b[3], b[4], b[5],
+                     (const uint8_t *)h->solid, iv);
+  TAU_LAUNCH_CHECK("k_init");
+  tau3d_clock c = {1e-5f, 1e-3f, 0.f, 0.f, 0.f, 0};
+  return tau3d_set_clock(h, &c);
+}
+
+extern "C" int tau3d_upload_state(tau3d_t *h, const float *const host[6]) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t n = h->plane_n * (size_t)h->nzl;
+  for (int f = 0; f < 6; f++)
+    TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f] + h3d::HALO * h->plane_n, host[f], n * sizeof(float),
+                           hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tau3d_download_state(tau3d_t *h, float *const host[6]) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t n = h->plane_n * (size_t)h->nzl;
+  for (int f = 0; f < 6; f++)
+    TAU_HIP(hipMemcpyAsync(host[f], h->buf[h->cur][f] + h3d::HALO * h->plane_n, n * sizeof(float),
+                           hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tau3d_download_solid(tau3d_t *h, uint8_t *host) {
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipMemcpyAsync(host, h->solid + h3d::HALO * h->plane_n, h->plane_n * (size_t)h->nzl,
+                         hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int planes_copy(tau3d_t *h, int zl_lo, int zl_hi, const float *const up[6], float *const down[6]) {
+  if (zl_lo < -h3d::HALO || zl_hi > h->nzl + h3d::HALO || zl_lo >= zl_hi)
+    return tau::fail("tau3d planes: range [%d,%d) outside [-3,%d)", zl_lo, zl_hi, h->nzl + 3);
+  TAU_HIP(hipSetDevice(h->device));
+  size_t off = (size_t)(zl_lo + h3d::HALO) * h->plane_n, n = (size_t)(zl_hi - zl_lo) * h->plane_n * sizeof(float);
+  for (int f = 0; f < 6; f++) {
+    if (up) TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f] + off, up[f], n, hipMemcpyHostToDevice, h->stream));
+    else TAU_HIP(hipMemcpyAsync(down[f], h->buf[h->cur][f] + off, n, hipMemcpyDeviceToHost, h->stream));
+  }
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tau3d_upload_planes(tau3d_t *h, int zl_lo, int zl_hi, const float *const host[6]) {
+  return planes_copy(h, zl_lo, zl_hi, host, nullptr);
+}
+extern "C" int tau3d_download_planes(tau3d_t *h, int zl_lo, int zl_hi, float *const host[6]) {
+  return planes_copy(h, zl_lo, zl_hi, nullptr, host);
+}
+extern "C" int tau3d_state_ptrs(tau3d_t *h, float *dptr[6], uint8_t **solid) {
+  for (int f = 0; f < 6; f++) dptr[f] = h->buf[h->cur][f] + h3d::HALO * h->plane_n;
+  if (solid) *solid = h->solid + h3d::HALO * h->plane_n;
+  return 0;
+}
+
+extern "C" int tau3d_fill_halo_periodic_async(tau3d_t *h) {
+  h3d::HaloArgs H;
+  for (int f = 0; f < 6; f++) H.f[f] = h->buf[h->cur][f];
+  H.plane_n = h->plane_n; H.nzl = h->nzl;
+  hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, 12), dim3(256), 0, h->stream, H);
+  TAU_LAUNCH_CHECK("k_halo_periodic");
+  return 0;
+}
+
+extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *stream) {
+  if (zl_lo < 0 || zl_hi > h->nzl || zl_lo >= zl_hi) return tau::fail("tau3d_step_range: bad plane range [%d,%d)", zl_lo, zl_hi);
+  h3d::Args A = h->base;
+  for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
+  A.zl_lo = zl_lo; A.zl_hi = zl_hi;
+  int nplanes = zl_hi - zl_lo;
+  A.zchunk = h->zchunk < nplanes ? h->zchunk : nplanes;
+  A.nzc = (nplanes + A.zchunk - 1) / A.zchunk;
+  unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  hipLaunchKernelGGL(h3d::k_step, dim3(nb), dim3(h3d::NT), 0, s, A);
+  TAU_LAUNCH_CHECK("k_step");
+  return 0;
+}
+
+extern "C" int tau3d_clock_begin_async(tau3d_t *h) {
+  hipLaunchKernelGGL(h3d::k_clock_begin, dim3(1), dim3(1), 0, h->stream, h->clk);
+  TAU_LAUNCH_CHECK("k_clock_begin");
+  return 0;
+}
+extern "C" int tau3d_clock_end_async(tau3d_t *h) {
+  hipLaunchKernelGGL(h3d::k_clock_end, dim3(1), dim3(1), 0, h->stream, h->clk);
+  TAU_LAUNCH_CHECK("k_clock_end");
+  h->cur ^= 1; // std::swap x6, :1706-1711
+  return 0;
+}
+
+extern "C" int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out) {
+  if (h->nzl != h->p.nz) return tau::fail("tau3d_step: single-domain call on a slab handle (use the *_async pieces)");
+  TAU_HIP(hipSetDevice(h->device));
+  for (int s = 0; s < nsteps; s++) {
+    if (tau3d_clock_begin_async(h)) return 1;
+    if (tau3d_fill_halo_periodic_async(h)) return 1;
+    if (tau3d_step_range_async(h, 0, h->nzl, nullptr)) return 1;
+    if (tau3d_clock_end_async(h)) return 1;
+  }
+  if (out) return tau3d_get_clock(h, out);
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int tau3d_step_explicit(tau3d_t *h, float dt, float inflow_gain, float *maxs) {
+  if (h->nzl != h->p.nz) return tau::fail("tau3d_step_explicit: single-domain call on a slab handle");
+  TAU_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(h3d::k_clock_set_explicit, dim3(1), dim3(1), 0, h->stream, h->clk, dt, inflow_gain);
+  TAU_LAUNCH_CHECK("k_clock_set_explicit");
+  if (tau3d_fill_halo_periodic_async(h)) return 1;
+  if (tau3d_step_range_async(h, 0, h->nzl, nullptr)) return 1;
+  h->cur ^= 1;
+  h3d::DevClock c;
+  TAU_HIP(hipMemcpyAsync(&c, h->clk, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  if (maxs) { memcpy(maxs, &c.maxs_bits, 4); }
+  return 0;
+}
+
+extern "C" int tau3d_halo_send_ptr(tau3d_t *h, int which, int field, int side, float **p) {
+  if (field < 0 || field > 5 || !p) return tau::fail("tau3d_halo_send_ptr: bad argument");
+  float *b = h->buf[h->cur ^ (which & 1)][field];
+  *p = side == 0 ? b + (size_t)h3d::HALO * h->plane_n : b + (size_t)h->nzl * h->plane_n;
+  return 0;
+}
+extern "C" int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p) {
+  if (field < 0 || field > 5 || !p) return tau::fail("tau3d_halo_recv_ptr: bad argument");
+  float *b = h->buf[h->cur ^ (which & 1)][field];
+  *p = side == 0 ? b : b + (size_t)(h->nzl + h3d::HALO) * h->plane_n;
+  return 0;
+}
+extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {
+  *p = reinterpret_cast<float *>(&h->clk->maxs_bits);
+  return 0;
+}
+extern "C" int tau3d_sync(tau3d_t *h) {
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}

@@ -1,0 +1,358 @@
+// stencil2d.hip — periodic 5-point-Laplacian steps for gfx950 (MI355X):
+//   Gray-Scott reaction-diffusion        (tau_gray_scott.cu:141-171)
+//   Burgers viscosity pass               (tau_burgers.cu:490-525)   — race-free ping-pong form
+//   shallow-water viscosity pass         (tau_shallow_water.cu:516-547) — race-free ping-pong form
+//
+// All three are two fp32 fields in, two out, 16 B/cell of compulsory HBM traffic — HBM bound.
+// CDNA4 layout: a wave64 owns a 256-column strip (one float4 per lane = 1 KiB per load
+// instruction) and MARCHES down the rows keeping the three live rows in VGPRs, so every
+// row is fetched once per strip; left/right neighbours come from the adjacent lane
+// (wave shuffle), only the two edge lanes of a strip issue an extra scalar load.  No LDS, no
+// integer modulo per cell (the reference wraps every index with %; here only strip edges and
+// chunk edges wrap, on scalar registers).
+//
+// This file is compiled with -ffp-contract=off and IEEE division so that Gray-Scott and the
+// shallow-water pass are BIT-EXACT against the oracle's arithmetic order.
+
+#include "../../include/taueng.h"
+#include "tau_common.h"
+#include <cmath>
+#include <new>
+#include <vector>
+
+namespace st2 {
+
+constexpr int ROWS = 32;        // rows marched by one wave
+constexpr int WAVES = 4;        // waves per workgroup
+enum { K_GS = 0, K_BURGERS = 1, K_SW = 2 };
+
+struct Args {
+  const float *a, *b;
+  float *oa, *ob;
+  int nx, ny;
+  int nstrips, nchunks;
+  // Gray-Scott
+  float dx2, dt, Du, Dv, feed, kill;
+  // Laplacian passes
+  float invdx2, invdy2, nudt, u0, inv_u0;
+};
+
+// -------- transcendental pair for the Burgers encoding, accurate to ~1e-7 relative
+__device__ __forceinline__ float fsinh(float x) {
+  float ax = fabsf(x);
+  float x2 = x * x;
+  float series = x * (1.f + x2 * (1.f / 6.f) * (1.f + x2 * (1.f / 20.f) * (1.f + x2 * (1.f / 42.f))));
+  float e = __builtin_amdgcn_exp2f(ax * 1.44269504088896341f);
+  float big = copysignf(0.5f * (e - __builtin_amdgcn_rcpf(e)), x);
+  return (ax < 0.5f) ? series : big;
+}
+__device__ __forceinline__ float fasinh(float x) {
+  float ax = fabsf(x);
+  float x2 = x * x;
+  // x - x^3/6 + 3x^5/40 - 15x^7/336 + 105x^9/3456
+  float series = ax * (1.f + x2 * (-1.f / 6.f + x2 * (3.f / 40.f + x2 * (-15.f / 336.f + x2 * (105.f / 3456.f)))));
+  float big = __builtin_amdgcn_logf(ax + __builtin_amdgcn_sqrtf(x2 + 1.0f)) * 0.69314718055994531f;
+  return copysignf((ax < 0.125f) ? series : big, x);
+}
+
+struct Row {
+  float4 a, b;     // the lane's four cells of both fields
+  float al, ar;    // strip-edge neighbours (valid on the edge lanes only)
+  float bl, br;
+};
+
+template <int KIND>
+__device__ __forceinline__ void load_row(const Args &A, int j, int x4, int xl, int xr, bool act, bool first, bool last,
+                                         Row &r) {
+  if (act) {
+    const size_t base = (size_t)j * A.nx;
+    r.a = *reinterpret_cast<const float4 *>(A.a + base + x4);
+    r.b = *reinterpret_cast<const float4 *>(A.b + base + x4);
+    r.al = first ? A.a[base + xl] : 0.f;
+    r.bl = first ? A.b[base + xl] : 0.f;
+    r.ar = last ? A.a[base + xr] : 0.f;
+    r.br = last ? A.b[base + xr] : 0.f;
+    if (KIND == K_BURGERS) { // decode once per fetched value: u = u0*sinh(phi), :503-506
+      r.a.x = A.u0 * fsinh(r.a.x); r.a.y = A.u0 * fsinh(r.a.y); r.a.z = A.u0 * fsinh(r.a.z); r.a.w = A.u0 * fsinh(r.a.w);
+      r.b.x = A.u0 * fsinh(r.b.x); r.b.y = A.u0 * fsinh(r.b.y); r.b.z = A.u0 * fsinh(r.b.z); r.b.w = A.u0 * fsinh(r.b.w);
+      r.al = A.u0 * fsinh(r.al); r.ar = A.u0 * fsinh(r.ar); r.bl = A.u0 * fsinh(r.bl); r.br = A.u0 * fsinh(r.br);
+    }
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void cell(const Args &A, float uc, float ul, float ur, float uu, float ud, float vc, float vl,
+                                     float vr, float vu, float vd, float &uo, float &vo) {
+  if (KIND == K_GS) { // tau_gray_scott.cu:155-170, same association order
+    float lap_u = (ur + ul + ud + uu - 4.0f * uc) / A.dx2;
+    float lap_v = (vr + vl + vd + vu - 4.0f * vc) / A.dx2;
+    float uvv = uc * vc * vc;
+    float du = A.Du * lap_u - uvv + A.feed * (1.0f - uc);
+    float dv = A.Dv * lap_v + uvv - (A.feed + A.kill) * vc;
+    uo = uc + A.dt * du;
+    vo = vc + A.dt * dv;
+  } else { // tau_shallow_water.cu:531-546 / tau_burgers.cu:513-521
+    float du = (ur - 2.0f * uc + ul) * A.invdx2 + (ud - 2.0f * uc + uu) * A.invdy2;
+    float dv = (vr - 2.0f * vc + vl) * A.invdx2 + (vd - 2.0f * vc + vu) * A.invdy2;
+    uo = uc + A.nudt * du;
+    vo = vc + A.nudt * dv;
+    if (KIND == K_BURGERS) { uo = fasinh(uo * A.inv_u0); vo = fasinh(vo * A.inv_u0); }
+  }
+}
+
+// "ud" above is the row j+1 (the reference's jp), "uu" the row j-1 (jm).
+template <int KIND>
+__global__ __launch_bounds__(64 * WAVES) void k_march(const Args A) {
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
+  unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * WAVES + (threadIdx.x >> 6);
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)A.nstrips);
+  const int chunk = (int)(wid / (unsigned)A.nstrips);
+  const int x4 = (strip * 64 + lane) * 4;
+  const bool act = x4 < A.nx;
+  const int nl = min(64, (A.nx - strip * 256) >> 2); // active lanes in this strip
+  const bool first = lane == 0, last = lane == nl - 1;
+  const int xl = (strip * 256 - 1 + A.nx) % A.nx;     // scalar (wave-uniform)
+  const int xr = (strip * 256 + nl * 4) % A.nx;
+  const int j0 = chunk * ROWS;
+  const int j1 = min(j0 + ROWS, A.ny);
+
+  Row up, cur, dn;
+  load_row<KIND>(A, (j0 - 1 + A.ny) % A.ny, x4, xl, xr, act, first, last, up);
+  load_row<KIND>(A, j0, x4, xl, xr, act, first, last, cur);
+  load_row<KIND>(A, (j0 + 1) % A.ny, x4, xl, xr, act, first, last, dn);
+
+  for (int j = j0; j < j1; j++) {
+    Row nx2;
+    const int jn = (j + 2 < A.ny) ? j + 2 : j + 2 - A.ny;
+    if (j + 1 < j1) load_row<KIND>(A, jn, x4, xl, xr, act, first, last, nx2); // prefetch row j+2
+
+    // neighbours across lanes (all lanes execute the shuffles)
+    float al = __shfl_up(cur.a.w, 1, 64), ar = __shfl_down(cur.a.x, 1, 64);
+    float bl = __shfl_up(cur.b.w, 1, 64), br = __shfl_down(cur.b.x, 1, 64);
+    if (first) { al = cur.al; bl = cur.bl; }
+    if (last) { ar = cur.ar; br = cur.br; }
+
+    if (act) {
+      float4 oa, ob;
+      cell<KIND>(A, cur.a.x, al, cur.a.y, up.a.x, dn.a.x, cur.b.x, bl, cur.b.y, up.b.x, dn.b.x, oa.x, ob.x);
+      cell<KIND>(A, cur.a.y, cur.a.x, cur.a.z, up.a.y, dn.a.y, cur.b.y, cur.b.x, cur.b.z, up.b.y, dn.b.y, oa.y, ob.y);
+      cell<KIND>(A, cur.a.z, cur.a.y, cur.a.w, up.a.z, dn.a.z, cur.b.z, cur.b.y, cur.b.w, up.b.z, dn.b.z, oa.z, ob.z);
+      cell<KIND>(A, cur.a.w, cur.a.z, ar, up.a.w, dn.a.w, cur.b.w, cur.b.z, br, up.b.w, dn.b.w, oa.w, ob.w);
+      const size_t o = (size_t)j * A.nx + x4;
+      *reinterpret_cast<float4 *>(A.oa + o) = oa;
+      *reinterpret_cast<float4 *>(A.ob + o) = ob;
+    }
+    up = cur; cur = dn; dn = nx2;
+  }
+}
+
+// any nx (not a multiple of 4): one thread per cell, wraps on index compare (no %)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_simple(const Args A) {
+  const int i = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int j = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (i >= A.nx || j >= A.ny) return;
+  const int ip = (i + 1 == A.nx) ? 0 : i + 1, im = (i == 0) ? A.nx - 1 : i - 1;
+  const int jp = (j + 1 == A.ny) ? 0 : j + 1, jm = (j == 0) ? A.ny - 1 : j - 1;
+  auto ld = [&](const float *f, int jj, int ii) {
+    float v = f[(size_t)jj * A.nx + ii];
+    return (KIND == K_BURGERS) ? A.u0 * fsinh(v) : v;
+  };
+  float uo, vo;
+  cell<KIND>(A, ld(A.a, j, i), ld(A.a, j, im), ld(A.a, j, ip), ld(A.a, jm, i), ld(A.a, jp, i), ld(A.b, j, i),
+             ld(A.b, j, im), ld(A.b, j, ip), ld(A.b, jm, i), ld(A.b, jp, i), uo, vo);
+  A.oa[(size_t)j * A.nx + i] = uo;
+  A.ob[(size_t)j * A.nx + i] = vo;
+}
+
+template <int KIND>
+static int launch(const Args &Ain, hipStream_t s) {
+  Args A = Ain;
+  if ((A.nx & 3) == 0) {
+    A.nstrips = (A.nx + 255) / 256;
+    A.nchunks = (A.ny + ROWS - 1) / ROWS;
+    unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
+    unsigned nb = (nwork + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL(k_march<KIND>, dim3(nb), dim3(64 * WAVES), 0, s, A);
+  } else {
+    hipLaunchKernelGGL(k_simple<KIND>, dim3((A.nx + 63) / 64, (A.ny + 3) / 4), dim3(256), 0, s, A);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return tau::fail("stencil2d launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+struct Pair {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  int nx, ny;
+  float *buf[2][2];
+  int cur;
+};
+
+static int pair_create(Pair *h, int nx, int ny, int device, void *stream) {
+  if (nx < 2 || ny < 2) return tau::fail("stencil2d: grid must be at least 2x2");
+  TAU_HIP(hipSetDevice(device));
+  h->device = device; h->nx = nx; h->ny = ny; h->cur = 0;
+  h->own_stream = (stream == nullptr);
+  if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  else h->stream = (hipStream_t)stream;
+  size_t bytes = (size_t)nx * ny * sizeof(float);
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < 2; f++) TAU_HIP(hipMalloc(&h->buf[s][f], bytes));
+  return 0;
+}
+static void pair_destroy(Pair *h) {
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < 2; f++) hipFree(h->buf[s][f]);
+  if (h->own_stream) hipStreamDestroy(h->stream);
+}
+static int pair_upload(Pair *h, const float *a, const float *b) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t bytes = (size_t)h->nx * h->ny * sizeof(float);
+  TAU_HIP(hipMemcpyAsync(h->buf[h->cur][0], a, bytes, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipMemcpyAsync(h->buf[h->cur][1], b, bytes, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+static int pair_download(Pair *h, float *a, float *b) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t bytes = (size_t)h->nx * h->ny * sizeof(float);
+  TAU_HIP(hipMemcpyAsync(a, h->buf[h->cur][0], bytes, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipMemcpyAsync(b, h->buf[h->cur][1], bytes, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+} // namespace st2
+
+// =====================================================================================
+// Gray-Scott C-ABI
+// =====================================================================================
+struct taugs {
+  st2::Pair pr;
+  taugs_params p;
+};
+
+extern "C" void taugs_params_default(taugs_params *P, int nx, int ny) { // tau_gray_scott.cu:43-61
+  P->nx = nx; P->ny = ny; P->dx = 1.0f; P->dt = 1.0f;
+  P->Du = 0.2f; P->Dv = 0.1f; P->feed = 0.03f; P->kill = 0.06f;
+}
+extern "C" int taugs_create(taugs_t **out, const taugs_params *p, int device, void *stream) {
+  if (!out || !p) return tau::fail("taugs_create: null argument");
+  taugs *h = new (std::nothrow) taugs();
+  if (!h) return tau::fail("taugs_create: out of host memory");
+  h->p = *p;
+  if (st2::pair_create(&h->pr, p->nx, p->ny, device, stream)) { delete h; return 1; }
+  *out = h;
+  return 0;
+}
+extern "C" void taugs_destroy(taugs_t *h) { if (h) { st2::pair_destroy(&h->pr); delete h; } }
+
+extern "C" int taugs_init_pattern(taugs_t *h, uint32_t seed) { // init_pattern, :173-204 (host) + H2D :308-309
+  const int nx = h->p.nx, ny = h->p.ny;
+  std::vector<float> u((size_t)nx * ny, 1.0f), v((size_t)nx * ny, 0.0f);
+  const int cx = nx / 2, cy = ny / 2, r = (nx < ny ? nx : ny) / 12;
+  for (int j = -r; j <= r; ++j)
+    for (int i = -r; i <= r; ++i) {
+      int x = (cx + i + nx) % nx, y = (cy + j + ny) % ny;
+      u[(size_t)y * nx + x] = 0.50f;
+      v[(size_t)y * nx + x] = 0.25f;
+    }
+  uint32_t state = seed ? seed : 1u;
+  auto rng = [&]() { state ^= state << 13; state ^= state >> 17; state ^= state << 5; return state; };
+  for (int n = 0; n < 64; ++n) {
+    int x = (int)(rng() % (uint32_t)nx);
+    int y = (int)(rng() % (uint32_t)ny);
+    u[(size_t)y * nx + x] = 0.35f;
+    v[(size_t)y * nx + x] = 0.65f;
+  }
+  return st2::pair_upload(&h->pr, u.data(), v.data());
+}
+extern "C" int taugs_upload(taugs_t *h, const float *u, const float *v) { return st2::pair_upload(&h->pr, u, v); }
+extern "C" int taugs_download(taugs_t *h, float *u, float *v) { return st2::pair_download(&h->pr, u, v); }
+extern "C" int taugs_state_ptrs(taugs_t *h, float **u, float **v) {
+  *u = h->pr.buf[h->pr.cur][0]; *v = h->pr.buf[h->pr.cur][1];
+  return 0;
+}
+extern "C" int taugs_step_async(taugs_t *h, int nsteps) {
+  TAU_HIP(hipSetDevice(h->pr.device));
+  st2::Args A{};
+  A.nx = h->p.nx; A.ny = h->p.ny;
+  A.dx2 = h->p.dx * h->p.dx; A.dt = h->p.dt; A.Du = h->p.Du; A.Dv = h->p.Dv; A.feed = h->p.feed; A.kill = h->p.kill;
+  for (int s = 0; s < nsteps; s++) {
+    A.a = h->pr.buf[h->pr.cur][0]; A.b = h->pr.buf[h->pr.cur][1];
+    A.oa = h->pr.buf[h->pr.cur ^ 1][0]; A.ob = h->pr.buf[h->pr.cur ^ 1][1];
+    if (st2::launch<st2::K_GS>(A, h->pr.stream)) return 1;
+    h->pr.cur ^= 1; // std::swap, :327-328
+  }
+  return 0;
+}
+extern "C" int taugs_sync(taugs_t *h) {
+  TAU_HIP(hipSetDevice(h->pr.device));
+  TAU_HIP(hipStreamSynchronize(h->pr.stream));
+  return 0;
+}
+extern "C" int taugs_step(taugs_t *h, int nsteps) {
+  if (taugs_step_async(h, nsteps)) return 1;
+  return taugs_sync(h);
+}
+
+// =====================================================================================
+// Laplacian viscosity passes C-ABI
+// =====================================================================================
+struct taulap {
+  st2::Pair pr;
+  taulap_params p;
+  int kind, oneD;
+};
+
+extern "C" int taulap_create(taulap_t **out, const taulap_params *p, int kind, int oneD, int device, void *stream) {
+  if (!out || !p) return tau::fail("taulap_create: null argument");
+  if (kind != 0 && kind != 1) return tau::fail("taulap_create: kind must be 0 (Burgers) or 1 (shallow water)");
+  taulap *h = new (std::nothrow) taulap();
+  if (!h) return tau::fail("taulap_create: out of host memory");
+  h->p = *p; h->kind = kind; h->oneD = oneD;
+  if (st2::pair_create(&h->pr, p->nx, p->ny, device, stream)) { delete h; return 1; }
+  *out = h;
+  return 0;
+}
+extern "C" void taulap_destroy(taulap_t *h) { if (h) { st2::pair_destroy(&h->pr); delete h; } }
+extern "C" int taulap_upload(taulap_t *h, const float *a, const float *b) { return st2::pair_upload(&h->pr, a, b); }
+extern "C" int taulap_download(taulap_t *h, float *a, float *b) { return st2::pair_download(&h->pr, a, b); }
+extern "C" int taulap_state_ptrs(taulap_t *h, float **a, float **b) {
+  *a = h->pr.buf[h->pr.cur][0]; *b = h->pr.buf[h->pr.cur][1];
+  return 0;
+}
+extern "C" int taulap_set_dt(taulap_t *h, float dt) { h->p.dt = dt; return 0; }
+extern "C" int taulap_step_async(taulap_t *h, int npasses) {
+  TAU_HIP(hipSetDevice(h->pr.device));
+  st2::Args A{};
+  A.nx = h->p.nx; A.ny = h->p.ny;
+  A.invdx2 = 1.0f / (h->p.dx * h->p.dx);
+  A.invdy2 = (h->kind == 0 && h->oneD) ? 0.0f : 1.0f / (h->p.dy * h->p.dy);
+  A.nudt = h->p.nu * h->p.dt;
+  A.u0 = h->p.u0; A.inv_u0 = 1.0f / h->p.u0;
+  for (int s = 0; s < npasses; s++) {
+    A.a = h->pr.buf[h->pr.cur][0]; A.b = h->pr.buf[h->pr.cur][1];
+    A.oa = h->pr.buf[h->pr.cur ^ 1][0]; A.ob = h->pr.buf[h->pr.cur ^ 1][1];
+    int rc = (h->kind == 0) ? st2::launch<st2::K_BURGERS>(A, h->pr.stream) : st2::launch<st2::K_SW>(A, h->pr.stream);
+    if (rc) return 1;
+    h->pr.cur ^= 1;
+  }
+  return 0;
+}
+extern "C" int taulap_sync(taulap_t *h) {
+  TAU_HIP(hipSetDevice(h->pr.device));
+  TAU_HIP(hipStreamSynchronize(h->pr.stream));
+  return 0;
+}
+extern "C" int taulap_step(taulap_t *h, int npasses) {
+  if (taulap_step_async(h, npasses)) return 1;
+  return taulap_sync(h);
+}

@@ -1,0 +1,322 @@
+"""ctypes binding of libtaueng.so — the host-side mirror of include/taueng.h.
+
+This is plumbing only: every class is a thin handle wrapper whose methods are the C-ABI entry
+points one-to-one.  There is NO CPU fallback here: if the HIP library is missing or no gfx950
+device is visible, construction raises TauError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class TauError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libtaueng.so")
+
+
+_lib = None
+
+
+class Tau3DParams(C.Structure):
+    """tau3d_params (include/tau_params.h) == reference Params, tau_hypersonic_3d_cuda.cu:21-42"""
+    _fields_ = ([("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32)] +
+                [(n, C.c_float) for n in
+                 "dx dy dz cfl u_ref R gamma_floor Twall tau_vib theta_v sdf_cx sdf_cy sdf_cz sdf_r "
+                 "inflow_r inflow_p inflow_u inflow_v inflow_w".split()] +
+                [("sponge_n", C.c_int32), ("sponge_strength", C.c_float),
+                 ("sponge_out_n", C.c_int32), ("sponge_out_strength", C.c_float)])
+
+
+class Tau3DClock(C.Structure):
+    _fields_ = [(n, C.c_float) for n in "t d_tau dt gain maxs".split()] + [("step", C.c_int32)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class GSParams(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dt Du Dv feed kill".split()]
+
+
+class LapParams(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dy nu dt u0".split()]
+
+
+def load():
+    """Load libtaueng.so (raises TauError when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise TauError(f"{p} not found — run `make -C fluid-sims_amd` (or __graft_entry__.build())")
+    L = C.CDLL(p)
+    L.tau_last_error.restype = C.c_char_p
+    vp, i32, f32 = C.c_void_p, C.c_int, C.c_float
+    sig = {
+        "tau_device_available": ([], i32), "tau_version": ([], i32),
+        "tau3d_params_default": ([C.POINTER(Tau3DParams), i32, i32, i32], None),
+        "tau3d_create": ([C.POINTER(vp), C.POINTER(Tau3DParams), i32, i32, i32, vp], i32),
+        "tau3d_destroy": ([vp], None),
+        "tau3d_init": ([vp, i32], i32),
+        "tau3d_upload_state": ([vp, C.POINTER(vp)], i32),
+        "tau3d_download_state": ([vp, C.POINTER(vp)], i32),
+        "tau3d_download_solid": ([vp, vp], i32),
+        "tau3d_upload_planes": ([vp, i32, i32, C.POINTER(vp)], i32),
+        "tau3d_download_planes": ([vp, i32, i32, C.POINTER(vp)], i32),
+        "tau3d_state_ptrs": ([vp, C.POINTER(vp), C.POINTER(vp)], i32),
+        "tau3d_get_clock": ([vp, C.POINTER(Tau3DClock)], i32),
+        "tau3d_set_clock": ([vp, C.POINTER(Tau3DClock)], i32),
+        "tau3d_step": ([vp, i32, C.POINTER(Tau3DClock)], i32),
+        "tau3d_step_explicit": ([vp, f32, f32, C.POINTER(f32)], i32),
+        "tau3d_clock_begin_async": ([vp], i32),
+        "tau3d_step_range_async": ([vp, i32, i32, vp], i32),
+        "tau3d_clock_end_async": ([vp], i32),
+        "tau3d_fill_halo_periodic_async": ([vp], i32),
+        "tau3d_halo_send_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
+        "tau3d_halo_recv_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
+        "tau3d_max_ptr": ([vp, C.POINTER(vp)], i32),
+        "tau3d_sync": ([vp], i32),
+        "taugs_params_default": ([C.POINTER(GSParams), i32, i32], None),
+        "taugs_create": ([C.POINTER(vp), C.POINTER(GSParams), i32, vp], i32),
+        "taugs_destroy": ([vp], None),
+        "taugs_init_pattern": ([vp, C.c_uint32], i32),
+        "taugs_upload": ([vp, vp, vp], i32),
+        "taugs_download": ([vp, vp, vp], i32),
+        "taugs_state_ptrs": ([vp, C.POINTER(vp), C.POINTER(vp)], i32),
+        "taugs_step": ([vp, i32], i32),
+        "taugs_step_async": ([vp, i32], i32),
+        "taugs_sync": ([vp], i32),
+        "taulap_create": ([C.POINTER(vp), C.POINTER(LapParams), i32, i32, i32, vp], i32),
+        "taulap_destroy": ([vp], None),
+        "taulap_upload": ([vp, vp, vp], i32),
+        "taulap_download": ([vp, vp, vp], i32),
+        "taulap_state_ptrs": ([vp, C.POINTER(vp), C.POINTER(vp)], i32),
+        "taulap_set_dt": ([vp, f32], i32),
+        "taulap_step": ([vp, i32], i32),
+        "taulap_step_async": ([vp, i32], i32),
+        "taulap_sync": ([vp], i32),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = res
+    _lib = L
+    return L
+
+
+EXPORTS_3D_2D = None  # filled lazily by tests from include/taueng.h
+
+
+def _ck(rc):
+    if rc != 0:
+        raise TauError(load().tau_last_error().decode())
+
+
+def _require_device():
+    L = load()
+    if not L.tau_device_available():
+        raise TauError("no gfx950 (MI355X) device visible to the HIP runtime — libtaueng has no CPU path")
+    return L
+
+
+def _f32(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a
+
+
+class Tau3D:
+    """3D hypersonic handle (tau3d_*).  Fields: xi, phix, phiy, phiz, lam, zet."""
+
+    def __init__(self, nx, ny=None, nz=None, params=None, z0=0, nzl=None, device=0, stream=None):
+        L = _require_device()
+        ny = nx if ny is None else ny
+        nz = nx if nz is None else nz
+        if params is None:
+            params = Tau3DParams()
+            L.tau3d_params_default(C.byref(params), nx, ny, nz)
+        self.params = params
+        self.nzl = params.nz if nzl is None else nzl
+        self.z0 = z0
+        self._h = C.c_void_p()
+        _ck(L.tau3d_create(C.byref(self._h), C.byref(params), z0, self.nzl, device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tau3d_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def shape(self):
+        return (self.nzl, self.params.ny, self.params.nx)
+
+    def init(self, mode=0):
+        _ck(self._L.tau3d_init(self._h, mode))
+
+    def upload(self, fields):
+        arrs = [_f32(f).reshape(-1) for f in fields]
+        n = int(np.prod(self.shape))
+        assert len(arrs) == 6 and all(a.size == n for a in arrs)
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+        _ck(self._L.tau3d_upload_state(self._h, ptrs))
+
+    def download(self):
+        arrs = [np.empty(self.shape, np.float32) for _ in range(6)]
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+        _ck(self._L.tau3d_download_state(self._h, ptrs))
+        return arrs
+
+    def download_planes(self, lo, hi):
+        shp = (hi - lo, self.params.ny, self.params.nx)
+        arrs = [np.empty(shp, np.float32) for _ in range(6)]
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+        _ck(self._L.tau3d_download_planes(self._h, lo, hi, ptrs))
+        return arrs
+
+    def upload_planes(self, lo, hi, fields):
+        arrs = [_f32(f).reshape(-1) for f in fields]
+        ptrs = (C.c_void_p * 6)(*[a.ctypes.data for a in arrs])
+        _ck(self._L.tau3d_upload_planes(self._h, lo, hi, ptrs))
+
+    def solid(self):
+        s = np.empty(self.shape, np.uint8)
+        _ck(self._L.tau3d_download_solid(self._h, s.ctypes.data))
+        return s
+
+    def clock(self):
+        c = Tau3DClock()
+        _ck(self._L.tau3d_get_clock(self._h, C.byref(c)))
+        return c
+
+    def set_clock(self, t, d_tau, step=0):
+        c = Tau3DClock(t, d_tau, 0.0, 0.0, 0.0, step)
+        _ck(self._L.tau3d_set_clock(self._h, C.byref(c)))
+
+    def step(self, n=1):
+        c = Tau3DClock()
+        _ck(self._L.tau3d_step(self._h, n, C.byref(c)))
+        return c
+
+    def step_explicit(self, dt, gain):
+        m = C.c_float()
+        _ck(self._L.tau3d_step_explicit(self._h, dt, gain, C.byref(m)))
+        return m.value
+
+    # ---- multi-GPU pieces
+    def clock_begin_async(self):
+        _ck(self._L.tau3d_clock_begin_async(self._h))
+
+    def step_range_async(self, lo, hi, stream=None):
+        _ck(self._L.tau3d_step_range_async(self._h, lo, hi, stream))
+
+    def clock_end_async(self):
+        _ck(self._L.tau3d_clock_end_async(self._h))
+
+    def fill_halo_periodic_async(self):
+        _ck(self._L.tau3d_fill_halo_periodic_async(self._h))
+
+    def halo_ptr(self, kind, which, field, side):
+        p = C.c_void_p()
+        fn = self._L.tau3d_halo_send_ptr if kind == "send" else self._L.tau3d_halo_recv_ptr
+        _ck(fn(self._h, which, field, side, C.byref(p)))
+        return p.value
+
+    def max_ptr(self):
+        p = C.c_void_p()
+        _ck(self._L.tau3d_max_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def sync(self):
+        _ck(self._L.tau3d_sync(self._h))
+
+
+class GrayScott:
+    """Gray-Scott handle (taugs_*)."""
+
+    def __init__(self, nx, ny, device=0, stream=None, **kw):
+        L = _require_device()
+        p = GSParams()
+        L.taugs_params_default(C.byref(p), nx, ny)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self.params = p
+        self._h = C.c_void_p()
+        _ck(L.taugs_create(C.byref(self._h), C.byref(p), device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.taugs_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def init_pattern(self, seed=1337):
+        _ck(self._L.taugs_init_pattern(self._h, seed))
+
+    def upload(self, u, v):
+        u, v = _f32(u), _f32(v)
+        _ck(self._L.taugs_upload(self._h, u.ctypes.data, v.ctypes.data))
+
+    def download(self):
+        shp = (self.params.ny, self.params.nx)
+        u, v = np.empty(shp, np.float32), np.empty(shp, np.float32)
+        _ck(self._L.taugs_download(self._h, u.ctypes.data, v.ctypes.data))
+        return u, v
+
+    def step(self, n=1):
+        _ck(self._L.taugs_step(self._h, n))
+
+    def step_async(self, n=1):
+        _ck(self._L.taugs_step_async(self._h, n))
+
+    def sync(self):
+        _ck(self._L.taugs_sync(self._h))
+
+
+class Laplacian2D:
+    """Viscosity pass handle (taulap_*): kind 'burgers' or 'sw'."""
+
+    def __init__(self, nx, ny, kind, nu, dt, dx=1.0, dy=1.0, u0=1.0, oneD=False, device=0, stream=None):
+        L = _require_device()
+        p = LapParams(nx, ny, dx, dy, nu, dt, u0)
+        self.params = p
+        self._h = C.c_void_p()
+        k = {"burgers": 0, "sw": 1}[kind]
+        _ck(L.taulap_create(C.byref(self._h), C.byref(p), k, int(oneD), device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.taulap_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def upload(self, a, b):
+        a, b = _f32(a), _f32(b)
+        _ck(self._L.taulap_upload(self._h, a.ctypes.data, b.ctypes.data))
+
+    def download(self):
+        shp = (self.params.ny, self.params.nx)
+        a, b = np.empty(shp, np.float32), np.empty(shp, np.float32)
+        _ck(self._L.taulap_download(self._h, a.ctypes.data, b.ctypes.data))
+        return a, b
+
+    def step(self, n=1):
+        _ck(self._L.taulap_step(self._h, n))
+
+    def step_async(self, n=1):
+        _ck(self._L.taulap_step_async(self._h, n))
+
+    def sync(self):
+        _ck(self._L.taulap_sync(self._h))

@@ -1,0 +1,139 @@
+/* taueng.h — C-ABI of libtaueng, the MI355X (gfx950) explicit time-stepping engine.
+ *
+ * The reference (seanwevans/fluid-sims) has no library or FFI: every simulator is a
+ * stand-alone program whose `main` owns the device buffers and launches the step
+ * kernels itself.  This header is the seam a reference `main` (or any FFI: cgo, JNI,
+ * ctypes) binds instead of those launches.  Each entry point names the reference
+ * code it replaces (file:line in the reference tree).
+ *
+ * Conventions:
+ *   - opaque handle per simulator; the library owns device buffers, the caller owns
+ *     host buffers; plain pointers and sizes only, no C++/torch types;
+ *   - every function returns 0 on success, non-zero on error; tau_last_error() gives
+ *     the message (the reference prints to stderr and exits: `ck`,
+ *     tau_hypersonic_3d_cuda.cu:62-67 — the thin C drivers reproduce that);
+ *   - state arrays keep the reference layout: row-major y*W+x (2D),
+ *     (z*ny+y)*nx+x (3D), ping-pong by pointer swap inside the handle;
+ *   - a call is synchronous-looking to the caller unless its name ends in _async;
+ *     all work of a handle runs on that handle's stream.
+ */
+#ifndef TAUENG_H
+#define TAUENG_H
+
+#include "tau_params.h"
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *tau_last_error(void);
+/* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never fails) */
+int tau_device_available(void);
+int tau_version(void);
+
+/* =====================================================================
+ * 3D two-temperature hypersonic Euler — replaces the launches in
+ * tau_hypersonic_3d_cuda.cu:1559-1605 (setup) and :1678-1713 (step loop).
+ *
+ * Z-slab form: a handle owns local planes [z0, z0+nzl) of the global nz
+ * (nzl = nz, z0 = 0 for a single GPU) plus a 3-plane halo on each side
+ * (WENO_HALO, :58).  Field f of the state is one contiguous device array of
+ * (nzl+6)*ny*nx floats, halo planes first; tau3d_state_ptrs() returns the
+ * pointer to local plane 0, i.e. the reference's (z*ny+y)*nx+x array.
+ * Field order: xi, phix, phiy, phiz, lam, zet (:1564-1565).
+ * ===================================================================== */
+typedef struct tau3d tau3d_t;
+
+void tau3d_params_default(tau3d_params *p, int nx, int ny, int nz); /* :1531-1557 */
+
+/* alloc + constants upload (replaces cudaMalloc x14 + cudaMemcpyToSymbol(P), :1559-1589).
+ * stream: a hipStream_t to run on, or NULL for a private stream. */
+int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nzl, int device, void *stream);
+void tau3d_destroy(tau3d_t *h);
+
+/* k_build_solid_mask + k_init (:1601-1605); resets the clock to t=1e-5, d_tau=1e-3 (:1635-1636).
+ * mode 0 = reference quiescent start; mode 1 = synthetic developed flow (every fluid cell at
+ * the full inflow state, SURVEY §8d input (ii)). */
+int tau3d_init(tau3d_t *h, int mode);
+
+/* host <-> device copies of the nzl interior planes, reference layout, 6 fields */
+int tau3d_upload_state(tau3d_t *h, const float *const host[6]);
+int tau3d_download_state(tau3d_t *h, float *const host[6]);
+int tau3d_download_solid(tau3d_t *h, uint8_t *host);
+/* same for a range of local planes [zl_lo, zl_hi), halo planes allowed: -3 <= zl_lo < zl_hi <= nzl+3 */
+int tau3d_upload_planes(tau3d_t *h, int zl_lo, int zl_hi, const float *const host[6]);
+int tau3d_download_planes(tau3d_t *h, int zl_lo, int zl_hi, float *const host[6]);
+
+/* device pointers (current ping-pong side): interior plane 0 of each field, the solid
+ * mask (interior plane 0) and the device clock block */
+int tau3d_state_ptrs(tau3d_t *h, float *dptr[6], uint8_t **solid);
+
+int tau3d_get_clock(tau3d_t *h, tau3d_clock *out);
+int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in);
+
+/* n full steps = the reference loop body :1680-1711 (log-time clock, k_step, d_tau
+ * controller, swap), single domain only (nzl == nz): halos are filled periodically on
+ * device.  The controller runs on the device — no per-step host round trip. */
+int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out);
+
+/* One k_step launch with an explicit dt / inflow_gain (the kernel call at :1689-1691 alone),
+ * for parity tests: halos periodic (single domain), result swapped in, *maxs = max wavespeed. */
+int tau3d_step_explicit(tau3d_t *h, float dt, float inflow_gain, float *maxs);
+
+/* ---- multi-GPU pieces (no reference counterpart: SURVEY §8e).  One step on rank r is
+ *   tau3d_clock_begin_async            t*=exp(d_tau), dt, gain; zero the max word
+ *   tau3d_step_range_async(edges)      planes [0,3) and [nzl-3,nzl) — need the halos
+ *   <caller: exchange tau3d_halo_send_ptr -> neighbour's tau3d_halo_recv_ptr>
+ *   tau3d_step_range_async(interior)   planes [3,nzl-3)
+ *   <caller: all-reduce(max) the word at tau3d_max_ptr>
+ *   tau3d_clock_end_async              d_tau controller, swap
+ * The caller (bench.py / the driver) orders these on streams it owns. */
+int tau3d_clock_begin_async(tau3d_t *h);
+int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *stream);
+int tau3d_clock_end_async(tau3d_t *h);
+/* fill own halos from own interior (periodic single domain) */
+int tau3d_fill_halo_periodic_async(tau3d_t *h);
+/* side 0 = low-z, 1 = high-z; which = 0 current (input) state, 1 = next (output) state.
+ * send: first/last 3 INTERIOR planes; recv: the halo planes.  Each is 3*ny*nx floats. */
+int tau3d_halo_send_ptr(tau3d_t *h, int which, int field, int side, float **p);
+int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p);
+int tau3d_max_ptr(tau3d_t *h, float **p);
+int tau3d_sync(tau3d_t *h);
+
+/* =====================================================================
+ * Gray-Scott — replaces step_kernel launch + swap, tau_gray_scott.cu:321-329
+ * ===================================================================== */
+typedef struct taugs taugs_t;
+void taugs_params_default(taugs_params *p, int nx, int ny);               /* :43-61 */
+int taugs_create(taugs_t **out, const taugs_params *p, int device, void *stream);
+void taugs_destroy(taugs_t *h);
+int taugs_init_pattern(taugs_t *h, uint32_t seed);                         /* :173-204 + H2D :308-309 */
+int taugs_upload(taugs_t *h, const float *u, const float *v);
+int taugs_download(taugs_t *h, float *u, float *v);
+int taugs_state_ptrs(taugs_t *h, float **u, float **v);
+int taugs_step(taugs_t *h, int nsteps);                                    /* :321-329 */
+int taugs_step_async(taugs_t *h, int nsteps);
+int taugs_sync(taugs_t *h);
+
+/* =====================================================================
+ * 5-point Laplacian viscosity passes (periodic), race-free ping-pong form of
+ * tau_burgers.cu:490-525 (kind 0, asinh-encoded fields) and
+ * tau_shallow_water.cu:516-547 (kind 1, plain u, v).
+ * ===================================================================== */
+typedef struct taulap taulap_t;
+int taulap_create(taulap_t **out, const taulap_params *p, int kind, int oneD, int device, void *stream);
+void taulap_destroy(taulap_t *h);
+int taulap_upload(taulap_t *h, const float *a, const float *b);
+int taulap_download(taulap_t *h, float *a, float *b);
+int taulap_state_ptrs(taulap_t *h, float **a, float **b);
+int taulap_set_dt(taulap_t *h, float dt);
+int taulap_step(taulap_t *h, int npasses);
+int taulap_step_async(taulap_t *h, int npasses);
+int taulap_sync(taulap_t *h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TAUENG_H */
