@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark: Gcell-updates/s of the 3D hypersonic step on a 512^3 fp32 grid.
+
+  python bench.py --gpus N --steps K --warmup W          (N = 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+
+A "step" is one full time step of the reference loop (tau_hypersonic_3d_cuda.cu:1680-1711: log-time
+clock, k_step over the whole grid, d_tau controller, swap) on synthetic input already resident in
+HBM: the SURVEY §8d "developed flow" start (every fluid cell at the Mach-100 inflow state, t = 0.02 so
+the inflow gain is 1, sphere r = 0.25 at the centre), W warm-up steps so the bow shock exists and the
+controller has settled, then exactly K timed steps bracketed by barrier + device sync.
+
+N > 1: the SAME 512^3 grid is Z-slab partitioned over the ranks (strong scaling, as BASELINE.json's
+metric states: "512^3 at 1/2/4/8 MI355X"); per step each rank exchanges 3 boundary planes x 6 fields
+with both ring neighbours (RCCL send/recv over xGMI, overlapped with the interior planes) and one
+4-byte all-reduce(max) feeds the device-side d_tau controller.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_CELL = 49.0     # 6 fp32 in + 1 u8 mask + 6 fp32 out
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E nominal (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n, state_slab, dt, z0, planes, max_seconds=25.0):
+    """Oracle (C restatement of the reference step, 1 thread) timed on a bounded sample of the SAME
+    workload: a `planes`-plane Z-slab of the warmed-up 512^3 state.  Reported baseline, not a target."""
+    from oracle import pyoracle
+    o = pyoracle.Oracle3D(n, n, n, z0=z0, nzl=planes)
+    out = o.new_state()
+    cells = 0
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        o.step_range(state_slab, out, dt, 1.0)
+        reps += 1
+        cells += planes * n * n
+        if time.perf_counter() - t0 > max_seconds * 0.5 or reps >= 8:
+            break
+    el = time.perf_counter() - t0
+    return {"value": cells / el / 1e9, "unit": "Gcell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{planes}-plane Z-slab (z0={z0}) of the warmed-up {n}^3 state, {reps} oracle steps, "
+                      f"{el:.1f} s, gcc -O2 IEEE fp32, 1 thread (the reference is single-threaded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--n", type=int, default=512, help="grid edge (headline: 512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import fluid_sims_amd as f
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (libtaueng has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    n = args.n
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    from importlib import import_module
+    slab = import_module("fluid_sims_amd.slab")
+
+    L = f.load()
+    params = f.Tau3DParams()
+    L.tau3d_params_default(ctypes.byref(params), n, n, n)
+    z0, nzl = slab.slab_bounds(n, world, rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    if world == 1:
+        eng = f.Tau3D(n, n, n, params=params, device=local)
+        eng.init(1)
+        eng.set_clock(0.02, 1e-4)
+        step = lambda k: eng.step_async(k)          # noqa: E731
+        sync = eng.sync
+        h = eng
+    else:
+        be = slab.EngineSlabBackend(f.taueng, params, z0, nzl, local)
+        be.h.init(1)
+        be.h.set_clock(0.02, 1e-4)
+        ring = slab.SlabRing(be, rank, world)
+        ring.prime()
+        step = lambda k: ring.step(k)               # noqa: E731
+        sync = ring.finish
+        h = be.h
+
+    step(args.warmup)
+    sync()
+    h.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    step(args.steps)
+    sync()
+    barrier()
+    el = time.perf_counter() - t0
+    k_ms, k_launches, k_cells = h.timing_read()
+    h.timing_enable(False)
+
+    if world > 1:
+        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+
+    clk = h.clock()
+    cells_total = float(n) ** 3 * args.steps
+    value = cells_total / el / 1e9
+
+    if rank == 0:
+        # dominant kernel: k_step.  achieved = algorithmic bytes of the launches / their summed duration
+        k_s = k_ms * 1e-3
+        achieved = ALGO_BYTES_PER_CELL * k_cells / k_s / 1e9 if k_s > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "k_step_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "kernel": "h3d::k_step", "launches": k_launches,
+                "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(k_launches, 1),
+                "note": "kernel is FP32-VALU bound (WENO5+HLLC, ~2.6k VALU instr/cell); the HBM fraction is "
+                        "reported because BASELINE.json's metric asks for it"}
+        out = {"metric": "Gcell-updates/s, 3D hypersonic 512^3 fp32", "value": round(value, 4),
+               "unit": "Gcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"tau_hypersonic_3d {n}^3 fp32, sphere r=0.25, Mach-100 inflow, "
+                                      f"developed-flow start (SURVEY 8d input ii)",
+                          "grid": [n, n, n], "decomposition": f"z-slab x{world}" if world > 1 else "single domain",
+                          "halo_planes": 3, "t": clk.t, "d_tau": clk.d_tau, "maxs": clk.maxs},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            planes = 8
+            zc = n // 2 - 40 if n >= 128 else 0
+            planes = min(planes, n)
+            st = h.download_planes(zc - 3, zc + planes + 3)
+            out["cpu_baseline"] = cpu_baseline(n, [np.ascontiguousarray(a) for a in st], clk.dt, zc, planes)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -618,6 +618,12 @@ struct tau3d {
   int cur;                  // which side holds the current state
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
+  // optional per-launch event timing
+  bool timing;
+  int n_ev;
+  double ev_cells;
+  hipEvent_t ev0[4096], ev1[4096];
+  bool ev_made;
 };
 
 static float host_evib_eq(const tau3d_params &P, float T) { // tau_hypersonic_3d_cuda.cu:206-211
@@ -698,6 +704,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipFree(h->solid);
   hipFree(h->clk);
   if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->ev_made) for (int i = 0; i < 4096; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); }
   delete h;
 }
 
@@ -811,8 +818,15 @@ extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *st
   A.nzc = (nplanes + A.zchunk - 1) / A.zchunk;
   unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const bool tm = h->timing && h->n_ev < 4096;
+  if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s));
   hipLaunchKernelGGL(h3d::k_step, dim3(nb), dim3(h3d::NT), 0, s, A);
   TAU_LAUNCH_CHECK("k_step");
+  if (tm) {
+    TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
+    h->n_ev++;
+    h->ev_cells += (double)nplanes * (double)h->plane_n;
+  }
   return 0;
 }
 
@@ -828,7 +842,7 @@ extern "C" int tau3d_clock_end_async(tau3d_t *h) {
   return 0;
 }
 
-extern "C" int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out) {
+extern "C" int tau3d_step_async(tau3d_t *h, int nsteps) {
   if (h->nzl != h->p.nz) return tau::fail("tau3d_step: single-domain call on a slab handle (use the *_async pieces)");
   TAU_HIP(hipSetDevice(h->device));
   for (int s = 0; s < nsteps; s++) {
@@ -837,6 +851,10 @@ extern "C" int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out) {
     if (tau3d_step_range_async(h, 0, h->nzl, nullptr)) return 1;
     if (tau3d_clock_end_async(h)) return 1;
   }
+  return 0;
+}
+extern "C" int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out) {
+  if (tau3d_step_async(h, nsteps)) return 1;
   if (out) return tau3d_get_clock(h, out);
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
@@ -871,6 +889,29 @@ extern "C" int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, f
 }
 extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {
   *p = reinterpret_cast<float *>(&h->clk->maxs_bits);
+  return 0;
+}
+extern "C" int tau3d_timing_enable(tau3d_t *h, int on) {
+  TAU_HIP(hipSetDevice(h->device));
+  if (on && !h->ev_made) {
+    for (int i = 0; i < 4096; i++) { TAU_HIP(hipEventCreate(&h->ev0[i])); TAU_HIP(hipEventCreate(&h->ev1[i])); }
+    h->ev_made = true;
+  }
+  h->timing = on != 0; h->n_ev = 0; h->ev_cells = 0.0;
+  return 0;
+}
+extern "C" int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, double *cells) {
+  TAU_HIP(hipSetDevice(h->device));
+  double tot = 0.0;
+  for (int i = 0; i < h->n_ev; i++) {
+    float ms = 0.f;
+    TAU_HIP(hipEventSynchronize(h->ev1[i]));
+    TAU_HIP(hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = h->n_ev;
+  if (cells) *cells = h->ev_cells;
   return 0;
 }
 extern "C" int tau3d_sync(tau3d_t *h) {

@@ -74,6 +74,7 @@ def load():
         "tau3d_get_clock": ([vp, C.POINTER(Tau3DClock)], i32),
         "tau3d_set_clock": ([vp, C.POINTER(Tau3DClock)], i32),
         "tau3d_step": ([vp, i32, C.POINTER(Tau3DClock)], i32),
+        "tau3d_step_async": ([vp, i32], i32),
         "tau3d_step_explicit": ([vp, f32, f32, C.POINTER(f32)], i32),
         "tau3d_clock_begin_async": ([vp], i32),
         "tau3d_step_range_async": ([vp, i32, i32, vp], i32),
@@ -83,6 +84,8 @@ def load():
         "tau3d_halo_recv_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
         "tau3d_max_ptr": ([vp, C.POINTER(vp)], i32),
         "tau3d_sync": ([vp], i32),
+        "tau3d_timing_enable": ([vp, i32], i32),
+        "tau3d_timing_read": ([vp, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_double)], i32),
         "taugs_params_default": ([C.POINTER(GSParams), i32, i32], None),
         "taugs_create": ([C.POINTER(vp), C.POINTER(GSParams), i32, vp], i32),
         "taugs_destroy": ([vp], None),
@@ -206,6 +209,9 @@ class Tau3D:
         _ck(self._L.tau3d_step(self._h, n, C.byref(c)))
         return c
 
+    def step_async(self, n=1):
+        _ck(self._L.tau3d_step_async(self._h, n))
+
     def step_explicit(self, dt, gain):
         m = C.c_float()
         _ck(self._L.tau3d_step_explicit(self._h, dt, gain, C.byref(m)))
@@ -237,6 +243,14 @@ class Tau3D:
 
     def sync(self):
         _ck(self._L.tau3d_sync(self._h))
+
+    def timing_enable(self, on=True):
+        _ck(self._L.tau3d_timing_enable(self._h, int(on)))
+
+    def timing_read(self):
+        ms, n, cells = C.c_double(), C.c_int(), C.c_double()
+        _ck(self._L.tau3d_timing_read(self._h, C.byref(ms), C.byref(n), C.byref(cells)))
+        return ms.value, n.value, cells.value
 
 
 class GrayScott:

@@ -77,6 +77,7 @@ int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in);
  * controller, swap), single domain only (nzl == nz): halos are filled periodically on
  * device.  The controller runs on the device — no per-step host round trip. */
 int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out);
+int tau3d_step_async(tau3d_t *h, int nsteps);   /* same, returns after enqueueing */
 
 /* One k_step launch with an explicit dt / inflow_gain (the kernel call at :1689-1691 alone),
  * for parity tests: halos periodic (single domain), result swapped in, *maxs = max wavespeed. */
@@ -101,6 +102,11 @@ int tau3d_halo_send_ptr(tau3d_t *h, int which, int field, int side, float **p);
 int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p);
 int tau3d_max_ptr(tau3d_t *h, float **p);
 int tau3d_sync(tau3d_t *h);
+/* Per-launch timing of k_step with HIP events on the launch stream (for bench.py's roofline
+ * figure).  enable(1) starts collecting (up to 4096 launches), read() synchronises and returns
+ * the summed duration in ms, the number of launches and the cells they updated. */
+int tau3d_timing_enable(tau3d_t *h, int on);
+int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, double *cells);
 
 /* =====================================================================
  * Gray-Scott — replaces step_kernel launch + swap, tau_gray_scott.cu:321-329
