@@ -155,22 +155,63 @@ __device__ __forceinline__ bool sdf_solid(const Args &A, int x, int y, int zg) {
 __device__ __forceinline__ int wrapi(int i, int n) { i %= n; return (i < 0) ? i + n : i; }
 
 // ---------------------------------------------------------------- WENO5, :534-558
-__device__ __forceinline__ float weno5(float v0, float v1, float v2, float v3, float v4) {
-  float p0 = 2.f * v0 - 7.f * v1 + 11.f * v2;
-  float p1 = -v1 + 5.f * v2 + 2.f * v3;
-  float p2 = 2.f * v2 + 5.f * v3 - v4;
-  float d0 = v0 - 2.f * v1 + v2, e0 = v0 - 4.f * v1 + 3.f * v2;
-  float d1 = v1 - 2.f * v2 + v3, e1 = v1 - v3;
-  float d2 = v2 - 2.f * v3 + v4, e2 = 3.f * v2 - 4.f * v3 + v4;
-  float b0 = (13.f / 12.f) * d0 * d0 + 0.25f * e0 * e0;
-  float b1 = (13.f / 12.f) * d1 * d1 + 0.25f * e1 * e1;
-  float b2 = (13.f / 12.f) * d2 * d2 + 0.25f * e2 * e2;
-  float t0 = WENO_EPS + b0, t1 = WENO_EPS + b1, t2 = WENO_EPS + b2;
-  float a0 = 0.1f * rcp(t0 * t0);
-  float a1 = 0.6f * rcp(t1 * t1);
-  float a2 = 0.3f * rcp(t2 * t2);
-  float s = a0 + a1 + a2;
-  return (a0 * p0 + a1 * p1 + a2 * p2) * (rcp(s) * (1.f / 6.f));
+// The reference evaluates weno5_left(v0..v4) for the left state and weno5_left(v5..v1) for the
+// right state of every face.  Two algebraically identical re-groupings are used here:
+//  * weno_face: both states of ONE face from its six cells, sharing the two second differences
+//    the two stencils have in common (x and y faces, whose cells come from LDS);
+//  * weno_cell: both edge states of ONE cell (left state of its high face, right state of its low
+//    face) from its five cells — the three smoothness indicators are the same for both
+//    (b0' = b2, b1' = b1, b2' = b0), so the marching (z) axis pays for them once per cell.
+// Both are written on first differences D_i = v_{i+1} - v_i: second differences, the one-sided
+// slopes and the three candidate values are short combinations of the D_i, and the result is
+//   v_c + sum_k a_k q_k / (6 sum_k a_k)   with a_k = c_k / (eps + b_k)^2
+// (identical to the reference's w0*p0 + w1*p1 + w2*p2 because the weights sum to one).
+__device__ __forceinline__ float inv_sq(float t) { return rcp(t * t); }
+// t_k = eps + 13/12 d^2 + 1/4 e^2
+__device__ __forceinline__ float smooth_t(float sd, float e) { return (0.25f * e) * e + sd; }
+__device__ __forceinline__ float sd_term(float d) { return ((13.f / 12.f) * d) * d + WENO_EPS; }
+
+__device__ __forceinline__ void weno_face(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
+                                          float &R) {
+  const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
+  const float sA = sd_term(D1 - D0), sB = sd_term(D2 - D1), sC = sd_term(D3 - D2), sD = sd_term(D4 - D3);
+  // left state (centre cell v2): stencils {0,1,2} {1,2,3} {2,3,4}
+  {
+    float i0 = inv_sq(smooth_t(sA, 3.f * D1 - D0));
+    float i1 = inv_sq(smooth_t(sB, D1 + D2));
+    float i2 = inv_sq(smooth_t(sC, 3.f * D2 - D3));
+    float a0 = 0.1f * i0, a1 = 0.6f * i1, a2 = 0.3f * i2;
+    float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    L = v2 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+  // right state (centre cell v3): the mirror image, stencils {5,4,3} {4,3,2} {3,2,1}
+  {
+    float i0 = inv_sq(smooth_t(sD, 3.f * D3 - D4));
+    float i1 = inv_sq(smooth_t(sC, D3 + D2));
+    float i2 = inv_sq(smooth_t(sB, 3.f * D2 - D1));
+    float a0 = 0.1f * i0, a1 = 0.6f * i1, a2 = 0.3f * i2;
+    float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
+    R = v3 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+}
+
+// cell-centred: m2,m1,c,p1,p2 around a cell -> Lhi = left state at its high face, Rlo = right state at its low face
+__device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
+  const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
+  const float i0 = inv_sq(smooth_t(sd_term(D1 - D0), 3.f * D1 - D0));
+  const float i1 = inv_sq(smooth_t(sd_term(D2 - D1), D1 + D2));
+  const float i2 = inv_sq(smooth_t(sd_term(D3 - D2), 3.f * D2 - D3));
+  const float a1 = 0.6f * i1;
+  {
+    float a0 = 0.1f * i0, a2 = 0.3f * i2;
+    float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    Lhi = c0 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+  {
+    float a0 = 0.1f * i2, a2 = 0.3f * i0;
+    float num = a0 * (2.f * D3 - 5.f * D2) - a1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
+    Rlo = c0 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
 }
 
 __device__ __forceinline__ void prim_floor(Prim &q) { // :565-571
@@ -267,39 +308,77 @@ __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R
   return F;
 }
 
-// Face between line cells c2 | c3 of the six cells v[0..5][var]; s = solid bits of the six
-// cells (bit k = cell k).  Branch structure of :1125-1143: solid face -> mirrored ghost,
-// solid anywhere in the stencil -> first order, else WENO5 on the six primitives.
-__device__ __forceinline__ Cons face_flux(const Args &A, const float (&v)[6][6], unsigned s, int axis) {
-  Prim L, R;
-#pragma unroll
-  for (int m = 0; m < 6; m++) {
-    L.q[m] = weno5(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m]);
-    R.q[m] = weno5(v[5][m], v[4][m], v[3][m], v[2][m], v[1][m]);
-  }
+// Solid handling of a face between cells `lo` | `hi` (branch structure of :1125-1143): s = solid
+// bits of the six cells around the face (bit 2 = lo, bit 3 = hi).  Any solid in the stencil ->
+// first order (L = lo, R = hi); one side solid -> the fluid side mirrored across the wall.
+__device__ __forceinline__ void solid_override(Prim &L, Prim &R, const float (&lo)[6], const float (&hi)[6],
+                                               unsigned s, int axis) {
   if (s != 0u) {
     const bool s2 = (s >> 2) & 1u, s3 = (s >> 3) & 1u;
 #pragma unroll
-    for (int m = 0; m < 6; m++) { L.q[m] = v[2][m]; R.q[m] = v[3][m]; }
+    for (int m = 0; m < 6; m++) { L.q[m] = lo[m]; R.q[m] = hi[m]; }
     const int un = (axis == 0) ? IU : (axis == 1) ? IV : IW;
-    if (s2 && !s3) { // low side solid: L = mirror(R)
+    if (s2 && !s3) { // low side solid: L = mirror(R), :772-781
 #pragma unroll
-      for (int m = 0; m < 6; m++) L.q[m] = R.q[m];
-      if (axis == 0) L.q[IU] = -L.q[IU]; else if (axis == 1) L.q[IV] = -L.q[IV]; else L.q[IW] = -L.q[IW];
+      for (int m = 0; m < 6; m++) L.q[m] = (m == un) ? -R.q[m] : R.q[m];
     } else if (s3 && !s2) { // high side solid: R = mirror(L)
 #pragma unroll
-      for (int m = 0; m < 6; m++) R.q[m] = L.q[m];
-      if (axis == 0) R.q[IU] = -R.q[IU]; else if (axis == 1) R.q[IV] = -R.q[IV]; else R.q[IW] = -R.q[IW];
+      for (int m = 0; m < 6; m++) R.q[m] = (m == un) ? -L.q[m] : L.q[m];
     }
-    (void)un;
   }
+}
+// same with a lane-varying axis in {0, 1}
+__device__ __forceinline__ void solid_override_xy(Prim &L, Prim &R, const float (&lo)[6], const float (&hi)[6],
+                                                  unsigned s, bool isx) {
+  if (s != 0u) {
+    const bool s2 = (s >> 2) & 1u, s3 = (s >> 3) & 1u;
+#pragma unroll
+    for (int m = 0; m < 6; m++) { L.q[m] = lo[m]; R.q[m] = hi[m]; }
+    if (s2 && !s3) {
+#pragma unroll
+      for (int m = 0; m < 6; m++) L.q[m] = R.q[m];
+      if (isx) L.q[IU] = -L.q[IU]; else L.q[IV] = -L.q[IV];
+    } else if (s3 && !s2) {
+#pragma unroll
+      for (int m = 0; m < 6; m++) R.q[m] = L.q[m];
+      if (isx) R.q[IU] = -R.q[IU]; else R.q[IV] = -R.q[IV];
+    }
+  }
+}
+
+// face between line cells v[2] | v[3]; six cells from LDS
+__device__ __forceinline__ Cons face_flux6(const Args &A, const float (&v)[6][6], unsigned s, int axis) {
+  Prim L, R;
+#pragma unroll
+  for (int m = 0; m < 6; m++) weno_face(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+  solid_override(L, R, v[2], v[3], s, axis);
   prim_floor(L);
   prim_floor(R);
   return hllc(A, L, R, axis);
 }
 
+// one cell of the grid as the kernel sees it: inflow ghost left of x = 0, transmissive ghost right
+// of x = nx-1 (built from the last interior cell of the same row), y periodic; :1019-1056
+__device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int zh, int zg, float (&q)[6], bool &sol) {
+  Prim p;
+  if (gx < 0) {
+    p = inflow_prim(A);
+    sol = sdf_solid(A, gx, gyw, zg);
+  } else if (gx >= A.nx) {
+    size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + (A.nx - 1);
+    p = outflow_prim(A, decode(A, gi));
+    sol = sdf_solid(A, gx, gyw, zg);
+  } else {
+    size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + gx;
+    p = decode(A, gi);
+    sol = A.solid[gi] != 0;
+  }
+#pragma unroll
+  for (int m = 0; m < 6; m++) q[m] = p.q[m];
+}
+
 // ---------------------------------------------------------------- the step kernel
-__global__ __launch_bounds__(NT) void k_step(const Args A) {
+__global__ __launch_bounds__(NT, 3) void k_step(const Args A) {
   __shared__ float sP[6][PLANE];            // current plane, primitives, x/y halo 3
   __shared__ uint8_t sS[PLANE];             // solid flags of the same cells
   __shared__ float sFx[6][TY][TX + 1];      // low-x face flux of cell (y, x); column TX = far edge
@@ -322,73 +401,88 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
 
   const int x = bx0 + tx, y = by0 + ty;
   const bool in_xy = (x < A.nx) && (y < A.ny);
-  const int xo = min(x, A.nx - 1), yo = min(y, A.ny - 1);
+  const int yw = (y >= A.ny) ? y - A.ny : y;   // partial tiles: own column is a wrapped / ghost column
   const size_t plane_n = (size_t)A.nx * A.ny;
-  const size_t col = (size_t)yo * A.nx + xo;
+  const size_t col = (size_t)yw * A.nx + min(x, A.nx - 1);
 
   const float dt = A.clk->dt;
   const float gain = A.clk->gain;
 
-  // z-window of the own column: planes z-2 .. z+3 around the current plane z
-  float W[6][6];
-  unsigned ws = 0; // solid bits of the window, bit k = W[k]
-  auto load_own = [&](int zl, float (&dst)[6], unsigned &bit) {
-    size_t gi = (size_t)(zl + HALO) * plane_n + col;
-    Prim q = decode(A, gi);
-#pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = q.q[m];
-    bit = A.solid[gi] ? 1u : 0u;
+  // own column: planes z-1 .. z+3 around the current plane z (W[1] is the cell being updated)
+  float W[5][6];
+  unsigned ws = 0; // solid bits of planes z-2 .. z+3 (bit 2 = plane z, bit 3 = plane z+1)
+  auto load_own = [&](int zl, float (&dst)[6]) -> unsigned {
+    bool sol;
+    fetch_cell(A, x, yw, zl + HALO, wrapi(A.z0 + zl, A.nz), dst, sol);
+    return sol ? 1u : 0u;
   };
 
-  // prologue: planes zc_lo-3 .. zc_lo+2 -> flux through the low-z face of plane zc_lo
+  // prologue: cells zc_lo-3 .. zc_lo+2 -> flux through the low-z face of plane zc_lo, and the
+  // left state cell zc_lo contributes to its high face
   float Fz_lo[6];
+  float Lz[6];          // carried: WENO left state at the face above the current cell
   {
-    unsigned bit;
+    float T[6];         // plane zc_lo-3 (only needed here)
+    ws |= load_own(zc_lo - 3, T) << 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) { load_own(zc_lo - 3 + k, W[k], bit); ws |= bit << k; }
-    Cons F = face_flux(A, W, ws, 2);
+    for (int k = 0; k < 5; k++) ws |= load_own(zc_lo - 2 + k, W[k]) << (k + 1);
+    // W[0..4] = zc_lo-2 .. zc_lo+2 ; face zc_lo-1/2 lies between W[1] and W[2]
+    Prim L, R;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      float Rdummy;
+      weno_cell(T[m], W[0][m], W[1][m], W[2][m], W[3][m], L.q[m], Rdummy);      // cell zc_lo-1 -> L at zc_lo-1/2
+      weno_cell(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lz[m], R.q[m]);     // cell zc_lo -> R there, L above
+    }
+    solid_override(L, R, W[1], W[2], ws, 2);
+    prim_floor(L);
+    prim_floor(R);
+    Cons F = hllc(A, L, R, 2);
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = F.c[m];
+    // shift so that W[0..3] = zc_lo-1 .. zc_lo+2 and the loop's first slide makes W = z-1 .. z+3
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int m = 0; m < 6; m++) W[k][m] = W[k + 1][m];
   }
 
   float smax = 0.f;
 
   for (int z = zc_lo; z < zc_hi; z++) {
-    // ---- slide the window to planes z-2 .. z+3
-    {
-#pragma unroll
-      for (int k = 0; k < 5; k++)
-#pragma unroll
-        for (int m = 0; m < 6; m++) W[k][m] = W[k + 1][m];
-      unsigned bit;
-      load_own(z + 3, W[5], bit);
-      ws = (ws >> 1) | (bit << 5);
-    }
-    // ---- stage plane z (with x/y halo) into LDS
+    // ---- bring plane z+3 into the window: W[0..4] = z-1 .. z+3
+    ws = (ws >> 1) | (load_own(z + 3, W[4]) << 5);
+
+    // ---- stage plane z into LDS: own cell from the window, the 276 halo cells decoded here
     {
       const int zh = z + HALO;
       const int zg = wrapi(A.z0 + z, A.nz);
-      for (int p = tid; p < PY * PX; p += NT) {
-        const int ly = p / PX, lx = p - ly * PX;
+      const int lc0 = (ty + HALO) * PXS + (tx + HALO);
+#pragma unroll
+      for (int m = 0; m < 6; m++) sP[m][lc0] = W[1][m];
+      sS[lc0] = (uint8_t)((ws >> 2) & 1u);
+      constexpr int NFULL = 2 * HALO * PX;            // six full halo rows
+      constexpr int NHALO = NFULL + TY * 2 * HALO;    // + 3 cells left and right of every interior row
+      for (int p = tid; p < NHALO; p += NT) {
+        int ly, lx;
+        if (p < NFULL) {
+          const int r = p / PX;
+          ly = (r < HALO) ? r : r + TY;
+          lx = p - r * PX;
+        } else {
+          const int q = p - NFULL;
+          const int r = q / (2 * HALO), c = q - r * (2 * HALO);
+          ly = HALO + r;
+          lx = (c < HALO) ? c : c + TX;
+        }
         const int gx = bx0 + lx - HALO;
         const int gy = wrapi(by0 + ly - HALO, A.ny);
-        Prim q;
+        float q[6];
         bool sol;
-        if (gx < 0) {
-          q = inflow_prim(A);
-          sol = sdf_solid(A, gx, gy, zg);
-        } else if (gx >= A.nx) {
-          size_t gi = ((size_t)zh * A.ny + gy) * A.nx + (A.nx - 1);
-          q = outflow_prim(A, decode(A, gi));
-          sol = sdf_solid(A, gx, gy, zg);
-        } else {
-          size_t gi = ((size_t)zh * A.ny + gy) * A.nx + gx;
-          q = decode(A, gi);
-          sol = A.solid[gi] != 0;
-        }
+        fetch_cell(A, gx, gy, zh, zg, q, sol);
         const int li = ly * PXS + lx;
 #pragma unroll
-        for (int m = 0; m < 6; m++) sP[m][li] = q.q[m];
+        for (int m = 0; m < 6; m++) sP[m][li] = q[m];
         sS[li] = sol ? 1 : 0;
       }
     }
@@ -405,7 +499,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
         for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3)];
         s |= (unsigned)sS[lc + (k - 3)] << k;
       }
-      Cons F = face_flux(A, v, s, 0);
+      Cons F = face_flux6(A, v, s, 0);
 #pragma unroll
       for (int m = 0; m < 6; m++) sFx[m][ty][tx] = F.c[m];
     }
@@ -418,7 +512,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
         for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3) * PXS];
         s |= (unsigned)sS[lc + (k - 3) * PXS] << k;
       }
-      Cons F = face_flux(A, v, s, 1);
+      Cons F = face_flux6(A, v, s, 1);
 #pragma unroll
       for (int m = 0; m < 6; m++) sFy[m][ty][tx] = F.c[m];
     }
@@ -438,7 +532,13 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
         for (int m = 0; m < 6; m++) v[k][m] = sP[m][c0 + (k - 3) * st];
         s |= (unsigned)sS[c0 + (k - 3) * st] << k;
       }
-      Cons F = face_flux(A, v, s, isx ? 0 : 1);
+      Prim L, R;
+#pragma unroll
+      for (int m = 0; m < 6; m++) weno_face(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+      solid_override_xy(L, R, v[2], v[3], s, isx);
+      prim_floor(L);
+      prim_floor(R);
+      Cons F = hllc(A, L, R, isx ? 0 : 1);
       if (isx) {
 #pragma unroll
         for (int m = 0; m < 6; m++) sFx[m][ey][TX] = F.c[m];
@@ -449,9 +549,20 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
     }
     float Fz_hi[6];
     {
-      Cons F = face_flux(A, W, ws, 2);
+      // cell z+1 (W[2]) from its five cells W[0..4]: right state at face z+1/2, left state at z+3/2
+      Prim L, R;
+      float Lnext[6];
 #pragma unroll
-      for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
+      for (int m = 0; m < 6; m++) {
+        L.q[m] = Lz[m];
+        weno_cell(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lnext[m], R.q[m]);
+      }
+      solid_override(L, R, W[1], W[2], ws, 2);
+      prim_floor(L);
+      prim_floor(R);
+      Cons F = hllc(A, L, R, 2);
+#pragma unroll
+      for (int m = 0; m < 6; m++) { Fz_hi[m] = F.c[m]; Lz[m] = Lnext[m]; }
     }
     __syncthreads();
 
@@ -463,7 +574,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
 #pragma unroll
         for (int m = 0; m < 6; m++) A.out[m][gi] = A.in[m][gi];
       } else {
-        const float r0 = W[2][IR], u0 = W[2][IU], v0 = W[2][IV], w0 = W[2][IW], p0 = W[2][IP], e0 = W[2][IE];
+        const float r0 = W[1][IR], u0 = W[1][IU], v0 = W[1][IV], w0 = W[1][IW], p0 = W[1][IP], e0 = W[1][IE];
         float U0[6];
         U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
         {
@@ -529,8 +640,13 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
         A.out[5][gi] = flog(fmaxf(ev1, RHO_P_FLOOR));
       }
     }
+    // ---- slide the window down one plane
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int m = 0; m < 6; m++) W[k][m] = W[k + 1][m];
   }
 
   // ---- max wavespeed: wave64 butterfly, then one atomic per workgroup
