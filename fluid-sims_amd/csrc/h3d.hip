@@ -74,7 +74,7 @@ struct Args {
   int zchunk;                // planes marched by one workgroup
   int ntx, nty, nzc;         // tiles in x, y; chunks in z
   float dx, dy, dz, inv_dx, inv_dy, inv_dz;
-  float u_ref, inv_u_ref, R, gamma, gm1, Twall, theta_v, Rtheta, inv_tau_vib;
+  float u_ref, inv_u_ref, R, gamma, gm1, inv_gm1, Twall, theta_v, Rtheta, inv_tau_vib;
   float sdf_cx, sdf_cy, sdf_cz, sdf_r;
   float in_r, in_u, in_v, in_w, in_p, in_ev;   // inflow_prim(), :611-622 (ev from host expf)
   int sponge_n, sponge_out_n;
@@ -232,8 +232,9 @@ __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R
   float sL = fminf(unL - aL, unR - aR);
   float sR = fmaxf(unL + aL, unR + aR);
   const float aRef = fmaxf(aL, aR);
-  { // entropy_fix_speed, :366-374
-    float d = 0.1f * aRef, id = rcp(fmaxf(d, DENOM_EPS));
+  const float iaRef = rcp(fmaxf(aRef, DENOM_EPS));
+  { // entropy_fix_speed, :366-374  (1/max(0.1 a, eps) == 10/max(a, eps) for every a > 1e-11)
+    const float d = 0.1f * aRef, id = (d > DENOM_EPS) ? 10.f * iaRef : (1.f / DENOM_EPS);
     float asl = fabsf(sL), asr = fabsf(sR);
     float fl = 0.5f * (asl * asl * id + d), fr = 0.5f * (asr * asr * id + d);
     sL = (asl >= d) ? sL : ((sL >= 0.f) ? fl : -fl);
@@ -242,8 +243,10 @@ __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R
   // conserved states and physical fluxes, :234-245, 268-308
   const float keL = 0.5f * (L.q[IU] * L.q[IU] + L.q[IV] * L.q[IV] + L.q[IW] * L.q[IW]);
   const float keR = 0.5f * (R.q[IU] * R.q[IU] + R.q[IV] * R.q[IV] + R.q[IW] * R.q[IW]);
-  const float ethL = pL * rcp(fmaxf(A.gm1 * rL, RHO_P_FLOOR));
-  const float ethR = pR * rcp(fmaxf(A.gm1 * rR, RHO_P_FLOOR));
+  // e_th = p / max((gamma-1) r, floor): the floor only bites below r = 1e-29
+  const float gL = A.gm1 * rL, gR = A.gm1 * rR;
+  const float ethL = (gL >= RHO_P_FLOOR) ? pL * irL * A.inv_gm1 : pL * (1.f / RHO_P_FLOOR);
+  const float ethR = (gR >= RHO_P_FLOOR) ? pR * irR * A.inv_gm1 : pR * (1.f / RHO_P_FLOOR);
   Cons UL, UR, FL, FR;
   UL.c[0] = rL; UL.c[1] = rL * L.q[IU]; UL.c[2] = rL * L.q[IV]; UL.c[3] = rL * L.q[IW];
   UL.c[4] = rL * (keL + ethL + L.q[IE]); UL.c[5] = rL * L.q[IE];
@@ -272,11 +275,13 @@ __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R
   if (axis == 0) vc = (fabsf(L.q[IV]) + fabsf(R.q[IV]) + fabsf(L.q[IW]) + fabsf(R.q[IW])) * 0.5f;
   else if (axis == 1) vc = (fabsf(L.q[IU]) + fabsf(R.q[IU]) + fabsf(L.q[IW]) + fabsf(R.q[IW])) * 0.5f;
   else vc = (fabsf(L.q[IU]) + fabsf(R.q[IU]) + fabsf(L.q[IV]) + fabsf(R.q[IV])) * 0.5f;
-  const float align = clampf(1.f - vc * rcp(fmaxf(aRef, DENOM_EPS)), 0.f, 1.f);
+  const float align = clampf(1.f - vc * iaRef, 0.f, 1.f);
   float alpha;
-  { // shock_sensor, :376-381
-    float dp = fabsf(pR - pL) * rcp(fmaxf(pR + pL, DENOM_EPS));
-    float dr = fabsf(rR - rL) * rcp(fmaxf(rR + rL, DENOM_EPS));
+  { // shock_sensor, :376-381 — both ratios over one reciprocal
+    const float sp = fmaxf(pR + pL, DENOM_EPS), sr = fmaxf(rR + rL, DENOM_EPS);
+    const float inv = rcp(sp * sr);
+    const float dp = fabsf(pR - pL) * sr * inv;
+    const float dr = fabsf(rR - rL) * sp * inv;
     alpha = clampf(5.f * (0.5f * (dp + dr)), 0.f, 1.f) * align;
   }
   const float ihll = rcp(denom_guard(sR - sL));
@@ -296,14 +301,15 @@ __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R
   const float EK = left ? UL.c[4] : UR.c[4], EvK = left ? UL.c[5] : UR.c[5];
   US.c[4] = ((sK - unK) * EK - pK * unK + pStar * sM) * iden;
   US.c[5] = EvK * fac;
+  const float wC = 1.f - alpha, wH = alpha * ihll;
   Cons F;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     float UK = left ? UL.c[k] : UR.c[k];
     float FK = left ? FL.c[k] : FR.c[k];
     float fhllc = FK + (US.c[k] - UK) * sK;
-    float fhll = (FL.c[k] * sR - FR.c[k] * sL + (UR.c[k] - UL.c[k]) * sLR) * ihll;
-    F.c[k] = fhllc * (1.f - alpha) + fhll * alpha;
+    float fhll = FL.c[k] * sR - FR.c[k] * sL + (UR.c[k] - UL.c[k]) * sLR;
+    F.c[k] = fhllc * wC + fhll * wH;
   }
   return F;
 }
@@ -774,7 +780,7 @@ static void fill_consts(tau3d *h) {
   A.dx = P.dx; A.dy = P.dy; A.dz = P.dz;
   A.inv_dx = 1.f / P.dx; A.inv_dy = 1.f / P.dy; A.inv_dz = 1.f / P.dz;
   A.u_ref = P.u_ref; A.inv_u_ref = 1.f / P.u_ref; A.R = P.R; A.gamma = P.gamma_floor;
-  A.gm1 = P.gamma_floor - 1.f; A.Twall = P.Twall; A.theta_v = P.theta_v; A.Rtheta = P.R * P.theta_v;
+  A.gm1 = P.gamma_floor - 1.f; A.inv_gm1 = 1.f / A.gm1; A.Twall = P.Twall; A.theta_v = P.theta_v; A.Rtheta = P.R * P.theta_v;
   A.inv_tau_vib = 1.f / fmaxf(P.tau_vib, 1e-9f);
   A.sdf_cx = P.sdf_cx; A.sdf_cy = P.sdf_cy; A.sdf_cz = P.sdf_cz; A.sdf_r = P.sdf_r;
   A.in_r = fmaxf(P.inflow_r, 1e-30f); A.in_p = fmaxf(P.inflow_p, 1e-30f);
@@ -804,7 +810,8 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     for (int f = 0; f < 6; f++) TAU_HIP(hipMalloc(&h->buf[s][f], h->field_n * sizeof(float)));
   TAU_HIP(hipMalloc(&h->solid, h->field_n));
   TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
-  h->zchunk = 32;
+  h->zchunk = 0; // 0 = pick per launch
+  if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
   fill_consts(h);
   tau3d_clock c = {1e-5f, 1e-3f, 0.f, 0.f, 0.f, 0};
   *out = h;
@@ -930,7 +937,14 @@ extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *st
   for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
   int nplanes = zl_hi - zl_lo;
-  A.zchunk = h->zchunk < nplanes ? h->zchunk : nplanes;
+  // enough workgroups (~32k) to load-balance 256 CUs x 3 resident blocks; chunks of 8..32 planes
+  int zc = h->zchunk;
+  if (zc <= 0) {
+    int want = (32768 + A.ntx * A.nty - 1) / (A.ntx * A.nty);
+    zc = nplanes / (want > 0 ? want : 1);
+    zc = zc < 8 ? 8 : (zc > 32 ? 32 : zc);
+  }
+  A.zchunk = zc < nplanes ? zc : nplanes;
   A.nzc = (nplanes + A.zchunk - 1) / A.zchunk;
   unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
