@@ -53,7 +53,11 @@ class EngineSlabBackend:
     def __init__(self, taueng, params, z0, nzl, device):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
-        self.stream = torch.cuda.current_stream(self.dev)
+        # one explicit (non-default) stream shared by the engine launches, torch copies and the
+        # RCCL hand-offs; the default stream's handle is NULL, which the C-ABI reads as "make your own"
+        self.stream = torch.cuda.Stream(self.dev)
+        torch.cuda.set_stream(self.stream)
+        assert self.stream.cuda_stream != 0
         self.h = taueng.Tau3D(params.nx, params.ny, params.nz, params=params, z0=z0, nzl=nzl, device=device,
                               stream=C.c_void_p(self.stream.cuda_stream))
         self.nzl = nzl

@@ -48,6 +48,29 @@ class LapParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dy nu dt u0".split()]
 
 
+def _load_hip_runtime():
+    """libtaueng.so has no DT_NEEDED on the HIP runtime: bind it to the runtime PyTorch ships when
+    torch is installed (one runtime for torch streams, RCCL and the engine), else to /opt/rocm's."""
+    cands = []
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cands.append(os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    cands += ["/opt/rocm/lib/libamdhip64.so", "libamdhip64.so"]
+    err = None
+    for c in cands:
+        if os.path.isabs(c) and not os.path.exists(c):
+            continue
+        try:
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+        except OSError as e:  # pragma: no cover
+            err = e
+    raise TauError(f"no HIP runtime (libamdhip64) could be loaded: {err}")
+
+
 def load():
     """Load libtaueng.so (raises TauError when it has not been built)."""
     global _lib
@@ -56,6 +79,7 @@ def load():
     p = lib_path()
     if not os.path.exists(p):
         raise TauError(f"{p} not found — run `make -C fluid-sims_amd` (or __graft_entry__.build())")
+    _load_hip_runtime()
     L = C.CDLL(p)
     L.tau_last_error.restype = C.c_char_p
     vp, i32, f32 = C.c_void_p, C.c_int, C.c_float

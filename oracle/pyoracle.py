@@ -63,6 +63,7 @@ class Oracle3D:
 
     def __init__(self, nx, ny=None, nz=None, z0=0, nzl=None, params=None):
         self.L = _lib("libtauoracle3d.so")
+        self.L.o3_clock_end.argtypes = [C.POINTER(Clock), C.c_float, C.c_float]
         self.L.o3_step.restype = C.c_float
         self.L.o3_step.argtypes = [C.POINTER(P3), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_float, C.c_float]
@@ -102,7 +103,7 @@ class Oracle3D:
         self.L.o3_clock_begin(C.byref(self.clock))
 
     def clock_end(self, maxs):
-        self.L.o3_clock_end(C.byref(self.clock), self.p.cfl, C.c_float(maxs))
+        self.L.o3_clock_end(C.byref(self.clock), self.p.cfl, maxs)
 
     def run(self, st, nsteps):
         """single-domain full steps (controller + k_step + swap); returns the final state"""

@@ -1,0 +1,75 @@
+"""GPU: the slab driver on the HIP engine — the self-neighbour (world = 1) ring must equal the
+single-domain entry point bit for bit, and the aliased halo / max tensors must be usable by RCCL."""
+import ctypes
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(eng, n):
+    p = eng.Tau3DParams()
+    eng.load().tau3d_params_default(ctypes.byref(p), *n)
+    return p
+
+
+def test_ring_world1_equals_step(eng):
+    import torch
+    slab = import_module("fluid_sims_amd.slab")
+    n = (64, 32, 48)
+    ref = eng.Tau3D(*n)
+    ref.init(1)
+    ref.set_clock(0.02, 1e-4)
+    c_ref = ref.step(9)
+    want = ref.download()
+
+    be = slab.EngineSlabBackend(eng.taueng, _params(eng, n), 0, n[2], 0)
+    be.h.init(1)
+    be.h.set_clock(0.02, 1e-4)
+    ring = slab.SlabRing(be, 0, 1)
+    ring.prime()
+    ring.step(9)
+    ring.finish()
+    got = be.h.download()
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    c = be.clock()
+    assert (c.t, c.d_tau, c.maxs, c.step) == (c_ref.t, c_ref.d_tau, c_ref.maxs, c_ref.step)
+    # halo tensors alias the engine's planes
+    lo_send = be.halo_tensor("send", 0, 0, 0).cpu().numpy().reshape(3, n[1], n[0])
+    assert np.array_equal(lo_send, got[0][0:3])
+    hi_recv = be.halo_tensor("recv", 0, 2, 1).cpu().numpy().reshape(3, n[1], n[0])
+    assert np.array_equal(hi_recv, be.h.download_planes(n[2], n[2] + 3)[2])
+    torch.cuda.synchronize()
+
+
+def test_rccl_on_aliased_tensors(eng):
+    """world-size-1 RCCL group: all_reduce(MAX) on the engine's max word and a broadcast of a halo
+    tensor run on the aliased device memory (the N > 1 path uses exactly these tensors)."""
+    import torch
+    import torch.distributed as dist
+    slab = import_module("fluid_sims_amd.slab")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ.setdefault("MASTER_PORT", "29577")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = (32, 32, 32)
+        be = slab.EngineSlabBackend(eng.taueng, _params(eng, n), 0, 32, 0)
+        be.h.init(1)
+        be.h.set_clock(0.02, 1e-4)
+        be.clock_begin()
+        be.step_range(0, 32)
+        m = be.max_tensor()
+        before = float(m.item())
+        dist.all_reduce(m, op=dist.ReduceOp.MAX)
+        dist.broadcast(be.halo_tensor("send", 1, 0, 0), src=0)
+        torch.cuda.synchronize()
+        assert before > 0 and float(m.item()) == before
+        be.clock_end()
+        be.sync()
+        assert be.clock().maxs == before
+    finally:
+        dist.destroy_process_group()
