@@ -161,3 +161,62 @@ class Oracle2D:
             a, an = an, a
             b, bn = bn, b
         return a, b
+
+
+class H2Params(C.Structure):
+    _fields_ = [("W", C.c_int32), ("H", C.c_int32)] + [(n, C.c_double) for n in
+               "gamma cfl visc_nu visc_rho visc_e mach geom_x0 geom_cy geom_rb geom_rn geom_theta".split()]
+
+
+class OracleH2:
+    """fp64 oracle of the GPU 2D Euler scheme (tau_hypersonic_cuda.cu); state = 4 arrays (H, W)."""
+
+    def __init__(self, W, H, **kw):
+        self.L = _lib("libtauoracleh2.so")
+        self.L.o2h_max_wavespeed.restype = C.c_double
+        self.L.o2h_dt_from_maxs.restype = C.c_double
+        self.L.o2h_dt_from_maxs.argtypes = [C.POINTER(H2Params), C.c_double]
+        self.L.o2h_step_dt.argtypes = [C.POINTER(H2Params), C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
+        self.L.o2h_unit_minmod.restype = C.c_double
+        self.L.o2h_unit_minmod.argtypes = [C.c_double, C.c_double]
+        self.L.o2h_unit_mc.restype = C.c_double
+        self.L.o2h_unit_mc.argtypes = [C.c_double] * 3
+        self.p = H2Params()
+        self.L.o2h_params_default(C.byref(self.p), W, H)
+        for k, v in kw.items():
+            setattr(self.p, k, v)
+        self.W, self.H = W, H
+        self.mask = np.zeros((H, W), np.uint8)
+        self.t = 0.0
+
+    def _p4(self, st):
+        return (C.c_void_p * 4)(*[a.ctypes.data for a in st])
+
+    def init(self):
+        st = [np.zeros((self.H, self.W)) for _ in range(4)]
+        self.L.o2h_init(C.byref(self.p), _vp(st[0]), _vp(st[1]), _vp(st[2]), _vp(st[3]), _vp(self.mask))
+        self.t = 0.0
+        return st
+
+    def apply_inflow(self, st):
+        self.L.o2h_apply_inflow(C.byref(self.p), _vp(st[0]), _vp(st[1]), _vp(st[2]), _vp(st[3]), _vp(self.mask))
+
+    def max_wavespeed(self, st):
+        return self.L.o2h_max_wavespeed(C.byref(self.p), _vp(st[0]), _vp(st[1]), _vp(st[2]), _vp(st[3]), _vp(self.mask))
+
+    def dt_from_maxs(self, maxs):
+        return self.L.o2h_dt_from_maxs(C.byref(self.p), maxs)
+
+    def step_dt(self, st, dt):
+        """one step on a state that already carries the inflow column; returns the new state"""
+        st = [np.ascontiguousarray(a, np.float64) for a in st]
+        out = [np.empty_like(a) for a in st]
+        self.L.o2h_step_dt(C.byref(self.p), self._p4(st), self._p4(out), _vp(self.mask), dt)
+        return out
+
+    def run(self, st, n):
+        other = [np.empty_like(a) for a in st]
+        t = C.c_double(self.t)
+        self.L.o2h_run(C.byref(self.p), self._p4(st), self._p4(other), _vp(self.mask), n, C.byref(t))
+        self.t = t.value
+        return st if n % 2 == 0 else other

@@ -97,3 +97,52 @@ def test_laplacian_oracle_fourier_mode(oracle_built, kind):
         a, b = o.lap_step("burgers", p, phi, -phi)
         np.testing.assert_allclose(p.u0 * np.sinh(a), want, atol=5e-7)
         np.testing.assert_allclose(p.u0 * np.sinh(b), -want, atol=5e-7)
+
+
+def _seq_sum(x):
+    s = 0.0
+    for v in x:
+        s += v
+    return s
+
+
+def test_tau2d_gpu_scheme_oracle_matches_reference(oracle_built):
+    """tau_hypersonic_cuda.cu at 512 x 256, 4 steps, default_config: every recorded digit."""
+    g = GOLD["tau2d_cuda_512x256_4steps_tile32x4"]
+    o = oracle_built.OracleH2(512, 256)
+    st = o.run(o.init(), 4)
+    fl = o.mask.reshape(-1) == 0
+    assert o.t == g["t"] and int(fl.sum()) == g["fluid"]
+    assert _seq_sum(np.maximum(st[0].reshape(-1), 1e-25)[fl]) == g["sum_rho"]
+    assert _seq_sum(st[1].reshape(-1)[fl]) == g["sum_mx"]
+    assert _seq_sum(st[3].reshape(-1)[fl]) == g["sum_E"]
+
+
+def test_tau2d_unit_known_answers(oracle_built):
+    """known answers of tau_hypersonic_cuda_tests.cu:245-314, 389-442"""
+    import ctypes as C
+    u = GOLD["unit_known_answers_tau_hypersonic_cuda_tests"]
+    o = oracle_built.OracleH2(8, 8)
+    L = o.L
+    d4 = C.c_double * 4
+    out, ref, a = d4(), d4(), C.c_double()
+    L.o2h_unit_roundtrip(C.c_double(1.1), d4(*u["roundtrip_cons"]), out)
+    np.testing.assert_allclose(list(out), u["roundtrip_cons"], rtol=0, atol=1e-12)
+    L.o2h_unit_flux(C.c_double(1.1), d4(*u["flux_prim"]), 0, out, C.byref(a))
+    # The reference test expects Fx.E = 102 / Fy.E = -136 (tests:420, 424); with the gamma = 1.1 its
+    # own default_config sets, (E + p) u = (5/0.1 + 25 + 5) * 3 = 240 — the reference's expectation is
+    # inconsistent with the reference's code (the suite never ran in CI, SURVEY §4).  The mass and
+    # momentum components are pinned to the reference's numbers, the energy one to the formula.
+    np.testing.assert_allclose(list(out)[:3], u["flux_x"][:3], rtol=1e-12)
+    assert out[3] == pytest.approx((5 / 0.1 + 0.5 * 2 * 25 + 5) * 3.0, rel=1e-14)
+    assert a.value == pytest.approx(np.sqrt(1.1 * 5 / 2), rel=1e-14)
+    L.o2h_unit_flux(C.c_double(1.1), d4(*u["flux_prim"]), 1, out, C.byref(a))
+    np.testing.assert_allclose(list(out)[:3], u["flux_y"][:3], rtol=1e-12)
+    assert out[3] == pytest.approx((5 / 0.1 + 0.5 * 2 * 25 + 5) * -4.0, rel=1e-14)
+    assert L.o2h_unit_minmod(1.0, 2.0) == u["minmod_1_2"] and L.o2h_unit_minmod(-1.0, 2.0) == u["minmod_m1_2"]
+    assert 0 < L.o2h_unit_mc(1.0, 1.2, 1.5) <= 1 and L.o2h_unit_mc(-1.0, 0.2, 1.0) == u["mc_limiter_m1_02_1"]
+    for ax in (0, 1):
+        L.o2h_unit_hllc(C.c_double(1.1), d4(*u["roundtrip_cons"]), ax, out, ref)
+        np.testing.assert_allclose(list(out), list(ref), rtol=0, atol=1e-11)   # HLLC(U,U) = F(U)
+    L.o2h_unit_inflow(C.c_double(1.1), C.c_double(25.0), out)
+    np.testing.assert_allclose(list(out), [1.0, 25.0 * np.sqrt(1.1), 0.0, 1.0], rtol=1e-15)
