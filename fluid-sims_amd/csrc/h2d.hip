@@ -1,0 +1,604 @@
+// h2d.hip — 2D compressible Euler step (GPU scheme of the reference) in fp32 for gfx950.
+//
+// Reference: tau_hypersonic_cuda.cu runs, per step and in fp64, six kernels that round-trip ~520 B
+// per cell through HBM (max wavespeed x2, predict -> 16 face-state arrays, x/y flux arrays, update).
+// Here the whole step is ONE kernel: a 256-thread workgroup owns a 32x8 tile, stages the
+// conserved state with a 2-cell halo in LDS (coalesced 128-B rows), computes the MUSCL-Hancock
+// predicted face states of the tile + 1-cell ring into LDS, then each face flux ONCE (low-x /
+// low-y face per thread, the 40 far-edge faces in one extra round of the last wave), then the
+// conservative update + 4th-order 5-tap diffusion, and finally the max wavespeed of the NEW state
+// (one atomicMax per workgroup) so the next step's dt needs no separate reduction pass and no
+// host round trip (the reference syncs the host every step, :1846-1850).
+// Compulsory traffic: 4 fp32 + 1 u8 in, 4 fp32 out = 33 B/cell.
+//
+// Semantics kept: inflow column overwrite (k_apply_inflow_left, :772-784) is applied on load, so
+// the state arrays at step boundaries equal the reference's; ghost rules of neighbor_or_wall /
+// load_neighbor_or_wall_tiled (:266-290, 349-371): inflow left, copy-out right, y clamp, NO-SLIP
+// mirror at a masked neighbour; HLLC with its HLLE fallbacks (:483-606); positivity contraction
+// (:373-398); repairs (:1166-1173).  Predicted states stay primitive in LDS (the reference
+// stores them conserved and converts back: an identity up to rounding that costs fp32 accuracy).
+
+#include "../../include/taueng.h"
+#include "tau_common.h"
+#include <cmath>
+#include <new>
+#include <vector>
+
+namespace h2d {
+
+constexpr int TX = 32, TY = 8, NT = TX * TY;
+constexpr int UW = TX + 4, UH = TY + 4;   // state tile, halo 2
+constexpr int PW = TX + 2, PH = TY + 2;   // predicted-state tile, ring 1
+constexpr float EPS_RHO = 1e-25f, EPS_P = 1e-25f; // :32-33
+
+struct P4 { float r, u, v, p; };
+struct C4 { float r, mx, my, E; };
+
+struct DevState {
+  unsigned maxs_bits[2];  // max wavespeed of the state each ping-pong side holds (float bits)
+  double t;
+  float dt_last;
+  int step;
+};
+
+struct Args {
+  const float *in[4];
+  float *out[4];
+  const uint8_t *mask;
+  DevState *st;
+  int W, H, ntx, nty;
+  int cur;                 // which maxs slot belongs to the input state
+  float dt_explicit;       // > 0: use this dt instead of the CFL one
+  float gamma, gm1, inv_gm1, cfl, dt_diff;
+  float visc_nu, visc_rho, visc_e;
+  float in_r, in_u, in_p;  // inflow_state(), :230-238
+  C4 in_c;
+};
+
+__device__ __forceinline__ P4 c2p(const Args &A, C4 c) { // cons_to_prim, :143-158
+  P4 p;
+  float rho = fmaxf(c.r, EPS_RHO);
+  float inv = 1.0f / rho;
+  float u = c.mx * inv, v = c.my * inv;
+  float kin = 0.5f * rho * (u * u + v * v);
+  p.r = rho; p.u = u; p.v = v;
+  p.p = A.gm1 * fmaxf(c.E - kin, EPS_P);
+  return p;
+}
+__device__ __forceinline__ C4 p2c(const Args &A, P4 p) { // prim_to_cons, :160-169
+  C4 c;
+  float rho = fmaxf(p.r, EPS_RHO), pr = fmaxf(p.p, EPS_P);
+  c.r = rho; c.mx = rho * p.u; c.my = rho * p.v;
+  c.E = pr * A.inv_gm1 + 0.5f * rho * (p.u * p.u + p.v * p.v);
+  return c;
+}
+__device__ __forceinline__ float sound(const Args &A, P4 p) { // :171-173
+  return sqrtf(A.gamma * fmaxf(p.p, EPS_P) / fmaxf(p.r, EPS_RHO));
+}
+__device__ __forceinline__ C4 flux_p(const Args &A, P4 p, C4 c, int ax) { // flux_axis, :193-202
+  C4 f;
+  float un = ax ? p.v : p.u;
+  f.r = ax ? c.my : c.mx;
+  f.mx = ax ? (c.mx * un) : (c.mx * un + p.p);
+  f.my = ax ? (c.my * un + p.p) : (c.my * un);
+  f.E = (c.E + p.p) * un;
+  return f;
+}
+__device__ __forceinline__ float minmod(float a, float b) { // :216-220
+  return (a * b <= 0.0f) ? 0.0f : ((fabsf(a) < fabsf(b)) ? a : b);
+}
+__device__ __forceinline__ float mc(float dl, float dc, float dr) { // :222-227
+  return minmod(minmod(dl, dr), minmod(minmod(dc, 2.0f * dl), minmod(dc, 2.0f * dr)));
+}
+
+// state tile in LDS
+struct Tile {
+  const float *r, *mx, *my, *E;
+  const uint8_t *m;
+  int x0, y0; // global coords of tile cell (0,0)  (= tile origin - 2)
+  __device__ __forceinline__ int li(int x, int y) const { return (y - y0) * UW + (x - x0); }
+  __device__ __forceinline__ C4 cons(int x, int y) const { int i = li(x, y); return C4{r[i], mx[i], my[i], E[i]}; }
+  __device__ __forceinline__ bool masked(int x, int y) const { return m[li(x, y)] != 0; }
+};
+
+// neighbor_or_wall / load_neighbor_or_wall_tiled, :266-290, 349-371
+__device__ __forceinline__ C4 neigh(const Args &A, const Tile &T, P4 center, int xn, int yn) {
+  yn = max(0, min(yn, A.H - 1));
+  if (xn < 0) return A.in_c;
+  if (xn >= A.W) return T.cons(A.W - 1, yn);
+  if (T.masked(xn, yn)) return p2c(A, P4{center.r, -center.u, -center.v, center.p}); // wall_ghost_prim: no-slip
+  return T.cons(xn, yn);
+}
+
+__device__ __forceinline__ void enforce_positive(P4 &qm, const P4 &qc, P4 &qp) { // :373-398
+  for (int it = 0; it < 8; it++) {
+    bool bad = (qm.r <= EPS_RHO) || (qp.r <= EPS_RHO) || (qm.p <= EPS_P) || (qp.p <= EPS_P);
+    if (!bad) return;
+    qm.r = 0.5f * (qm.r + qc.r); qm.u = 0.5f * (qm.u + qc.u); qm.v = 0.5f * (qm.v + qc.v); qm.p = 0.5f * (qm.p + qc.p);
+    qp.r = 0.5f * (qp.r + qc.r); qp.u = 0.5f * (qp.u + qc.u); qp.v = 0.5f * (qp.v + qc.v); qp.p = 0.5f * (qp.p + qc.p);
+  }
+  qm.r = fmaxf(qm.r, EPS_RHO); qp.r = fmaxf(qp.r, EPS_RHO);
+  qm.p = fmaxf(qm.p, EPS_P);   qp.p = fmaxf(qp.p, EPS_P);
+}
+
+__device__ __forceinline__ P4 half_step(const Args &A, P4 q, C4 dF, float h) { // :442-455 (+ :931-934 floors)
+  C4 c = p2c(A, q);
+  c.r -= h * dF.r; c.mx -= h * dF.mx; c.my -= h * dF.my; c.E -= h * dF.E;
+  P4 o = c2p(A, c);
+  o.r = fmaxf(o.r, EPS_RHO);
+  o.p = fmaxf(o.p, EPS_P);
+  return o;
+}
+
+// MUSCL-Hancock predicted low / high face states of one cell along one axis, :911-961
+__device__ __forceinline__ void predict_axis(const Args &A, const Tile &T, P4 qc, int x, int y, int ax, float half,
+                                             P4 &lo, P4 &hi) {
+  const int dx = ax ? 0 : 1, dy = ax ? 1 : 0;
+  P4 qm = c2p(A, neigh(A, T, qc, x - dx, y - dy));
+  P4 qp = c2p(A, neigh(A, T, qc, x + dx, y + dy));
+  float s_r = mc(qc.r - qm.r, 0.5f * (qp.r - qm.r), qp.r - qc.r);
+  float s_u = mc(qc.u - qm.u, 0.5f * (qp.u - qm.u), qp.u - qc.u);
+  float s_v = mc(qc.v - qm.v, 0.5f * (qp.v - qm.v), qp.v - qc.v);
+  float s_p = mc(qc.p - qm.p, 0.5f * (qp.p - qm.p), qp.p - qc.p);
+  P4 L{qc.r - 0.5f * s_r, qc.u - 0.5f * s_u, qc.v - 0.5f * s_v, qc.p - 0.5f * s_p};
+  P4 R{qc.r + 0.5f * s_r, qc.u + 0.5f * s_u, qc.v + 0.5f * s_v, qc.p + 0.5f * s_p};
+  enforce_positive(L, qc, R);
+  // flux_axis(prim) = flux of prim_to_cons(prim) whose own cons_to_prim floors rho and p
+  P4 Lf{fmaxf(L.r, EPS_RHO), L.u, L.v, fmaxf(L.p, EPS_P)}, Rf{fmaxf(R.r, EPS_RHO), R.u, R.v, fmaxf(R.p, EPS_P)};
+  C4 FL = flux_p(A, Lf, p2c(A, L), ax), FR = flux_p(A, Rf, p2c(A, R), ax);
+  C4 dF{FR.r - FL.r, FR.mx - FL.mx, FR.my - FL.my, FR.E - FL.E};
+  lo = half_step(A, L, dF, half);
+  hi = half_step(A, R, dF, half);
+}
+
+__device__ __forceinline__ C4 hlle(const Args &A, P4 L, P4 R, C4 UL, C4 UR, C4 FL, C4 FR, float SL, float SR) { // :483-509
+  float denom = SR - SL;
+  if (fabsf(denom) < 1e-14f) return C4{0.5f * (FL.r + FR.r), 0.5f * (FL.mx + FR.mx), 0.5f * (FL.my + FR.my), 0.5f * (FL.E + FR.E)};
+  float id = 1.0f / denom, s = SL * SR;
+  return C4{id * (SR * FL.r - SL * FR.r + s * (UR.r - UL.r)), id * (SR * FL.mx - SL * FR.mx + s * (UR.mx - UL.mx)),
+            id * (SR * FL.my - SL * FR.my + s * (UR.my - UL.my)), id * (SR * FL.E - SL * FR.E + s * (UR.E - UL.E))};
+}
+
+// HLLC with HLLE fallbacks on every degeneracy, :519-606.  L, R are primitive (floored).
+__device__ __forceinline__ C4 hllc(const Args &A, P4 L, P4 R, int ax) {
+  L.r = fmaxf(L.r, EPS_RHO); R.r = fmaxf(R.r, EPS_RHO);
+  L.p = fmaxf(L.p, EPS_P);   R.p = fmaxf(R.p, EPS_P);
+  C4 UL = p2c(A, L), UR = p2c(A, R);
+  float unL = ax ? L.v : L.u, unR = ax ? R.v : R.u, utL = ax ? L.u : L.v, utR = ax ? R.u : R.v;
+  float aL = sound(A, L), aR = sound(A, R);
+  float SL = fminf(unL - aL, unR - aR), SR = fmaxf(unL + aL, unR + aR);
+  C4 FL = flux_p(A, L, UL, ax), FR = flux_p(A, R, UR, ax);
+  if (SL >= 0.0f) return FL;
+  if (SR <= 0.0f) return FR;
+  float num = R.p - L.p + L.r * unL * (SL - unL) - R.r * unR * (SR - unR);
+  float den = L.r * (SL - unL) - R.r * (SR - unR);
+  if (fabsf(den) < 1e-14f || !isfinite(num) || !isfinite(den)) return hlle(A, L, R, UL, UR, FL, FR, SL, SR);
+  float SM = num / den;
+  if (!isfinite(SM)) return hlle(A, L, R, UL, UR, FL, FR, SL, SR);
+  float pStar = fmaxf(L.p + L.r * (SL - unL) * (SM - unL), EPS_P);
+  float dLS = SL - SM, dRS = SR - SM;
+  if (fabsf(dLS) < 1e-14f || fabsf(dRS) < 1e-14f) return hlle(A, L, R, UL, UR, FL, FR, SL, SR);
+  float rsL = L.r * (SL - unL) / dLS, rsR = R.r * (SR - unR) / dRS;
+  if (!(rsL > 0.0f) || !(rsR > 0.0f) || !isfinite(rsL) || !isfinite(rsR)) return hlle(A, L, R, UL, UR, FL, FR, SL, SR);
+  float EsL = ((SL - unL) * UL.E - L.p * unL + pStar * SM) / dLS;
+  float EsR = ((SR - unR) * UR.E - R.p * unR + pStar * SM) / dRS;
+  if (!isfinite(EsL) || !isfinite(EsR)) return hlle(A, L, R, UL, UR, FL, FR, SL, SR);
+  const bool left = SM >= 0.0f;
+  float rs = left ? rsL : rsR, ut = left ? utL : utR, Es = left ? EsL : EsR, S = left ? SL : SR;
+  C4 UK = left ? UL : UR, FK = left ? FL : FR;
+  float mN = rs * SM, mT = rs * ut;
+  C4 US = ax ? C4{rs, mT, mN, Es} : C4{rs, mN, mT, Es};
+  return C4{FK.r + S * (US.r - UK.r), FK.mx + S * (US.mx - UK.mx), FK.my + S * (US.my - UK.my), FK.E + S * (US.E - UK.E)};
+}
+
+struct PredTile { // predicted states, primitive, in LDS; index by global coords
+  float *q;       // [16][PH*PW]: xlo(4) xhi(4) ylo(4) yhi(4)
+  int x0, y0;     // global coords of pred cell (0,0) (= tile origin - 1)
+  __device__ __forceinline__ int li(int x, int y) const { return (y - y0) * PW + (x - x0); }
+  __device__ __forceinline__ P4 get(int slot, int x, int y) const {
+    int i = li(x, y);
+    const float *b = q + slot * 4 * (PH * PW);
+    return P4{b[i], b[PH * PW + i], b[2 * PH * PW + i], b[3 * PH * PW + i]};
+  }
+  __device__ __forceinline__ void put(int slot, int x, int y, P4 p) {
+    int i = li(x, y);
+    float *b = q + slot * 4 * (PH * PW);
+    b[i] = p.r; b[PH * PW + i] = p.u; b[2 * PH * PW + i] = p.v; b[3 * PH * PW + i] = p.p;
+  }
+};
+
+// flux through the face between (xa,ya) [low side] and (xb,yb) [high side], :964-1030
+__device__ __forceinline__ C4 face(const Args &A, const Tile &T, const PredTile &Q, int xa, int ya, int xb, int yb, int ax) {
+  const bool hasL = (xa >= 0) && (ya >= 0) && !T.masked(xa, ya);
+  const bool hasR = (xb < A.W) && (yb < A.H) && !T.masked(xb, yb);
+  P4 L, R;
+  if (hasL && hasR) {
+    L = Q.get(ax ? 3 : 1, xa, ya);
+    R = Q.get(ax ? 2 : 0, xb, yb);
+  } else if (hasR) {
+    L = c2p(A, neigh(A, T, c2p(A, T.cons(xb, yb)), xa, ya));
+    R = Q.get(ax ? 2 : 0, xb, yb);
+  } else if (hasL) {
+    L = Q.get(ax ? 3 : 1, xa, ya);
+    R = c2p(A, neigh(A, T, c2p(A, T.cons(xa, ya)), xb, yb));
+  } else {
+    return C4{0.f, 0.f, 0.f, 0.f};
+  }
+  return hllc(A, L, R, ax);
+}
+
+__device__ __forceinline__ float cell_speed(const Args &A, C4 c) { // k_max_wavespeed_blocks, :794-802
+  P4 p = c2p(A, c);
+  float a = sound(A, p);
+  float v = fmaxf(fabsf(p.u) + a, fabsf(p.v) + a);
+  return isfinite(v) ? v : 1e-12f;
+}
+
+__global__ __launch_bounds__(NT) void k_step(const Args A) {
+  __shared__ float sU[4][UH * UW];
+  __shared__ uint8_t sM[UH * UW];
+  __shared__ float sQ[16 * PH * PW];
+  __shared__ float sFx[4][TY][TX + 1];
+  __shared__ float sFy[4][TY + 1][TX];
+  __shared__ float sRed[NT / 64];
+
+  const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid >> 5, lane = tid & 63, wave = tid >> 6;
+  unsigned b = tau::xcd_swizzle(blockIdx.x, (unsigned)(A.ntx * A.nty));
+  const int bx0 = (int)(b % (unsigned)A.ntx) * TX, by0 = (int)(b / (unsigned)A.ntx) * TY;
+  const int x = bx0 + tx, y = by0 + ty;
+
+  // dt: convective limit from the max wavespeed of the input state, capped by the diffusion limit (:1856-1865)
+  float dt;
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float maxs = __uint_as_float(A.st->maxs_bits[A.cur]);
+    if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
+    dt = fminf(A.cfl / maxs, A.dt_diff);
+  }
+  const float half = 0.5f * dt;
+
+  // ---- A: stage the conserved state, halo 2, clamped like the reference's tile load (:877-901);
+  //         the inflow column overwrite of k_apply_inflow_left happens here
+  for (int t = tid; t < UH * UW; t += NT) {
+    const int ly = t / UW, lx = t - ly * UW;
+    const int sx = max(0, min(bx0 - 2 + lx, A.W - 1)), sy = max(0, min(by0 - 2 + ly, A.H - 1));
+    const size_t gi = (size_t)sy * A.W + sx;
+    const uint8_t m = A.mask[gi];
+    C4 c{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
+    if (sx == 0 && !m) c = A.in_c;
+    sU[0][t] = c.r; sU[1][t] = c.mx; sU[2][t] = c.my; sU[3][t] = c.E;
+    sM[t] = m;
+  }
+  __syncthreads();
+  const Tile T{sU[0], sU[1], sU[2], sU[3], sM, bx0 - 2, by0 - 2};
+  PredTile Q{sQ, bx0 - 1, by0 - 1};
+
+  // ---- B: predicted face states for the tile + 1-cell ring
+  for (int t = tid; t < PH * PW; t += NT) {
+    const int py = t / PW, px = t - py * PW;
+    const int cx = bx0 - 1 + px, cy = by0 - 1 + py;
+    if (cx < 0 || cx >= A.W || cy < 0 || cy >= A.H) continue;
+    if (T.masked(cx, cy)) continue;
+    const P4 qc = c2p(A, T.cons(cx, cy));
+    P4 lo, hi;
+    predict_axis(A, T, qc, cx, cy, 0, half, lo, hi);
+    Q.put(0, cx, cy, lo); Q.put(1, cx, cy, hi);
+    predict_axis(A, T, qc, cx, cy, 1, half, lo, hi);
+    Q.put(2, cx, cy, lo); Q.put(3, cx, cy, hi);
+  }
+  __syncthreads();
+
+  // ---- C: face fluxes, each once
+  const bool row_ok = y < A.H, col_ok = x < A.W;
+  if (row_ok && x <= A.W) { // low-x face of (x,y): fx = x
+    C4 F = face(A, T, Q, x - 1, y, x, y, 0);
+    sFx[0][ty][tx] = F.r; sFx[1][ty][tx] = F.mx; sFx[2][ty][tx] = F.my; sFx[3][ty][tx] = F.E;
+  }
+  if (col_ok && y <= A.H) { // low-y face of (x,y): fy = y
+    C4 F = face(A, T, Q, x, y - 1, x, y, 1);
+    sFy[0][ty][tx] = F.r; sFy[1][ty][tx] = F.mx; sFy[2][ty][tx] = F.my; sFy[3][ty][tx] = F.E;
+  }
+  if (wave == NT / 64 - 1 && lane < TY + TX) { // far edges: 8 x-faces at column TX, 32 y-faces at row TY
+    const bool isx = lane < TY;
+    const int ey = isx ? lane : TY, ex = isx ? TX : lane - TY;
+    const int gx = bx0 + ex, gy = by0 + ey;
+    if (isx ? (gy < A.H && gx <= A.W) : (gx < A.W && gy <= A.H)) {
+      C4 F = isx ? face(A, T, Q, gx - 1, gy, gx, gy, 0) : face(A, T, Q, gx, gy - 1, gx, gy, 1);
+      if (isx) { sFx[0][ey][TX] = F.r; sFx[1][ey][TX] = F.mx; sFx[2][ey][TX] = F.my; sFx[3][ey][TX] = F.E; }
+      else { sFy[0][TY][ex] = F.r; sFy[1][TY][ex] = F.mx; sFy[2][TY][ex] = F.my; sFy[3][TY][ex] = F.E; }
+    }
+  }
+  __syncthreads();
+
+  // ---- D: update + separable 4th-order diffusion + repairs, :1096-1175
+  float smax = 0.f;
+  if (row_ok && col_ok) {
+    const size_t gi = (size_t)y * A.W + x;
+    const C4 Uc = T.cons(x, y);
+    C4 Un = Uc;
+    if (!T.masked(x, y)) {
+      Un.r -= dt * (sFx[0][ty][tx + 1] - sFx[0][ty][tx]); Un.mx -= dt * (sFx[1][ty][tx + 1] - sFx[1][ty][tx]);
+      Un.my -= dt * (sFx[2][ty][tx + 1] - sFx[2][ty][tx]); Un.E -= dt * (sFx[3][ty][tx + 1] - sFx[3][ty][tx]);
+      Un.r -= dt * (sFy[0][ty + 1][tx] - sFy[0][ty][tx]); Un.mx -= dt * (sFy[1][ty + 1][tx] - sFy[1][ty][tx]);
+      Un.my -= dt * (sFy[2][ty + 1][tx] - sFy[2][ty][tx]); Un.E -= dt * (sFy[3][ty + 1][tx] - sFy[3][ty][tx]);
+      const P4 cp = c2p(A, Uc);
+      const C4 xm2 = neigh(A, T, cp, x - 2, y), xm1 = neigh(A, T, cp, x - 1, y), xp1 = neigh(A, T, cp, x + 1, y), xp2 = neigh(A, T, cp, x + 2, y);
+      const C4 ym2 = neigh(A, T, cp, x, y - 2), ym1 = neigh(A, T, cp, x, y - 1), yp1 = neigh(A, T, cp, x, y + 1), yp2 = neigh(A, T, cp, x, y + 2);
+      const float i12 = 1.0f / 12.0f;
+#define D2(f) (((-xm2.f + 16.0f * xm1.f - 30.0f * Uc.f + 16.0f * xp1.f - xp2.f) * i12) + \
+               ((-ym2.f + 16.0f * ym1.f - 30.0f * Uc.f + 16.0f * yp1.f - yp2.f) * i12))
+      Un.r += (A.visc_rho * dt) * D2(r);
+      Un.mx += (A.visc_nu * dt) * D2(mx);
+      Un.my += (A.visc_nu * dt) * D2(my);
+      Un.E += (A.visc_e * dt) * D2(E);
+#undef D2
+      Un.r = fmaxf(Un.r, EPS_RHO);
+      P4 pp = c2p(A, Un);
+      if (pp.p <= EPS_P || !isfinite(pp.p) || !isfinite(pp.r) || !isfinite(pp.u) || !isfinite(pp.v)) {
+        pp.r = fmaxf(pp.r, EPS_RHO);
+        pp.p = fmaxf(pp.p, EPS_P);
+        Un = p2c(A, pp);
+      }
+      // wavespeed of the new state as the NEXT step will see it (its inflow column overwritten)
+      smax = cell_speed(A, (x == 0) ? A.in_c : Un);
+    }
+    A.out[0][gi] = Un.r; A.out[1][gi] = Un.mx; A.out[2][gi] = Un.my; A.out[3][gi] = Un.E;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  if (lane == 0) sRed[wave] = smax;
+  __syncthreads();
+  if (tid == 0) {
+    float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+    if (m > 0.f) atomicMax(&A.st->maxs_bits[A.cur ^ 1], __float_as_uint(m));
+  }
+}
+
+// max wavespeed of a freshly initialised / uploaded state (the reference's two reduction kernels)
+__global__ __launch_bounds__(256) void k_maxspeed(const Args A) {
+  __shared__ float sRed[4];
+  const size_t n = (size_t)A.W * A.H;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (A.mask[i]) continue;
+    C4 c{A.in[0][i], A.in[1][i], A.in[2][i], A.in[3][i]};
+    if (i % A.W == 0) c = A.in_c;
+    m = fmaxf(m, cell_speed(A, c));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+    if (m > 0.f) atomicMax(&A.st->maxs_bits[A.cur], __float_as_uint(m));
+  }
+}
+
+// bookkeeping before a step: t += dt, zero the slot the step will reduce into
+__global__ void k_prepare(DevState *s, int cur, float cfl, float dt_diff, float dt_explicit) {
+  float dt = dt_explicit;
+  if (!(dt > 0.f)) {
+    float maxs = __uint_as_float(s->maxs_bits[cur]);
+    if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
+    dt = fminf(cfl / maxs, dt_diff);
+  }
+  s->t += (double)dt;
+  s->dt_last = dt;
+  s->step += 1;
+  s->maxs_bits[cur ^ 1] = 0u;
+}
+
+} // namespace h2d
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+struct tauh2 {
+  tauh2_params p;
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  float *buf[2][4];
+  uint8_t *mask;
+  h2d::DevState *st;
+  int cur;
+  bool maxs_valid;
+  h2d::Args base;
+};
+
+namespace {
+// host fp64 geometry, expression for expression the reference's k_init (:625-686, 729-770), so the
+// mask is bit-identical to the reference's
+double sdSegment(double px, double py, double ax, double ay, double bx, double by) {
+  double abx = bx - ax, aby = by - ay, apx = px - ax, apy = py - ay;
+  double denom = abx * abx + aby * aby + 1e-30;
+  double t = (apx * abx + apy * aby) / denom;
+  t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+  double qx = ax + t * abx, qy = ay + t * aby;
+  return sqrt((px - qx) * (px - qx) + (py - qy) * (py - qy));
+}
+double sdBody(double x, double y, double Rb, double Rn, double theta) {
+  double r = fabs(y);
+  double st = sin(theta), ct = cos(theta), tt = tan(theta);
+  double xt = Rn * (1.0 - st), rt = Rn * ct;
+  double xb = xt + (Rb - rt) / fmax(tt, 1e-30);
+  double rprof;
+  if (x < 0.0) rprof = -1.0;
+  else if (x <= xt) { double dx = x - Rn, in = Rn * Rn - dx * dx; rprof = (in > 0.0) ? sqrt(in) : 0.0; }
+  else if (x <= xb) rprof = rt + (x - xt) * tt;
+  else rprof = -1.0;
+  int inside = (x >= 0.0 && x <= xb && r <= rprof);
+  double d = fabs(sqrt((x - Rn) * (x - Rn) + r * r) - Rn);
+  double d_cone = sdSegment(x, r, xt, rt, xb, Rb), d_base = sdSegment(x, y, xb, -Rb, xb, +Rb);
+  double d_rim = sqrt((x - xb) * (x - xb) + (r - Rb) * (r - Rb));
+  if (d_cone < d) d = d_cone;
+  if (d_base < d) d = d_base;
+  if (d_rim < d) d = d_rim;
+  return inside ? -d : d;
+}
+} // namespace
+
+extern "C" void tauh2_params_default(tauh2_params *c, int W, int H) { // default_config, :1394-1409
+  c->W = W; c->H = H;
+  c->gamma = 1.1; c->cfl = 0.25; c->visc_nu = 5e-2; c->visc_rho = 5e-2; c->visc_e = 2e-2;
+  c->mach = 25.0; c->geom_x0 = 125.0; c->geom_cy = (double)H / 2.0;
+  c->geom_rb = (double)H / 12.0; c->geom_rn = (double)H / 24.0; c->geom_theta = 3.14159265358979323846 / 4.0;
+}
+
+static void h2_consts(tauh2 *h) {
+  const tauh2_params &P = h->p;
+  h2d::Args &A = h->base;
+  memset(&A, 0, sizeof(A));
+  A.W = P.W; A.H = P.H; A.ntx = (P.W + 1 + h2d::TX - 1) / h2d::TX; A.nty = (P.H + 1 + h2d::TY - 1) / h2d::TY;
+  // (+1: the last x / y face of the domain must belong to some tile even when W, H divide evenly —
+  //  the far-edge round covers it, so plain ceil is enough)
+  A.ntx = (P.W + h2d::TX - 1) / h2d::TX; A.nty = (P.H + h2d::TY - 1) / h2d::TY;
+  A.gamma = (float)P.gamma; A.gm1 = (float)(P.gamma - 1.0); A.inv_gm1 = (float)(1.0 / (P.gamma - 1.0));
+  A.cfl = (float)P.cfl;
+  double nu_max = fmax(P.visc_nu, fmax(P.visc_rho, P.visc_e));
+  A.dt_diff = (std::isfinite(nu_max) && nu_max > 1e-12) ? (float)(0.25 / nu_max) : 3.0e38f;
+  A.visc_nu = (float)P.visc_nu; A.visc_rho = (float)P.visc_rho; A.visc_e = (float)P.visc_e;
+  double a = sqrt(P.gamma * 1.0 / 1.0), u = P.mach * a;
+  A.in_r = 1.0f; A.in_u = (float)u; A.in_p = 1.0f;
+  A.in_c.r = 1.0f; A.in_c.mx = (float)(1.0 * u); A.in_c.my = 0.0f;
+  A.in_c.E = (float)(1.0 / (P.gamma - 1.0) + 0.5 * 1.0 * (u * u));
+  A.mask = h->mask; A.st = h->st;
+}
+
+extern "C" int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, void *stream) {
+  if (!out || !p) return tau::fail("tauh2_create: null argument");
+  if (p->W < 8 || p->H < 8) return tau::fail("tauh2_create: grid must be at least 8x8");
+  if (!(p->gamma > 1.0)) return tau::fail("tauh2_create: gamma must be > 1");
+  TAU_HIP(hipSetDevice(device));
+  tauh2 *h = new (std::nothrow) tauh2();
+  if (!h) return tau::fail("tauh2_create: out of host memory");
+  h->p = *p; h->device = device; h->cur = 0; h->maxs_valid = false;
+  h->own_stream = (stream == nullptr);
+  if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  else h->stream = (hipStream_t)stream;
+  size_t n = (size_t)p->W * p->H;
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < 4; f++) TAU_HIP(hipMalloc(&h->buf[s][f], n * sizeof(float)));
+  TAU_HIP(hipMalloc(&h->mask, n));
+  TAU_HIP(hipMalloc(&h->st, sizeof(h2d::DevState)));
+  TAU_HIP(hipMemsetAsync(h->st, 0, sizeof(h2d::DevState), h->stream));
+  TAU_HIP(hipMemsetAsync(h->mask, 0, n, h->stream));
+  h2_consts(h);
+  *out = h;
+  return 0;
+}
+extern "C" void tauh2_destroy(tauh2_t *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < 4; f++) hipFree(h->buf[s][f]);
+  hipFree(h->mask); hipFree(h->st);
+  if (h->own_stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int tauh2_upload(tauh2_t *h, const float *const host[4], const uint8_t *mask) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t n = (size_t)h->p.W * h->p.H;
+  for (int f = 0; f < 4; f++)
+    TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f], host[f], n * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if (mask) TAU_HIP(hipMemcpyAsync(h->mask, mask, n, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  h->maxs_valid = false;
+  return 0;
+}
+extern "C" int tauh2_download(tauh2_t *h, float *const host[4], uint8_t *mask) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t n = (size_t)h->p.W * h->p.H;
+  for (int f = 0; f < 4; f++)
+    TAU_HIP(hipMemcpyAsync(host[f], h->buf[h->cur][f], n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  if (mask) TAU_HIP(hipMemcpyAsync(mask, h->mask, n, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tauh2_state_ptrs(tauh2_t *h, float *dptr[4], uint8_t **mask) {
+  for (int f = 0; f < 4; f++) dptr[f] = h->buf[h->cur][f];
+  if (mask) *mask = h->mask;
+  return 0;
+}
+
+extern "C" int tauh2_init(tauh2_t *h) { // k_init, :740-770 (geometry on the host in fp64, state constant per class)
+  const tauh2_params &P = h->p;
+  size_t n = (size_t)P.W * P.H;
+  std::vector<uint8_t> m(n);
+  std::vector<float> st[4];
+  for (int f = 0; f < 4; f++) st[f].resize(n);
+  double Rb = P.geom_rb, Rn = P.geom_rn, th = P.geom_theta;
+  double xb = Rn * (1.0 - sin(th)) + (Rb - Rn * cos(th)) / fmax(tan(th), 1e-30);
+  const h2d::C4 in = h->base.in_c;
+  const float restE = (float)(1.0 / (P.gamma - 1.0));
+  for (int y = 0; y < P.H; y++)
+    for (int x = 0; x < P.W; x++) {
+      size_t i = (size_t)y * P.W + x;
+      double X = (double)x - P.geom_x0, Y = (double)y - P.geom_cy;
+      double sd = sdBody(X, Y, Rb, Rn, th) - Rb;
+      sd = fmax(sd, X - xb);
+      m[i] = (sd < 0.0) ? 1 : 0;
+      st[0][i] = 1.0f; st[1][i] = m[i] ? 0.0f : in.mx; st[2][i] = 0.0f; st[3][i] = m[i] ? restE : in.E;
+    }
+  const float *ptr[4] = {st[0].data(), st[1].data(), st[2].data(), st[3].data()};
+  if (tauh2_upload(h, ptr, m.data())) return 1;
+  h2d::DevState z{};
+  TAU_HIP(hipMemcpyAsync(h->st, &z, sizeof(z), hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static int h2_launch_step(tauh2 *h, float dt_explicit) {
+  h2d::Args A = h->base;
+  for (int f = 0; f < 4; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
+  A.cur = h->cur; A.dt_explicit = dt_explicit;
+  if (!h->maxs_valid) { // first step after init / upload: one reduction pass
+    TAU_HIP(hipMemsetAsync(&h->st->maxs_bits[h->cur], 0, sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(h2d::k_maxspeed, dim3(2048), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("h2d::k_maxspeed");
+    h->maxs_valid = true;
+  }
+  hipLaunchKernelGGL(h2d::k_prepare, dim3(1), dim3(1), 0, h->stream, h->st, h->cur, A.cfl, A.dt_diff, dt_explicit);
+  TAU_LAUNCH_CHECK("h2d::k_prepare");
+  hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("h2d::k_step");
+  h->cur ^= 1; // swap_Us, :1378-1392
+  return 0;
+}
+
+extern "C" int tauh2_step_async(tauh2_t *h, int nsteps) {
+  TAU_HIP(hipSetDevice(h->device));
+  for (int s = 0; s < nsteps; s++)
+    if (h2_launch_step(h, 0.f)) return 1;
+  return 0;
+}
+extern "C" int tauh2_sync(tauh2_t *h) {
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tauh2_get_time(tauh2_t *h, double *t, double *dt_last, double *maxs, int *step) {
+  TAU_HIP(hipSetDevice(h->device));
+  h2d::DevState s;
+  TAU_HIP(hipMemcpyAsync(&s, h->st, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  if (t) *t = s.t;
+  if (dt_last) *dt_last = s.dt_last;
+  if (maxs) { float m; memcpy(&m, &s.maxs_bits[h->cur], 4); *maxs = m; }
+  if (step) *step = s.step;
+  return 0;
+}
+extern "C" int tauh2_step(tauh2_t *h, int nsteps, double *t_out) {
+  if (tauh2_step_async(h, nsteps)) return 1;
+  if (t_out) return tauh2_get_time(h, t_out, nullptr, nullptr, nullptr);
+  return tauh2_sync(h);
+}
+extern "C" int tauh2_step_explicit(tauh2_t *h, double dt) {
+  if (!(dt > 0.0)) return tau::fail("tauh2_step_explicit: dt must be positive");
+  TAU_HIP(hipSetDevice(h->device));
+  if (h2_launch_step(h, (float)dt)) return 1;
+  return tauh2_sync(h);
+}

@@ -44,6 +44,12 @@ class GSParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dt Du Dv feed kill".split()]
 
 
+class H2Params(C.Structure):
+    """tauh2_params == reference SimConfig (tau_hypersonic_cuda.cu:37-50) + the W, H it fixes at compile time"""
+    _fields_ = [("W", C.c_int32), ("H", C.c_int32)] + [(n, C.c_double) for n in
+               "gamma cfl visc_nu visc_rho visc_e mach geom_x0 geom_cy geom_rb geom_rn geom_theta".split()]
+
+
 class LapParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dy nu dt u0".split()]
 
@@ -110,6 +116,18 @@ def load():
         "tau3d_sync": ([vp], i32),
         "tau3d_timing_enable": ([vp, i32], i32),
         "tau3d_timing_read": ([vp, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_double)], i32),
+        "tauh2_params_default": ([C.POINTER(H2Params), i32, i32], None),
+        "tauh2_create": ([C.POINTER(vp), C.POINTER(H2Params), i32, vp], i32),
+        "tauh2_destroy": ([vp], None),
+        "tauh2_init": ([vp], i32),
+        "tauh2_upload": ([vp, C.POINTER(vp), vp], i32),
+        "tauh2_download": ([vp, C.POINTER(vp), vp], i32),
+        "tauh2_state_ptrs": ([vp, C.POINTER(vp), C.POINTER(vp)], i32),
+        "tauh2_step": ([vp, i32, C.POINTER(C.c_double)], i32),
+        "tauh2_step_async": ([vp, i32], i32),
+        "tauh2_step_explicit": ([vp, C.c_double], i32),
+        "tauh2_get_time": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
+        "tauh2_sync": ([vp], i32),
         "taugs_params_default": ([C.POINTER(GSParams), i32, i32], None),
         "taugs_create": ([C.POINTER(vp), C.POINTER(GSParams), i32, vp], i32),
         "taugs_destroy": ([vp], None),
@@ -275,6 +293,67 @@ class Tau3D:
         ms, n, cells = C.c_double(), C.c_int(), C.c_double()
         _ck(self._L.tau3d_timing_read(self._h, C.byref(ms), C.byref(n), C.byref(cells)))
         return ms.value, n.value, cells.value
+
+
+class Hypersonic2D:
+    """2D Euler handle (tauh2_*): state = rho, mx, my, E fp32 arrays of shape (H, W) + u8 mask."""
+
+    def __init__(self, W, H, device=0, stream=None, **kw):
+        L = _require_device()
+        p = H2Params()
+        L.tauh2_params_default(C.byref(p), W, H)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self.params = p
+        self._h = C.c_void_p()
+        _ck(L.tauh2_create(C.byref(self._h), C.byref(p), device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tauh2_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def shape(self):
+        return (self.params.H, self.params.W)
+
+    def init(self):
+        _ck(self._L.tauh2_init(self._h))
+
+    def upload(self, fields, mask=None):
+        arrs = [_f32(f).reshape(-1) for f in fields]
+        ptrs = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        _ck(self._L.tauh2_upload(self._h, ptrs, None if m is None else m.ctypes.data))
+
+    def download(self, with_mask=False):
+        arrs = [np.empty(self.shape, np.float32) for _ in range(4)]
+        ptrs = (C.c_void_p * 4)(*[a.ctypes.data for a in arrs])
+        m = np.empty(self.shape, np.uint8) if with_mask else None
+        _ck(self._L.tauh2_download(self._h, ptrs, None if m is None else m.ctypes.data))
+        return (arrs, m) if with_mask else arrs
+
+    def step(self, n=1):
+        t = C.c_double()
+        _ck(self._L.tauh2_step(self._h, n, C.byref(t)))
+        return t.value
+
+    def step_async(self, n=1):
+        _ck(self._L.tauh2_step_async(self._h, n))
+
+    def step_explicit(self, dt):
+        _ck(self._L.tauh2_step_explicit(self._h, dt))
+
+    def time(self):
+        t, dt, m, s = C.c_double(), C.c_double(), C.c_double(), C.c_int()
+        _ck(self._L.tauh2_get_time(self._h, C.byref(t), C.byref(dt), C.byref(m), C.byref(s)))
+        return {"t": t.value, "dt": dt.value, "maxs": m.value, "step": s.value}
+
+    def sync(self):
+        _ck(self._L.tauh2_sync(self._h))
 
 
 class GrayScott:

@@ -109,6 +109,29 @@ int tau3d_timing_enable(tau3d_t *h, int on);
 int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, double *cells);
 
 /* =====================================================================
+ * 2D compressible Euler, GPU scheme — replaces the six launches per step of
+ * tau_hypersonic_cuda.cu:1833-1886 (and run_hypersonic_steps, tau_hypersonic_cuda_tests.cu:178-243)
+ * with one fused fp32 kernel.  State: rho, mx, my, E as four row-major y*W+x fp32 arrays
+ * (the reference keeps them fp64; BASELINE.json asks for fp32) + a u8 body mask.
+ * ===================================================================== */
+typedef struct tauh2 tauh2_t;
+void tauh2_params_default(tauh2_params *p, int W, int H);                   /* default_config, :1394-1409 */
+int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, void *stream);
+void tauh2_destroy(tauh2_t *h);
+int tauh2_init(tauh2_t *h);                                                 /* k_init, :740-770 */
+int tauh2_upload(tauh2_t *h, const float *const host[4], const uint8_t *mask /* may be NULL */);
+int tauh2_download(tauh2_t *h, float *const host[4], uint8_t *mask /* may be NULL */);
+int tauh2_state_ptrs(tauh2_t *h, float *dptr[4], uint8_t **mask);
+/* n steps of the loop body :1833-1888 (inflow column, CFL/diffusion dt, predict, fluxes, update,
+ * swap); dt control stays on the device.  *t_out = accumulated sim_t. */
+int tauh2_step(tauh2_t *h, int nsteps, double *t_out);
+int tauh2_step_async(tauh2_t *h, int nsteps);
+/* one step with a caller-chosen dt (parity tests) */
+int tauh2_step_explicit(tauh2_t *h, double dt);
+int tauh2_get_time(tauh2_t *h, double *t, double *dt_last, double *maxs, int *step);
+int tauh2_sync(tauh2_t *h);
+
+/* =====================================================================
  * Gray-Scott — replaces step_kernel launch + swap, tau_gray_scott.cu:321-329
  * ===================================================================== */
 typedef struct taugs taugs_t;

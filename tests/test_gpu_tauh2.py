@@ -1,0 +1,137 @@
+"""GPU: fused fp32 2D Euler step (tauh2_*, through the C-ABI) against the fp64 oracle of the
+reference's GPU scheme (tau_hypersonic_cuda.cu)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_checkvalues.json")))
+GAMMA = 1.1
+TOL = 1e-5   # north_star: conserved fields within 1e-5 relative (fp32 engine vs fp64 oracle, single step)
+
+
+def scales(st):
+    rho, mx, my, E = [np.asarray(a, np.float64) for a in st]
+    r = np.maximum(rho, 1e-25)
+    u, v = mx / r, my / r
+    p = (GAMMA - 1) * np.maximum(E - 0.5 * r * (u * u + v * v), 1e-25)
+    a = np.sqrt(GAMMA * p / r)
+    mom = r * (np.sqrt(u * u + v * v) + a)
+    return [r, mom, mom, np.abs(E)]
+
+
+def rel_err(got, want, fluid):
+    sc = scales(want)
+    return [float((np.abs(np.asarray(g, np.float64) - w) / s)[fluid].max()) for g, w, s in zip(got, want, sc)]
+
+
+@pytest.mark.parametrize("W,H", [(512, 256), (100, 60), (257, 96), (1024, 128)])
+def test_init_mask_bit_exact(eng, oracle_built, W, H):
+    o = oracle_built.OracleH2(W, H)
+    want = o.init()
+    e = eng.Hypersonic2D(W, H)
+    e.init()
+    got, mask = e.download(with_mask=True)
+    assert np.array_equal(mask, o.mask), "body mask must be bit-exact"
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w.astype(np.float32))
+    e.close()
+
+
+@pytest.mark.parametrize("W,H,warm", [(512, 256, 0), (512, 256, 40), (100, 60, 25), (257, 96, 60), (1024, 128, 120)])
+def test_single_step_parity(eng, oracle_built, W, H, warm):
+    o = oracle_built.OracleH2(W, H)
+    o.init()
+    e = eng.Hypersonic2D(W, H)
+    e.init()
+    if warm:
+        e.step(warm)
+    state = e.download()
+    assert all(np.isfinite(a).all() for a in state)
+    st64 = [a.astype(np.float64) for a in state]
+    o.apply_inflow(st64)
+    dt = o.dt_from_maxs(o.max_wavespeed(st64))
+    want = o.step_dt(st64, dt)
+    e.step_explicit(dt)
+    got = e.download()
+    fluid = o.mask == 0
+    errs = rel_err(got, want, fluid)
+    print("tauh2 parity", (W, H, warm), ["%.2e" % x for x in errs])
+    assert max(errs) <= TOL, errs
+    for g, s in zip(got, state):     # masked cells copy through
+        assert np.array_equal(g[~fluid], s[~fluid])
+    e.close()
+
+
+def test_device_dt_matches_oracle(eng, oracle_built):
+    """the on-device CFL/diffusion dt (no host round trip) equals the reference's host formula"""
+    o = oracle_built.OracleH2(512, 256)
+    e = eng.Hypersonic2D(512, 256)
+    e.init()
+    e.step(30)
+    st64 = [a.astype(np.float64) for a in e.download()]
+    o.apply_inflow(st64)
+    maxs = o.max_wavespeed(st64)
+    t0 = e.time()
+    e.step(1)
+    t1 = e.time()
+    assert t1["dt"] == pytest.approx(o.dt_from_maxs(maxs), rel=2e-6)
+    assert t1["t"] - t0["t"] == pytest.approx(t1["dt"], rel=1e-6)
+
+
+def test_trajectory_matches_reference_checkvalues(eng):
+    g = GOLD["tau2d_cuda_512x256_4steps_tile32x4"]
+    e = eng.Hypersonic2D(512, 256)
+    e.init()
+    t = e.step(4)
+    (rho, mx, my, E), mask = e.download(with_mask=True)
+    fl = mask == 0
+    assert int(fl.sum()) == g["fluid"]
+    assert t == pytest.approx(g["t"], rel=1e-6)
+    assert rho[fl].sum(dtype=np.float64) == pytest.approx(g["sum_rho"], rel=1e-6)
+    assert mx[fl].sum(dtype=np.float64) == pytest.approx(g["sum_mx"], rel=1e-6)
+    assert E[fl].sum(dtype=np.float64) == pytest.approx(g["sum_E"], rel=1e-6)
+    e.close()
+
+
+def test_full_size_band_vs_oracle(eng, oracle_built):
+    """BASELINE size 4096^2: one step on the GPU; a 40-row band through the body and its bow shock is
+    recomputed by the fp64 oracle (rows >= 4 away from the band edge are exact: stencil radius 2)."""
+    n, band, pad = 4096, 40, 6
+    e = eng.Hypersonic2D(n, n)
+    e.init()
+    e.step(150)
+    state, mask = e.download(with_mask=True)
+    j0 = n // 2 - 690     # the rounded shoulder of the body: v != 0, shock + wall + diffusion all in the band
+    rows = slice(j0 - pad, j0 + band + pad)
+    o = oracle_built.OracleH2(n, band + 2 * pad)
+    o.mask[:] = mask[rows]
+    st64 = [np.ascontiguousarray(a[rows], np.float64) for a in state]
+    o.apply_inflow(st64)
+    full64 = [a.astype(np.float64) for a in state]
+    dt = 0.9 * o.dt_from_maxs(o.max_wavespeed(st64))
+    want = o.step_dt(st64, dt)
+    e.step_explicit(dt)
+    got = e.download()
+    fluid = (mask[rows] == 0)[pad:-pad]
+    assert fluid.sum() < fluid.size
+    errs = rel_err([g[rows][pad:-pad] for g in got], [w[pad:-pad] for w in want], fluid)
+    print("tauh2 4096^2 band parity", ["%.2e" % x for x in errs])
+    assert max(errs) <= TOL, errs
+    del full64
+    e.close()
+
+
+def test_deterministic(eng):
+    outs = []
+    for _ in range(2):
+        e = eng.Hypersonic2D(512, 256)
+        e.init()
+        t = e.step(50)
+        outs.append((e.download(), t))
+        e.close()
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert np.array_equal(a, b)
+    assert outs[0][1] == outs[1][1]
