@@ -1,0 +1,383 @@
+// sph.hip — 2D weakly-compressible SPH sub-step for gfx950 (MI355X).
+//
+// Reference (tau_sph.cu): per sub-step k_clear_heads -> k_build_cells (linked lists through
+// atomicExch: nondeterministic order, pointer chasing) -> k_density_pressure_cell -> k_forces_cell ->
+// k_integrate; every neighbour visit is a dependent global load.
+//
+// Here the uniform grid is rebuilt by a DETERMINISTIC counting order instead of linked lists:
+//   1. k_keys      cell index of every particle (same float divide + floor + clamp as
+//                  grid_x/grid_y, :141-157 — the integer index is bit-exact)
+//   2. radix sort  (cell, particle id) pairs — stable, so particles inside a cell are in ascending id
+//   3. k_cell_start / k_gather   cell -> [start, end) ranges; particle records gathered into cell order
+//   4. k_density   one lane per (sorted) particle; the three cells of a grid row are ONE contiguous
+//                  record range, so a particle walks 3 ranges of ~48 contiguous 16-B records instead of
+//                  9 linked lists; the 64 lanes of a wave sit in ~4 neighbouring cells and read the
+//                  same ranges (L1/LDS-free broadcast of the same lines)
+//   5. k_forces    same walk over two 16-B records per neighbour, + symplectic-Euler integrate fused in
+// State arrays stay in the reference's layout and order (pos, vel, acc as float2 AoS, s, press).
+// Only the summation order differs from a linked-list run (ascending id inside row-ordered cells),
+// which is a rounding-level difference (compare at 1e-5, cell indices exactly).
+
+#include "../../include/taueng.h"
+#include "tau_common.h"
+#include <hipcub/hipcub.hpp>
+#include <cmath>
+#include <new>
+#include <random>
+#include <vector>
+
+namespace sph {
+
+struct Args {
+  int N, Gx, Gy, M;
+  float cell, h, mass, rho0, c0, gammaEOS, viscAlpha, gx, gy, boxX, boxY, dt;
+  float alpha;        // 10 / (7 pi h^2), evaluated as the reference does (fp64 product, rounded once)
+  int useVisc, useGrav;
+  float2 *pos, *vel, *acc;
+  float *s, *press;
+  int *cellOf;
+  unsigned *keys, *ids, *keys_s, *ids_s;
+  int *cellStart;     // M + 1
+  float4 *recA;       // sorted: x, y, vx, vy
+  float2 *recB;       // sorted: p / rho^2, rho
+};
+
+__device__ __forceinline__ int grid_c(float x, float cell, int G) { // grid_x / grid_y, :141-157
+  int g = (int)floorf(x / cell);
+  g = g < 0 ? 0 : g;
+  return g >= G ? G - 1 : g;
+}
+__device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+
+__global__ __launch_bounds__(256) void k_keys(const Args A) { // k_build_cells' index arithmetic, :170-174
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.N) return;
+  float2 p = A.pos[i];
+  int c = grid_c(p.y, A.cell, A.Gy) * A.Gx + grid_c(p.x, A.cell, A.Gx);
+  A.keys[i] = (unsigned)c;
+  A.ids[i] = (unsigned)i;
+  A.cellOf[i] = c;
+}
+
+__global__ __launch_bounds__(256) void k_cell_start(const Args A) {
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= A.N) return;
+  int c = (int)A.keys_s[k];
+  int prev = (k == 0) ? -1 : (int)A.keys_s[k - 1];
+  for (int cc = prev + 1; cc <= c; cc++) A.cellStart[cc] = k;   // also fills empty cells
+  if (k == A.N - 1)
+    for (int cc = c + 1; cc <= A.M; cc++) A.cellStart[cc] = A.N;
+}
+
+__global__ __launch_bounds__(256) void k_gather(const Args A) {
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= A.N) return;
+  unsigned id = A.ids_s[k];
+  float2 p = A.pos[id], v = A.vel[id];
+  A.recA[k] = make_float4(p.x, p.y, v.x, v.y);
+}
+
+__device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :105-116
+  float q = r * ih;
+  float q2 = q * q;
+  float t = 2.f - q;
+  float w1 = 1.f - 1.5f * q2 + 0.75f * q2 * q;
+  float w2 = 0.25f * t * t * t;
+  return alpha * ((q < 1.0f) ? w1 : ((q < 2.0f) ? w2 : 0.f));
+}
+
+__global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pressure_cell, :178-213
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= A.N) return;
+  const float4 me = A.recA[k];
+  const int c = (int)A.keys_s[k];
+  const int gy = c / A.Gx, gx = c - gy * A.Gx;
+  const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
+  const float ih = 1.0f / A.h;
+  const float alpha = A.alpha;
+  const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
+  float rho = 0.f;
+  for (int oy = -1; oy <= 1; ++oy) {
+    const int cy = gy + oy;
+    if ((unsigned)cy >= (unsigned)A.Gy) continue;
+    const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
+    for (int j = j0; j < j1; j++) {
+      const float4 o = A.recA[j];
+      const float dx = me.x - o.x, dy = me.y - o.y;
+      const float r2 = dx * dx + dy * dy;
+      if (r2 < twoh2) rho += A.mass * W_cubic(sqrtf(r2), ih, alpha);
+    }
+  }
+  const float si = logf(fmaxf(rho, 1e-6f));
+  rho = expf(si);
+  const float ratio = rho / A.rho0;
+  float p = (A.c0 * A.c0) * A.rho0 * (powf(ratio, A.gammaEOS) - 1.0f) / A.gammaEOS;
+  p = fmaxf(p, 0.0f);
+  const unsigned id = A.ids_s[k];
+  A.s[id] = si;
+  A.press[id] = p;
+  A.recB[k] = make_float2(p / (rho * rho), rho);
+}
+
+__global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell :215-272 + k_integrate :324-355
+  int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= A.N) return;
+  const float4 me = A.recA[k];
+  const float2 meB = A.recB[k];
+  const int c = (int)A.keys_s[k];
+  const int gy = c / A.Gx, gx = c - gy * A.Gx;
+  const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
+  const float ih = 1.0f / h;
+  const float alpha = A.alpha;
+  const float eps2 = 0.01f * h * h;
+  const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
+  float ax = 0.f, ay = 0.f;
+  for (int oy = -1; oy <= 1; ++oy) {
+    const int cy = gy + oy;
+    if ((unsigned)cy >= (unsigned)A.Gy) continue;
+    const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
+    for (int j = j0; j < j1; j++) {
+      if (j == k) continue;
+      const float4 o = A.recA[j];
+      const float dx = me.x - o.x, dy = me.y - o.y;
+      const float r2 = dx * dx + dy * dy;
+      if (r2 >= twoh2 || r2 <= 1e-16f) continue;
+      const float r = sqrtf(r2);
+      if (r <= 1e-8f) continue;              // gradW_cubic's own guard, :119
+      const float2 oB = A.recB[j];
+      // gradW_cubic, :118-133
+      const float q = r * ih, t = 2.0f - q;
+      const float dWdq = alpha * ((q < 1.0f) ? (-3.0f * q + 2.25f * q * q) : (-0.75f * t * t));
+      const float g = dWdq * ih * rcpf(r);
+      const float gwx = g * dx, gwy = g * dy;
+      float coef = -A.mass * (meB.x + oB.x);   // -m (p_i/rho_i^2 + p_j/rho_j^2)
+      if (A.useVisc) {
+        const float dvx = me.z - o.z, dvy = me.w - o.w;
+        const float dot = dvx * dx + dvy * dy;
+        if (dot < 0.f) {
+          const float mu = (h * dot) * rcpf(r2 + eps2);
+          const float rhoBar = 0.5f * (meB.y + oB.y);
+          const float Pi_ij = (-A.viscAlpha * A.c0 * mu) * rcpf(rhoBar);
+          coef += -A.mass * Pi_ij;
+        }
+      }
+      ax += coef * gwx;
+      ay += coef * gwy;
+    }
+  }
+  if (A.useGrav) { ax += A.gx; ay += A.gy; }
+  const unsigned id = A.ids_s[k];
+  A.acc[id] = make_float2(ax, ay);
+  // k_integrate
+  float vx = me.z + ax * A.dt, vy = me.w + ay * A.dt;
+  float x = me.x + vx * A.dt, y = me.y + vy * A.dt;
+  const float e = 0.2f;
+  if (x < 0.f) { x = 0.f; vx = -e * vx; }
+  if (x > A.boxX) { x = A.boxX; vx = -e * vx; }
+  if (y < 0.f) { y = 0.f; vy = -e * vy; }
+  if (y > A.boxY) { y = A.boxY; vy = -e * vy; }
+  A.pos[id] = make_float2(x, y);
+  A.vel[id] = make_float2(vx, vy);
+}
+
+} // namespace sph
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+struct tausph {
+  tausph_params p;
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  sph::Args a;
+  void *cub_tmp;
+  size_t cub_bytes;
+  int key_bits;
+  float tau, t;
+  long step;
+  double pair_range_sum; // not used on the hot path
+};
+
+extern "C" void tausph_params_default(tausph_params *P, int N) { // tau_sph.cu:49-85
+  P->N = N; P->boxX = 1.0f; P->boxY = 1.0f; P->dTau = 1.0f; P->t0 = 1.0f; P->CFL = 1.0f;
+  P->rho0 = 1.0f; P->c0 = 1.0f; P->gammaEOS = 1.0f; P->hMul = 2.0f; P->viscAlpha = 0.25f; P->gravity = 9.81f;
+  P->useVisc = 1; P->useGrav = 1; P->viscSub = 1; P->seed = 69420;
+}
+
+extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device, void *stream) {
+  if (!out || !P) return tau::fail("tausph_create: null argument");
+  if (P->N < 1) return tau::fail("tausph_create: N must be positive");
+  if (!(P->boxX > 0.f) || !(P->boxY > 0.f) || !(P->hMul > 0.f)) return tau::fail("tausph_create: bad box / hMul");
+  TAU_HIP(hipSetDevice(device));
+  tausph *h = new (std::nothrow) tausph();
+  if (!h) return tau::fail("tausph_create: out of host memory");
+  h->p = *P; h->device = device;
+  h->own_stream = (stream == nullptr);
+  if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  else h->stream = (hipStream_t)stream;
+  sph::Args &A = h->a;
+  memset(&A, 0, sizeof(A));
+  const float area = P->boxX * P->boxY;             // :573-576
+  A.N = P->N; A.mass = (P->rho0 * area) / P->N;
+  A.h = P->hMul * sqrtf(area / P->N);
+  A.alpha = (float)(10.0f / (7.0f * M_PI * A.h * A.h)); // W_cubic's constant, :107
+  A.cell = 2.0f * A.h;                               // ensure_cell_buffers, :512-521
+  A.Gx = (int)ceilf(P->boxX / A.cell); A.Gy = (int)ceilf(P->boxY / A.cell);
+  if (A.Gx < 1) A.Gx = 1;
+  if (A.Gy < 1) A.Gy = 1;
+  A.M = A.Gx * A.Gy;
+  A.rho0 = P->rho0; A.c0 = P->c0; A.gammaEOS = P->gammaEOS; A.viscAlpha = P->viscAlpha;
+  A.gx = 0.f; A.gy = -(P->useGrav ? P->gravity : 0.f);
+  A.boxX = P->boxX; A.boxY = P->boxY; A.useVisc = P->useVisc; A.useGrav = P->useGrav;
+  const size_t N = (size_t)P->N;
+  TAU_HIP(hipMalloc(&A.pos, N * sizeof(float2))); TAU_HIP(hipMalloc(&A.vel, N * sizeof(float2)));
+  TAU_HIP(hipMalloc(&A.acc, N * sizeof(float2)));
+  TAU_HIP(hipMalloc(&A.s, N * sizeof(float))); TAU_HIP(hipMalloc(&A.press, N * sizeof(float)));
+  TAU_HIP(hipMalloc(&A.cellOf, N * sizeof(int)));
+  TAU_HIP(hipMalloc(&A.keys, N * 4)); TAU_HIP(hipMalloc(&A.ids, N * 4));
+  TAU_HIP(hipMalloc(&A.keys_s, N * 4)); TAU_HIP(hipMalloc(&A.ids_s, N * 4));
+  TAU_HIP(hipMalloc(&A.cellStart, ((size_t)A.M + 1) * sizeof(int)));
+  TAU_HIP(hipMalloc(&A.recA, N * sizeof(float4))); TAU_HIP(hipMalloc(&A.recB, N * sizeof(float2)));
+  TAU_HIP(hipMemsetAsync(A.acc, 0, N * sizeof(float2), h->stream));
+  TAU_HIP(hipMemsetAsync(A.s, 0, N * sizeof(float), h->stream));
+  TAU_HIP(hipMemsetAsync(A.press, 0, N * sizeof(float), h->stream));
+  h->key_bits = 1;
+  while ((1 << h->key_bits) < A.M) h->key_bits++;
+  h->cub_tmp = nullptr; h->cub_bytes = 0;
+  TAU_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, h->cub_bytes, A.keys, A.keys_s, A.ids, A.ids_s, (int)N, 0,
+                                             h->key_bits, h->stream));
+  TAU_HIP(hipMalloc(&h->cub_tmp, h->cub_bytes));
+  h->tau = 0.f; h->t = P->t0 * expf(h->tau); h->step = 0; // :577-578
+  *out = h;
+  return 0;
+}
+extern "C" void tausph_destroy(tausph_t *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  sph::Args &A = h->a;
+  hipFree(A.pos); hipFree(A.vel); hipFree(A.acc); hipFree(A.s); hipFree(A.press); hipFree(A.cellOf);
+  hipFree(A.keys); hipFree(A.ids); hipFree(A.keys_s); hipFree(A.ids_s); hipFree(A.cellStart);
+  hipFree(A.recA); hipFree(A.recB); hipFree(h->cub_tmp);
+  if (h->own_stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+extern "C" int tausph_upload(tausph_t *h, const float *pos_xy, const float *vel_xy) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t b = (size_t)h->p.N * sizeof(float2);
+  TAU_HIP(hipMemcpyAsync(h->a.pos, pos_xy, b, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipMemcpyAsync(h->a.vel, vel_xy, b, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+extern "C" int tausph_reset_particles(tausph_t *h) { // reset_particles, :493-510 (host) + H2D :567-570
+  const tausph_params &P = h->p;
+  std::vector<float> pos(2 * (size_t)P.N), vel(2 * (size_t)P.N, 0.f);
+  std::mt19937 rng(P.seed);
+  std::uniform_real_distribution<float> U(0.f, 1.f);
+  int nSide = (int)sqrtf((float)P.N);
+  int nx = nSide, ny = (P.N + nSide - 1) / nSide;
+  float padX = 0.05f * P.boxX, padY = 0.05f * P.boxY;
+  float width = P.boxX - 2 * padX, height = 0.6f * P.boxY - padY;
+  for (int i = 0; i < P.N; ++i) {
+    int ix = i % nx, iy = i / nx;
+    float fx = (ix + 0.5f) / nx, fy = (iy + 0.5f) / ny;
+    float x = padX + fx * width, y = padY + fy * height;
+    x += (U(rng) - 0.5f) * 0.2f * width / nx;
+    y += (U(rng) - 0.5f) * 0.2f * height / ny;
+    pos[2 * (size_t)i] = x; pos[2 * (size_t)i + 1] = y;
+  }
+  h->tau = 0.f; h->t = P.t0 * expf(h->tau); h->step = 0;
+  return tausph_upload(h, pos.data(), vel.data());
+}
+
+extern "C" int tausph_download(tausph_t *h, float *pos_xy, float *vel_xy, float *acc_xy, float *s, float *press,
+                               int32_t *cellOf) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t N = (size_t)h->p.N;
+  if (pos_xy) TAU_HIP(hipMemcpyAsync(pos_xy, h->a.pos, N * 8, hipMemcpyDeviceToHost, h->stream));
+  if (vel_xy) TAU_HIP(hipMemcpyAsync(vel_xy, h->a.vel, N * 8, hipMemcpyDeviceToHost, h->stream));
+  if (acc_xy) TAU_HIP(hipMemcpyAsync(acc_xy, h->a.acc, N * 8, hipMemcpyDeviceToHost, h->stream));
+  if (s) TAU_HIP(hipMemcpyAsync(s, h->a.s, N * 4, hipMemcpyDeviceToHost, h->stream));
+  if (press) TAU_HIP(hipMemcpyAsync(press, h->a.press, N * 4, hipMemcpyDeviceToHost, h->stream));
+  if (cellOf) TAU_HIP(hipMemcpyAsync(cellOf, h->a.cellOf, N * 4, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tausph_state_ptrs(tausph_t *h, float **pos, float **vel, float **acc, float **s, float **press) {
+  if (pos) *pos = (float *)h->a.pos;
+  if (vel) *vel = (float *)h->a.vel;
+  if (acc) *acc = (float *)h->a.acc;
+  if (s) *s = h->a.s;
+  if (press) *press = h->a.press;
+  return 0;
+}
+extern "C" int tausph_grid(tausph_t *h, int *Gx, int *Gy, float *cell, float *hh, float *mass) {
+  if (Gx) *Gx = h->a.Gx;
+  if (Gy) *Gy = h->a.Gy;
+  if (cell) *cell = h->a.cell;
+  if (hh) *hh = h->a.h;
+  if (mass) *mass = h->a.mass;
+  return 0;
+}
+
+extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launches of :676-701
+  TAU_HIP(hipSetDevice(h->device));
+  sph::Args A = h->a;
+  A.dt = dt;
+  const unsigned gs = (unsigned)((A.N + 255) / 256);
+  hipLaunchKernelGGL(sph::k_keys, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_keys");
+  TAU_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, h->cub_bytes, A.keys, A.keys_s, A.ids, A.ids_s, A.N, 0,
+                                             h->key_bits, h->stream));
+  hipLaunchKernelGGL(sph::k_cell_start, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_cell_start");
+  hipLaunchKernelGGL(sph::k_gather, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_gather");
+  hipLaunchKernelGGL(sph::k_density, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_density");
+  hipLaunchKernelGGL(sph::k_forces, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_forces");
+  return 0;
+}
+
+extern "C" float tausph_dt(tausph_t *h) { // :666-669
+  float dt_try = h->t * h->p.dTau;
+  float dt_cfl = h->p.CFL * h->a.h / (h->p.c0 * (1.0f + 2.0f * h->p.viscAlpha));
+  return fminf(dt_try, dt_cfl);
+}
+
+extern "C" int tausph_step_async(tausph_t *h, int nsteps) { // host loop body, :665-721
+  for (int n = 0; n < nsteps; n++) {
+    int K = (h->p.viscSub > 0 ? h->p.viscSub : 1);
+    float dt_sub = tausph_dt(h) / K;
+    float dTau_accum = 0.f;
+    for (int k = 0; k < K; ++k) {
+      if (tausph_substep_async(h, dt_sub)) return 1;
+      float dTau_actual = dt_sub / fmaxf(h->t, 1e-9f);
+      dTau_accum += dTau_actual;
+      h->t = h->p.t0 * expf(h->tau + dTau_accum);
+    }
+    h->tau += dTau_accum;
+    h->step++;
+  }
+  return 0;
+}
+extern "C" int tausph_sync(tausph_t *h) {
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tausph_step(tausph_t *h, int nsteps) {
+  if (tausph_step_async(h, nsteps)) return 1;
+  return tausph_sync(h);
+}
+extern "C" int tausph_get_clock(tausph_t *h, float *t, float *tau, int64_t *step) {
+  if (t) *t = h->t;
+  if (tau) *tau = h->tau;
+  if (step) *step = h->step;
+  return 0;
+}

@@ -50,6 +50,13 @@ class H2Params(C.Structure):
                "gamma cfl visc_nu visc_rho visc_e mach geom_x0 geom_cy geom_rb geom_rn geom_theta".split()]
 
 
+class SphParams(C.Structure):
+    """tausph_params == reference Params (tau_sph.cu:49-85)"""
+    _fields_ = ([("N", C.c_int32)] + [(n, C.c_float) for n in
+                "boxX boxY dTau t0 CFL rho0 c0 gammaEOS hMul viscAlpha gravity".split()] +
+                [(n, C.c_int32) for n in "useVisc useGrav viscSub seed".split()])
+
+
 class LapParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dy nu dt u0".split()]
 
@@ -128,6 +135,20 @@ def load():
         "tauh2_step_explicit": ([vp, C.c_double], i32),
         "tauh2_get_time": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
         "tauh2_sync": ([vp], i32),
+        "tausph_params_default": ([C.POINTER(SphParams), i32], None),
+        "tausph_create": ([C.POINTER(vp), C.POINTER(SphParams), i32, vp], i32),
+        "tausph_destroy": ([vp], None),
+        "tausph_reset_particles": ([vp], i32),
+        "tausph_upload": ([vp, vp, vp], i32),
+        "tausph_download": ([vp, vp, vp, vp, vp, vp, vp], i32),
+        "tausph_state_ptrs": ([vp] + [C.POINTER(vp)] * 5, i32),
+        "tausph_grid": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32)], i32),
+        "tausph_dt": ([vp], f32),
+        "tausph_substep_async": ([vp, f32], i32),
+        "tausph_step": ([vp, i32], i32),
+        "tausph_step_async": ([vp, i32], i32),
+        "tausph_get_clock": ([vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64)], i32),
+        "tausph_sync": ([vp], i32),
         "taugs_params_default": ([C.POINTER(GSParams), i32, i32], None),
         "taugs_create": ([C.POINTER(vp), C.POINTER(GSParams), i32, vp], i32),
         "taugs_destroy": ([vp], None),
@@ -354,6 +375,72 @@ class Hypersonic2D:
 
     def sync(self):
         _ck(self._L.tauh2_sync(self._h))
+
+
+class Sph2D:
+    """2D WCSPH handle (tausph_*): pos/vel/acc as (N, 2) float32, s = ln rho, press."""
+
+    def __init__(self, N, device=0, stream=None, **kw):
+        L = _require_device()
+        p = SphParams()
+        L.tausph_params_default(C.byref(p), N)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self.params = p
+        self._h = C.c_void_p()
+        _ck(L.tausph_create(C.byref(self._h), C.byref(p), device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tausph_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def reset_particles(self):
+        _ck(self._L.tausph_reset_particles(self._h))
+
+    def upload(self, pos, vel):
+        pos, vel = _f32(pos), _f32(vel)
+        _ck(self._L.tausph_upload(self._h, pos.ctypes.data, vel.ctypes.data))
+
+    def download(self):
+        n = self.params.N
+        out = {k: np.empty((n, 2), np.float32) for k in ("pos", "vel", "acc")}
+        out["s"] = np.empty(n, np.float32)
+        out["press"] = np.empty(n, np.float32)
+        out["cell"] = np.empty(n, np.int32)
+        _ck(self._L.tausph_download(self._h, out["pos"].ctypes.data, out["vel"].ctypes.data, out["acc"].ctypes.data,
+                                    out["s"].ctypes.data, out["press"].ctypes.data, out["cell"].ctypes.data))
+        return out
+
+    def grid(self):
+        gx, gy = C.c_int(), C.c_int()
+        cell, h, m = C.c_float(), C.c_float(), C.c_float()
+        _ck(self._L.tausph_grid(self._h, C.byref(gx), C.byref(gy), C.byref(cell), C.byref(h), C.byref(m)))
+        return {"Gx": gx.value, "Gy": gy.value, "cell": cell.value, "h": h.value, "mass": m.value}
+
+    def dt(self):
+        return self._L.tausph_dt(self._h)
+
+    def substep(self, dt):
+        _ck(self._L.tausph_substep_async(self._h, dt))
+        self.sync()
+
+    def step(self, n=1):
+        _ck(self._L.tausph_step(self._h, n))
+
+    def step_async(self, n=1):
+        _ck(self._L.tausph_step_async(self._h, n))
+
+    def clock(self):
+        t, tau, s = C.c_float(), C.c_float(), C.c_int64()
+        _ck(self._L.tausph_get_clock(self._h, C.byref(t), C.byref(tau), C.byref(s)))
+        return {"t": t.value, "tau": tau.value, "step": s.value}
+
+    def sync(self):
+        _ck(self._L.tausph_sync(self._h))
 
 
 class GrayScott:

@@ -82,19 +82,23 @@ typedef struct tauh2_params {
   double geom_theta;         /* pi/4 */
 } tauh2_params;
 
-/* ---- 2D WCSPH (tau_sph.cu:49-85) ---- */
+/* ---- 2D WCSPH (tau_sph.cu:49-85; same names and defaults) ---- */
 typedef struct tausph_params {
-  int32_t n;            /* particles */
-  float boxX, boxY;
-  float rho0;
-  float c0;
-  float gamma;
-  float hMul;
-  float alpha;          /* Monaghan viscosity */
-  float gx, gy;         /* gravity */
-  float cfl;
-  float dTau;
-  float restitution;    /* 0.2 in k_integrate (:324-355) */
+  int32_t N;            /* particle count, 1<<16 */
+  float boxX, boxY;     /* 1, 1 */
+  float dTau;           /* 1 */
+  float t0;             /* 1 */
+  float CFL;            /* 1 */
+  float rho0;           /* 1 */
+  float c0;             /* 1 */
+  float gammaEOS;       /* 1 */
+  float hMul;           /* 2 */
+  float viscAlpha;      /* 0.25 */
+  float gravity;        /* 9.81 */
+  int32_t useVisc;      /* 1 */
+  int32_t useGrav;      /* 1 */
+  int32_t viscSub;      /* 1: sub-steps per step */
+  int32_t seed;         /* 69420 */
 } tausph_params;
 
 #ifdef __cplusplus

@@ -132,6 +132,29 @@ int tauh2_get_time(tauh2_t *h, double *t, double *dt_last, double *maxs, int *st
 int tauh2_sync(tauh2_t *h);
 
 /* =====================================================================
+ * 2D WCSPH — replaces the per-sub-step launches of tau_sph.cu:676-701 (clear heads, build
+ * cells, density/pressure, forces, integrate) and the host dt / log-time loop :665-721.
+ * State in the reference layout and particle order: pos, vel, acc (float2 AoS), s = ln rho, press.
+ * Rain (:377-392, racy) and XSPH (:274-322, off by default) are not on the hot path.
+ * ===================================================================== */
+typedef struct tausph tausph_t;
+void tausph_params_default(tausph_params *p, int N);                        /* :49-85 */
+int tausph_create(tausph_t **out, const tausph_params *p, int device, void *stream);
+void tausph_destroy(tausph_t *h);
+int tausph_reset_particles(tausph_t *h);                                    /* :493-510 + H2D :567-570 */
+int tausph_upload(tausph_t *h, const float *pos_xy, const float *vel_xy);
+/* any pointer may be NULL; cellOf = integer cell index gy*Gx+gx of the last sub-step's build */
+int tausph_download(tausph_t *h, float *pos_xy, float *vel_xy, float *acc_xy, float *s, float *press, int32_t *cellOf);
+int tausph_state_ptrs(tausph_t *h, float **pos, float **vel, float **acc, float **s, float **press);
+int tausph_grid(tausph_t *h, int *Gx, int *Gy, float *cell, float *hh, float *mass); /* :512-521, 573-576 */
+float tausph_dt(tausph_t *h);                                               /* :666-669 */
+int tausph_substep_async(tausph_t *h, float dt);                            /* one pass of :676-701 */
+int tausph_step(tausph_t *h, int nsteps);                                   /* :665-721 */
+int tausph_step_async(tausph_t *h, int nsteps);
+int tausph_get_clock(tausph_t *h, float *t, float *tau, int64_t *step);
+int tausph_sync(tausph_t *h);
+
+/* =====================================================================
  * Gray-Scott — replaces step_kernel launch + swap, tau_gray_scott.cu:321-329
  * ===================================================================== */
 typedef struct taugs taugs_t;

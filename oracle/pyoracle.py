@@ -220,3 +220,77 @@ class OracleH2:
         self.L.o2h_run(C.byref(self.p), self._p4(st), self._p4(other), _vp(self.mask), n, C.byref(t))
         self.t = t.value
         return st if n % 2 == 0 else other
+
+
+class SphParams(C.Structure):
+    _fields_ = ([("N", C.c_int32)] + [(n, C.c_float) for n in
+                "boxX boxY dTau t0 CFL rho0 c0 gammaEOS hMul viscAlpha gravity".split()] +
+                [(n, C.c_int32) for n in "useVisc useGrav viscSub seed".split()])
+
+
+class OracleSph:
+    """2D WCSPH oracle (tau_sph.cu), linked-list neighbour order = descending particle index."""
+
+    def __init__(self, N, **kw):
+        L = _lib("libtauoraclesph.so")
+        L.osph_create.restype = C.c_void_p
+        L.osph_create.argtypes = [C.POINTER(SphParams)]
+        L.osph_destroy.argtypes = [C.c_void_p]
+        L.osph_step.argtypes = [C.c_void_p, C.c_int]
+        L.osph_substep.argtypes = [C.c_void_p, C.c_float]
+        L.osph_dt.restype = C.c_float
+        L.osph_dt.argtypes = [C.c_void_p]
+        L.osph_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.osph_get_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6
+        L.osph_grid.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+        L.osph_get_clock.argtypes = [C.c_void_p] + [C.c_void_p] * 3
+        L.osph_get_accabs.argtypes = [C.c_void_p, C.c_void_p]
+        self.L = L
+        self.p = SphParams()
+        L.osph_params_default(C.byref(self.p), N)
+        for k, v in kw.items():
+            setattr(self.p, k, v)
+        self.N = N
+        self.h = L.osph_create(C.byref(self.p))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.osph_destroy(self.h)
+            self.h = None
+
+    def grid(self):
+        gx, gy = C.c_int(), C.c_int()
+        cell, h, m = C.c_float(), C.c_float(), C.c_float()
+        self.L.osph_grid(self.h, C.byref(gx), C.byref(gy), C.byref(cell), C.byref(h), C.byref(m))
+        return {"Gx": gx.value, "Gy": gy.value, "cell": cell.value, "h": h.value, "mass": m.value}
+
+    def set_state(self, pos, vel):
+        pos = np.ascontiguousarray(pos, np.float32)
+        vel = np.ascontiguousarray(vel, np.float32)
+        self.L.osph_set_state(self.h, pos.ctypes.data, vel.ctypes.data)
+
+    def state(self):
+        n = self.N
+        out = {k: np.empty((n, 2), np.float32) for k in ("pos", "vel", "acc")}
+        out["s"] = np.empty(n, np.float32)
+        out["press"] = np.empty(n, np.float32)
+        out["cell"] = np.empty(n, np.int32)
+        self.L.osph_get_state(self.h, out["pos"].ctypes.data, out["vel"].ctypes.data, out["acc"].ctypes.data,
+                              out["s"].ctypes.data, out["press"].ctypes.data, out["cell"].ctypes.data)
+        out["acc_abs"] = np.empty(n, np.float32)   # sum of |pair term|: the conditioning scale of acc
+        self.L.osph_get_accabs(self.h, out["acc_abs"].ctypes.data)
+        return out
+
+    def dt(self):
+        return self.L.osph_dt(self.h)
+
+    def substep(self, dt):
+        self.L.osph_substep(self.h, dt)
+
+    def step(self, n=1):
+        self.L.osph_step(self.h, n)
+
+    def clock(self):
+        t, tau, s = C.c_float(), C.c_float(), C.c_long()
+        self.L.osph_get_clock(self.h, C.byref(t), C.byref(tau), C.byref(s))
+        return {"t": t.value, "tau": tau.value, "step": s.value}

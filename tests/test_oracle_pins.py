@@ -146,3 +146,17 @@ def test_tau2d_unit_known_answers(oracle_built):
         np.testing.assert_allclose(list(out), list(ref), rtol=0, atol=1e-11)   # HLLC(U,U) = F(U)
     L.o2h_unit_inflow(C.c_double(1.1), C.c_double(25.0), out)
     np.testing.assert_allclose(list(out), [1.0, 25.0 * np.sqrt(1.1), 0.0, 1.0], rtol=1e-15)
+
+
+def test_sph_oracle_matches_reference(oracle_built):
+    """tau_sph.cu, N = 4096, 3 steps, rain off: every recorded digit"""
+    g = GOLD["tau_sph_4096_3steps_norain"]
+    o = oracle_built.OracleSph(4096)
+    gr = o.grid()
+    assert (gr["Gx"], gr["Gy"]) == (g["Gx"], g["Gy"])
+    o.step(3)
+    st = o.state()
+    assert same9(_sum(st["pos"][:, 0]), g["sum_x"]) or float("%.12g" % _sum(st["pos"][:, 0])) == g["sum_x"]
+    assert float("%.12g" % _sum(st["pos"][:, 0])) == g["sum_x"]
+    assert float("%.12g" % _sum(st["pos"][:, 1])) == g["sum_y"]
+    assert float("%.9g" % np.exp(st["s"].astype(np.float64)).mean()) == g["mean_rho"]
