@@ -389,6 +389,27 @@ __global__ void k_prepare(DevState *s, int cur, float cfl, float dt_diff, float 
   s->maxs_bits[cur ^ 1] = 0u;
 }
 
+// ---- device self-test: the kernel's own helpers evaluated on the known answers of the
+// reference's unit tests (tau_hypersonic_cuda_tests.cu:245-346), fp32
+__global__ void k_unit(const Args A, float *out) {
+  { P4 q = c2p(A, p2c(A, P4{1.4f, 2.2f, -0.7f, 3.6f})); out[0] = q.r; out[1] = q.u; out[2] = q.v; out[3] = q.p; }      // :245-253
+  { C4 c = p2c(A, P4{-2.0f, 1.5f, -0.5f, -7.0f}); P4 q = c2p(A, C4{1.0f, 3.0f, 4.0f, 1e-20f});                          // :255-264
+    out[4] = c.r; out[5] = c.E; out[6] = q.r; out[7] = q.p; }
+  out[8] = minmod(1.0f, 2.0f); out[9] = minmod(-1.0f, 2.0f); out[10] = mc(1.0f, 1.2f, 1.5f); out[11] = mc(-1.0f, 0.2f, 1.0f); // :266-271
+  { P4 p{2.0f, 3.0f, -4.0f, 5.0f}; C4 U = p2c(A, p); C4 Fx = flux_p(A, p, U, 0), Fy = flux_p(A, p, U, 1);               // :273-288
+    out[12] = Fx.r; out[13] = Fx.mx; out[14] = Fx.my; out[15] = Fx.E; out[16] = Fy.r; out[17] = Fy.mx; out[18] = Fy.my;
+    out[19] = Fy.E; out[20] = sound(A, p); }
+  out[21] = A.in_r; out[22] = A.in_u; out[23] = 0.f; out[24] = A.in_p;                                                     // :290-296
+  { P4 p = c2p(A, p2c(A, P4{1.4f, 2.2f, -0.7f, 3.6f})); C4 U = p2c(A, p);                                                  // :298-314
+    for (int ax = 0; ax < 2; ax++) { C4 F = hllc(A, p, p, ax), G = flux_p(A, p, U, ax);
+      out[25 + 4 * ax] = F.r - G.r; out[26 + 4 * ax] = F.mx - G.mx; out[27 + 4 * ax] = F.my - G.my; out[28 + 4 * ax] = F.E - G.E; } }
+  { P4 qc{1.0f, 4.0f, -2.0f, 1.0f}, qm{-1.0f, 8.0f, -4.0f, -3.0f}, qp{-2.0f, -8.0f, 4.0f, -2.0f}; enforce_positive(qm, qc, qp); // :316-326
+    out[33] = qm.r; out[34] = qm.p; out[35] = qp.r; out[36] = qp.p; }
+  { P4 qc{1.0f, 2.0f, -1.0f, 1.0f}, qm{0.8f, 2.2f, -0.9f, 1.1f}, qp{1.2f, 1.8f, -1.2f, 0.9f}; enforce_positive(qm, qc, qp);   // :328-338
+    out[37] = qm.r; out[38] = qm.p; out[39] = qp.r; out[40] = qp.p; }
+  { C4 g = p2c(A, P4{1.0f, -3.0f, 0.5f, 1.0f}); C4 w = p2c(A, P4{1.0f, 3.0f, -0.5f, 1.0f}); out[41] = g.mx + w.mx; out[42] = g.my + w.my; } // no-slip ghost, :262-264
+}
+
 } // namespace h2d
 
 // =====================================================================================
@@ -596,6 +617,21 @@ extern "C" int tauh2_step(tauh2_t *h, int nsteps, double *t_out) {
   if (t_out) return tauh2_get_time(h, t_out, nullptr, nullptr, nullptr);
   return tauh2_sync(h);
 }
+extern "C" int tauh2_unit_eval(tauh2_t *h, float out[48]) {
+  TAU_HIP(hipSetDevice(h->device));
+  float *d = nullptr;
+  TAU_HIP(hipMalloc(&d, 48 * sizeof(float)));
+  TAU_HIP(hipMemsetAsync(d, 0, 48 * sizeof(float), h->stream));
+  hipLaunchKernelGGL(h2d::k_unit, dim3(1), dim3(1), 0, h->stream, h->base, d);
+  TAU_LAUNCH_CHECK("h2d::k_unit");
+  TAU_HIP(hipMemcpyAsync(out, d, 48 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  TAU_HIP(hipFree(d));
+  return 0;
+}
+/* signed distance of the rounded sphere-cone body (host fp64, the expression k_init evaluates) */
+extern "C" double tauh2_body_sdf(double x, double y, double Rb, double Rn, double theta) { return sdBody(x, y, Rb, Rn, theta); }
+
 extern "C" int tauh2_step_explicit(tauh2_t *h, double dt) {
   if (!(dt > 0.0)) return tau::fail("tauh2_step_explicit: dt must be positive");
   TAU_HIP(hipSetDevice(h->device));

@@ -135,6 +135,8 @@ def load():
         "tauh2_step_explicit": ([vp, C.c_double], i32),
         "tauh2_get_time": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
         "tauh2_sync": ([vp], i32),
+        "tauh2_unit_eval": ([vp, C.POINTER(f32)], i32),
+        "tauh2_body_sdf": ([C.c_double] * 5, C.c_double),
         "tausph_params_default": ([C.POINTER(SphParams), i32], None),
         "tausph_create": ([C.POINTER(vp), C.POINTER(SphParams), i32, vp], i32),
         "tausph_destroy": ([vp], None),
@@ -367,6 +369,11 @@ class Hypersonic2D:
 
     def step_explicit(self, dt):
         _ck(self._L.tauh2_step_explicit(self._h, dt))
+
+    def unit_eval(self):
+        out = (C.c_float * 48)()
+        _ck(self._L.tauh2_unit_eval(self._h, out))
+        return np.array(out, np.float32)
 
     def time(self):
         t, dt, m, s = C.c_double(), C.c_double(), C.c_double(), C.c_int()

@@ -128,6 +128,11 @@ int tauh2_step(tauh2_t *h, int nsteps, double *t_out);
 int tauh2_step_async(tauh2_t *h, int nsteps);
 /* one step with a caller-chosen dt (parity tests) */
 int tauh2_step_explicit(tauh2_t *h, double dt);
+/* test seam (the reference's is the NO_MAIN/NO_RAYLIB include boundary, tau_hypersonic_cuda.cu:16-18):
+ * evaluates the kernel's device helpers on the known answers of tau_hypersonic_cuda_tests.cu:245-346;
+ * out[48] layout is documented at h2d::k_unit */
+int tauh2_unit_eval(tauh2_t *h, float out[48]);
+double tauh2_body_sdf(double x, double y, double Rb, double Rn, double theta); /* sdSphereConeCapsule, :644-686 */
 int tauh2_get_time(tauh2_t *h, double *t, double *dt_last, double *maxs, int *step);
 int tauh2_sync(tauh2_t *h);
 

@@ -1,0 +1,118 @@
+"""The plain-C drivers that keep the reference's Makefile target names: CLI validation (CPU) and
+end-to-end runs through the C-ABI (GPU)."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "bin")
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_checkvalues.json")))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(os.path.join(BIN, "tau_sph")):
+        subprocess.run(["make", "-C", ROOT, "-j4"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return BIN
+
+
+def run(*args, **kw):
+    return subprocess.run(list(args), capture_output=True, text=True, cwd=ROOT, **kw)
+
+
+def test_reference_target_names_exist(built):
+    for t in ("tau_hypersonic", "tau_hypersonic_simd", "tau_2d_hypersonic_cuda", "tau_hypersonic_cuda_tests", "tau3d",
+              "tgs", "tau_sph"):
+        assert os.access(os.path.join(built, t), os.X_OK), t
+
+
+@pytest.mark.parametrize("args,msg", [
+    (["--gamma", "1.0"], "Invalid --gamma: 1 (must be > 1)."),
+    (["--cfl", "0"], "Invalid --cfl: 0 (must be > 0)."),
+    (["--visc-nu", "-1"], "Invalid --visc-nu: -1 (must be >= 0)."),
+    (["--mach", "-3"], "Invalid --mach: -3 (must be > 0)."),
+    (["--steps-per-frame", "0"], "Invalid --steps-per-frame: 0 (must be in [1, 1024])."),
+    (["--steps-per-frame", "2000"], "Invalid --steps-per-frame: 2000 (must be in [1, 1024])."),
+    (["--geom-theta", "1.6"], "Invalid --geom-theta: 1.6 (must be in (0, pi/2))."),
+    (["--geom-rb", "1", "--geom-rn", "50"], "Require geom-rb >= geom-rn*cos(theta)."),
+    (["--tile-bx", "0"], "Invalid tile dimensions"),
+    (["--mach", "abc"], "Invalid value for --mach: abc"),
+    (["--bogus"], "Unknown or incomplete argument: --bogus"),
+    (["--mach"], "Unknown or incomplete argument: --mach"),
+])
+def test_tau2d_cli_validation_matches_reference(built, args, msg):
+    """same rules and messages as tau_hypersonic_cuda.cu:1458-1639; error -> usage on stderr, exit 1"""
+    r = run(os.path.join(built, "tau_2d_hypersonic_cuda"), *args)
+    assert r.returncode == 1
+    assert msg in r.stderr and "Usage:" in r.stderr
+
+
+def test_cpu_drivers_reproduce_reference(built):
+    g = GOLD["tau_hypersonic_cpu_256sq_8steps"]
+    r = run(os.path.join(built, "tau_hypersonic"), "--W", "256", "--H", "256", "--steps", "8")
+    assert r.returncode == 0
+    assert "t=%.17g" % g["t"] in r.stdout and "fluid=%d" % g["fluid"] in r.stdout and "sum_rho=%.17g" % g["sum_rho"] in r.stdout
+    r = run(os.path.join(built, "tau_hypersonic_simd"), "--steps", "10")
+    assert "sum_rho=82947.469425548319" in r.stdout   # the SIMD file's own value
+
+
+def test_tests_binary_usage(built):
+    assert run(os.path.join(built, "tau_hypersonic_cuda_tests"), "--nope").returncode == 2
+
+
+def test_gpu_programs_refuse_without_gpu(built):
+    import fluid_sims_amd as f
+    if f.load().tau_device_available():
+        pytest.skip("a GPU is visible")
+    for t in ("tau3d", "tgs", "tau_sph"):
+        r = run(os.path.join(built, t))
+        assert r.returncode == 1 and "no CPU path" in r.stderr
+
+
+@pytest.mark.gpu
+def test_tgs_end_to_end(built):
+    g = GOLD["gray_scott_128sq_100steps"]
+    r = run(os.path.join(built, "tgs"), "--headless", "--steps", "100")
+    assert r.returncode == 0, r.stderr
+    m = re.search(r"sum u = (\S+), sum v = (\S+)", r.stdout)
+    assert float(m.group(1)) == pytest.approx(g["sum_u"], rel=1e-9) and float(m.group(2)) == pytest.approx(g["sum_v"], rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_tau3d_end_to_end(built, tmp_path):
+    g = GOLD["tau3d_32cube_4steps"]
+    d = tmp_path / "s.bin"
+    r = run(os.path.join(built, "tau3d"), "--n", "32", "--frames", "2", "--dump", str(d))
+    assert r.returncode == 0, r.stderr
+    raw = open(d, "rb").read()
+    hdr, body = raw.split(b"\n", 1)
+    a = np.frombuffer(body, np.float32).reshape(6, 32, 32, 32)
+    assert b"steps=4" in hdr
+    assert float(a[0].sum(dtype=np.float64)) == pytest.approx(g["sum_xi"], rel=1e-6)
+    assert "Gcell-updates/s" in r.stdout
+
+
+@pytest.mark.gpu
+def test_make_test_round_trip(built, tmp_path):
+    """the reference's `make test`: write a baseline, verify the same run against it (Makefile:39-43)"""
+    b = str(tmp_path / "base.txt")
+    exe = os.path.join(built, "tau_hypersonic_cuda_tests")
+    r1 = run(exe, "--steps", "24", "--W", "1024", "--H", "256", "--write-baseline", "--baseline", b)
+    assert r1.returncode == 0, r1.stdout + r1.stderr
+    r2 = run(exe, "--steps", "24", "--W", "1024", "--H", "256", "--verify-baseline", "--baseline", b)
+    assert r2.returncode == 0 and " 0 failed" in r2.stdout, r2.stdout + r2.stderr
+    assert len(open(b).read().split("\n")) >= 12
+
+
+@pytest.mark.gpu
+def test_tau2d_and_sph_end_to_end(built):
+    r = run(os.path.join(built, "tau_2d_hypersonic_cuda"), "--W", "512", "--H", "256", "--frames", "2")
+    assert r.returncode == 0 and "step 4" in r.stdout, r.stdout + r.stderr
+    m = re.search(r"step 4  t=(\S+)", r.stdout)
+    assert float(m.group(1)) == pytest.approx(GOLD["tau2d_cuda_512x256_4steps_tile32x4"]["t"], rel=1e-5)
+    r = run(os.path.join(built, "tau_sph"), "--n", "4096", "--headless", "--steps", "3")
+    assert r.returncode == 0 and "grid=16x16" in r.stdout, r.stdout + r.stderr
