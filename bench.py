@@ -52,6 +52,19 @@ def cpu_baseline(n, state_slab, dt, z0, planes, max_seconds=25.0):
                       f"{el:.1f} s, gcc -O2 IEEE fp32, 1 thread (the reference is single-threaded)"}
 
 
+def cpu_baseline_2d(steps=100):
+    """What north_star names: tau_hypersonic_simd.c (fp64, AVX2 compute_dt, -O3 -mavx2 -mfma) on the host,
+    300^2 as shipped, 1 thread — the restated CPU program of BASELINE config 1 (fluid-sims_amd/cpu/)."""
+    from importlib import import_module
+    m = import_module("fluid_sims_amd.cpu2d")
+    s = m.CpuHypersonic2D(300, 300, simd=True)
+    t0 = time.perf_counter()
+    s.step(steps)
+    el = time.perf_counter() - t0
+    return {"value": 300 * 300 * steps / el / 1e9, "unit": "Gcell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"tau_hypersonic_simd restated, 2D 300x300 fp64, {steps} steps, {el:.2f} s, 1 thread"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +178,10 @@ def main():
             planes = min(planes, n)
             st = h.download_planes(zc - 3, zc + planes + 3)
             out["cpu_baseline"] = cpu_baseline(n, [np.ascontiguousarray(a) for a in st], clk.dt, zc, planes)
+            try:
+                out["cpu_baseline_2d_simd"] = cpu_baseline_2d()
+            except Exception as e:  # the 2D CPU program is an extra, never fatal for the headline
+                out["cpu_baseline_2d_simd"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
 
     if world > 1:

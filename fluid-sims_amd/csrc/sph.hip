@@ -59,14 +59,17 @@ __global__ __launch_bounds__(256) void k_keys(const Args A) { // k_build_cells' 
   A.cellOf[i] = c;
 }
 
+// cellStart[c] = first sorted slot whose key is >= c (lower bound), one lane per cell: empty cells
+// and the empty top of the box cost a 22-step binary search each instead of a serial fill
 __global__ __launch_bounds__(256) void k_cell_start(const Args A) {
-  int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= A.N) return;
-  int c = (int)A.keys_s[k];
-  int prev = (k == 0) ? -1 : (int)A.keys_s[k - 1];
-  for (int cc = prev + 1; cc <= c; cc++) A.cellStart[cc] = k;   // also fills empty cells
-  if (k == A.N - 1)
-    for (int cc = c + 1; cc <= A.M; cc++) A.cellStart[cc] = A.N;
+  int c = blockIdx.x * 256 + threadIdx.x;
+  if (c > A.M) return;
+  int lo = 0, hi = A.N;
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if ((int)A.keys_s[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  A.cellStart[c] = lo;
 }
 
 __global__ __launch_bounds__(256) void k_gather(const Args A) {
@@ -333,7 +336,7 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
   TAU_LAUNCH_CHECK("sph::k_keys");
   TAU_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, h->cub_bytes, A.keys, A.keys_s, A.ids, A.ids_s, A.N, 0,
                                              h->key_bits, h->stream));
-  hipLaunchKernelGGL(sph::k_cell_start, dim3(gs), dim3(256), 0, h->stream, A);
+  hipLaunchKernelGGL(sph::k_cell_start, dim3((unsigned)((A.M + 1 + 255) / 256)), dim3(256), 0, h->stream, A);
   TAU_LAUNCH_CHECK("sph::k_cell_start");
   hipLaunchKernelGGL(sph::k_gather, dim3(gs), dim3(256), 0, h->stream, A);
   TAU_LAUNCH_CHECK("sph::k_gather");

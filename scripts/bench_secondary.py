@@ -1,0 +1,76 @@
+#!/usr/bin/env python
+"""Throughput of the non-headline configs of BASELINE.json on one MI355X (inputs resident in HBM):
+Gray-Scott 8192^2, Burgers / shallow-water viscosity passes 8192^2, 2D Euler 4096^2 fp32, SPH 4M particles.
+Prints one JSON line per workload with the algorithmic-bytes roofline fraction."""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+import fluid_sims_amd as f  # noqa: E402
+
+HBM = 8000.0
+
+
+def timed(step_async, sync, units_per_step, steps, warm):
+    step_async(warm)
+    sync()
+    t0 = time.perf_counter()
+    step_async(steps)
+    sync()
+    el = time.perf_counter() - t0
+    return units_per_step * steps / el, el / steps * 1e3
+
+
+def line(name, unit, rate, ms, bytes_per_unit, bound, extra=None):
+    gbs = rate * bytes_per_unit / 1e9
+    d = {"workload": name, "value": round(rate / 1e9, 4), "unit": "G" + unit + "/s", "ms_per_step": round(ms, 4),
+         "algorithmic_bytes_per_unit": bytes_per_unit, "achieved_GBps": round(gbs, 1), "hbm_peak_GBps": HBM,
+         "frac_hbm": round(gbs / HBM, 4), "binding_bound": bound}
+    d.update(extra or {})
+    print(json.dumps(d), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--quick", action="store_true")
+    a = ap.parse_args()
+    k = 0.25 if a.quick else 1.0
+
+    n = 8192
+    g = f.GrayScott(n, n)
+    g.init_pattern(1337)
+    r, ms = timed(g.step_async, g.sync, n * n, int(400 * k), 20)
+    line(f"tau_gray_scott {n}^2", "cell-updates", r, ms, 16, "hbm")
+    g.close()
+    rng = np.random.default_rng(1)
+    fld = (rng.standard_normal((n, n)) * 0.5).astype(np.float32)
+    for kind, bound in (("sw", "hbm"), ("burgers", "valu(sinh/asinh)+hbm")):
+        h = f.Laplacian2D(n, n, kind, nu=0.1, dt=0.2, u0=1.0)
+        h.upload(fld, fld * 0.5)
+        r, ms = timed(h.step_async, h.sync, n * n, int(400 * k), 10)
+        line(f"{kind} viscosity pass {n}^2", "cell-updates", r, ms, 16, bound)
+        h.close()
+    del fld
+
+    n = 4096
+    e = f.Hypersonic2D(n, n)
+    e.init()
+    r, ms = timed(e.step_async, e.sync, n * n, int(400 * k), 100)
+    line(f"tau_hypersonic_cuda {n}^2 fp32", "cell-updates", r, ms, 33, "valu", {"sim": e.time()})
+    e.close()
+
+    N = 1 << 22
+    s = f.Sph2D(N)
+    s.reset_particles()
+    r, ms = timed(s.step_async, s.sync, N, int(100 * k), 20)
+    line(f"tau_sph {N} particles", "particle-substeps", r, ms, 100, "pair-evaluation valu/latency", {"grid": s.grid()})
+    s.close()
+
+
+if __name__ == "__main__":
+    main()
