@@ -5,8 +5,8 @@
 //
 // All three are two fp32 fields in, two out, 16 B/cell of compulsory HBM traffic — HBM bound.
 // CDNA4 layout: a wave64 owns a 256-column strip (one float4 per lane = 1 KiB per load
-// instruction) and MARCHES down the rows keeping the three live rows in VGPRs, so every
-// row is fetched once per strip; left/right neighbours come from the adjacent lane
+// instruction) and MARCHES down a chunk of rows keeping the three live rows in VGPRs, so every
+// row is fetched once per strip and chunk (chunk-edge rows a second time, from L2); left/right neighbours come from the adjacent lane
 // (wave shuffle), only the two edge lanes of a strip issue an extra scalar load.  No LDS, no
 // integer modulo per cell (the reference wraps every index with %; here only strip edges and
 // chunk edges wrap, on scalar registers).
@@ -17,12 +17,13 @@
 #include "../../include/taueng.h"
 #include "tau_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
 namespace st2 {
 
-constexpr int ROWS = 32;        // rows marched by one wave
+constexpr int ROWS = 8;         // rows marched by one wave (measured best at 8192^2: 32 k waves, halo rows come from L2)
 constexpr int WAVES = 4;        // waves per workgroup
 enum { K_GS = 0, K_BURGERS = 1, K_SW = 2 };
 
@@ -30,7 +31,7 @@ struct Args {
   const float *a, *b;
   float *oa, *ob;
   int nx, ny;
-  int nstrips, nchunks;
+  int nstrips, nchunks, rows, nt;
   // Gray-Scott
   float dx2, dt, Du, Dv, feed, kill;
   // Laplacian passes
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(const Args A) {
   const bool first = lane == 0, last = lane == nl - 1;
   const int xl = (strip * 256 - 1 + A.nx) % A.nx;     // scalar (wave-uniform)
   const int xr = (strip * 256 + nl * 4) % A.nx;
-  const int j0 = chunk * ROWS;
-  const int j1 = min(j0 + ROWS, A.ny);
+  const int j0 = chunk * A.rows;
+  const int j1 = min(j0 + A.rows, A.ny);
 
   Row up, cur, dn;
   load_row<KIND>(A, (j0 - 1 + A.ny) % A.ny, x4, xl, xr, act, first, last, up);
@@ -141,8 +142,14 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(const Args A) {
       cell<KIND>(A, cur.a.z, cur.a.y, cur.a.w, up.a.z, dn.a.z, cur.b.z, cur.b.y, cur.b.w, up.b.z, dn.b.z, oa.z, ob.z);
       cell<KIND>(A, cur.a.w, cur.a.z, ar, up.a.w, dn.a.w, cur.b.w, cur.b.z, br, up.b.w, dn.b.w, oa.w, ob.w);
       const size_t o = (size_t)j * A.nx + x4;
-      *reinterpret_cast<float4 *>(A.oa + o) = oa;
-      *reinterpret_cast<float4 *>(A.ob + o) = ob;
+      if (A.nt) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(v4f{oa.x, oa.y, oa.z, oa.w}, reinterpret_cast<v4f *>(A.oa + o));
+        __builtin_nontemporal_store(v4f{ob.x, ob.y, ob.z, ob.w}, reinterpret_cast<v4f *>(A.ob + o));
+      } else {
+        *reinterpret_cast<float4 *>(A.oa + o) = oa;
+        *reinterpret_cast<float4 *>(A.ob + o) = ob;
+      }
     }
     up = cur; cur = dn; dn = nx2;
   }
@@ -171,8 +178,12 @@ template <int KIND>
 static int launch(const Args &Ain, hipStream_t s) {
   Args A = Ain;
   if ((A.nx & 3) == 0) {
+    static const int env_rows = getenv("TAU_ST2_ROWS") ? atoi(getenv("TAU_ST2_ROWS")) : 0;
+    static const int env_nt = getenv("TAU_ST2_NT") ? atoi(getenv("TAU_ST2_NT")) : 1;   // streaming (nt) stores: +2-4 %
+    A.rows = env_rows > 0 ? env_rows : ROWS;
+    A.nt = env_nt;
     A.nstrips = (A.nx + 255) / 256;
-    A.nchunks = (A.ny + ROWS - 1) / ROWS;
+    A.nchunks = (A.ny + A.rows - 1) / A.rows;
     unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
     unsigned nb = (nwork + WAVES - 1) / WAVES;
     hipLaunchKernelGGL(k_march<KIND>, dim3(nb), dim3(64 * WAVES), 0, s, A);
