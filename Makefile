@@ -3,11 +3,10 @@
 #
 #   make            engine library + every driver
 #   make cpu        tau_hypersonic tau_hypersonic_simd            (CPU programs, as in the reference)
-#   make cuda       tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph   (HIP engine behind them)
+#   make cuda       tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph tau_burgers tau_sw   (HIP engine behind them)
 #   make test       the reference's regression round trip (needs an MI355X)
 #   make <target>   a single program by its reference name
-# Not provided: jsc jsc3d sim tau_mhd number_fluid2d/3d th3cs tau_burgers tau_sw (out of the hot-path
-# scope of this round; the Burgers / shallow-water viscosity passes are in the library).
+# Not provided: jsc jsc3d sim tau_mhd number_fluid2d/3d th3cs (out of the hot-path scope).
 CC      ?= gcc
 ROCM    ?= /opt/rocm
 ENG      = fluid-sims_amd
@@ -16,7 +15,7 @@ CFLAGS  ?= -O2 -Wall -std=gnu99
 LINK     = -L$(ENG)/lib -ltaueng -L$(ROCM)/lib -lamdhip64 -lstdc++ -lm -Wl,-rpath,$(abspath $(ENG)/lib) -Wl,-rpath,$(ROCM)/lib
 
 CPU_BINS  := tau_hypersonic tau_hypersonic_simd
-CUDA_BINS := tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph
+CUDA_BINS := tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph tau_burgers tau_sw
 
 .PHONY: all cpu cuda test clean engine $(CPU_BINS) $(CUDA_BINS)
 all: cpu cuda
@@ -40,6 +39,13 @@ $(BIN)/tau_hypersonic: $(ENG)/apps/tau_hypersonic.c $(ENG)/cpu/tau_hypersonic_cp
 $(BIN)/tau_hypersonic_simd: $(ENG)/apps/tau_hypersonic.c $(ENG)/cpu/tau_hypersonic_cpu.c
 	@mkdir -p $(BIN)
 	$(CC) -O3 -mavx2 -mfma -DTAU_SIMD $^ -lm -o $@
+
+$(BIN)/tau_burgers: $(ENG)/apps/tau_flow.c $(ENG)/apps/tau_cli.h include/taueng.h engine
+	@mkdir -p $(BIN)
+	$(CC) $(CFLAGS) $< -o $@ $(LINK)
+$(BIN)/tau_sw: $(ENG)/apps/tau_flow.c $(ENG)/apps/tau_cli.h include/taueng.h engine
+	@mkdir -p $(BIN)
+	$(CC) $(CFLAGS) -DTAU_SW $< -o $@ $(LINK)
 
 $(CUDA_BINS): %: $(BIN)/%
 $(BIN)/%: $(ENG)/apps/%.c $(ENG)/apps/tau_cli.h include/taueng.h engine

@@ -1,0 +1,122 @@
+/* tau_burgers / tau_sw — headless drivers of the 2D viscous Burgers and shallow-water solvers.
+ *
+ * Stand where the reference's targets do (Makefile:75-76, 90-91; tau_burgers.cu, tau_shallow_water.cu):
+ * same long options (tau_burgers.cu:143-240; tau_shallow_water.cu:147-172 + its parser), same defaults,
+ * same loop (do_step + tau += dtau, t *= exp(dtau)), same headless report (steps, frames, FPS — the
+ * reference's only throughput print, tau_burgers.cu:790-820).  ncurses rendering is out of scope, so the
+ * programs always run the headless branch; --steps 0 means 2000 steps as in that branch (:797).
+ * Built twice: -DTAU_SW selects the shallow-water option table.  Additive: --dump PATH.
+ */
+#include "tau_cli.h"
+#include <getopt.h>
+
+#ifdef TAU_SW
+#define KIND 1
+#define PROG "tau_sw"
+#else
+#define KIND 0
+#define PROG "tau_burgers"
+#endif
+
+int main(int argc, char **argv) {
+  tauflow_params P;
+  tauflow_params_default(&P, KIND, 512, 512);
+  int steps = 0, stride = 5, colehopf = 0;
+  const char *dump = NULL;
+  static const struct option lo[] = {
+      {"nx", required_argument, 0, 0}, {"ny", required_argument, 0, 0}, {"dx", required_argument, 0, 0},
+      {"dy", required_argument, 0, 0}, {"nu", required_argument, 0, 0}, {"CFL", required_argument, 0, 0},
+      {"steps", required_argument, 0, 0}, {"tau0", required_argument, 0, 0}, {"t0", required_argument, 0, 0},
+      {"dtau", required_argument, 0, 0}, {"offx", required_argument, 0, 0}, {"offy", required_argument, 0, 0},
+      {"asym", required_argument, 0, 0}, {"swirl", required_argument, 0, 0}, {"headless", no_argument, 0, 'H'},
+      {"stride", required_argument, 0, 'r'}, {"fps", required_argument, 0, 'f'}, {"halfblocks", no_argument, 0, 0},
+      {"dump", required_argument, 0, 0}, {"help", no_argument, 0, 'h'},
+#ifdef TAU_SW
+      {"g", required_argument, 0, 0}, {"f0", required_argument, 0, 0}, {"H0", required_argument, 0, 0},
+      {"bump", required_argument, 0, 0}, {"bsig", required_argument, 0, 0}, {"rc", required_argument, 0, 0},
+#else
+      {"u0", required_argument, 0, 0}, {"amp", required_argument, 0, 0}, {"bsig", required_argument, 0, 0},
+      {"rc", required_argument, 0, 0}, {"muscl", no_argument, 0, 0}, {"visc_substeps", required_argument, 0, 0},
+      {"colehopf", no_argument, 0, 0}, {"ck", required_argument, 0, 0}, {"ca", required_argument, 0, 0},
+#endif
+      {0, 0, 0, 0}};
+  int idx = 0, c;
+  while ((c = getopt_long(argc, argv, "Hr:f:h", lo, &idx)) != -1) {
+    if (c == 'h') { printf("Usage: %s [options]   (long options of the reference program; see the source header)\n", argv[0]); return 0; }
+    if (c == 'H' || c == 'f') continue;
+    if (c == 'r') { stride = atoi(optarg); continue; }
+    if (c != 0) return 1;
+    const char *n = lo[idx].name;
+    if (!strcmp(n, "nx")) P.nx = atoi(optarg);
+    else if (!strcmp(n, "ny")) P.ny = atoi(optarg);
+    else if (!strcmp(n, "dx")) P.dx = (float)atof(optarg);
+    else if (!strcmp(n, "dy")) P.dy = (float)atof(optarg);
+    else if (!strcmp(n, "nu")) P.nu = (float)atof(optarg);
+    else if (!strcmp(n, "CFL")) P.CFL = (float)atof(optarg);
+    else if (!strcmp(n, "steps")) steps = atoi(optarg);
+    else if (!strcmp(n, "tau0")) P.tau0 = (float)atof(optarg);
+    else if (!strcmp(n, "t0")) P.t0 = (float)atof(optarg);
+    else if (!strcmp(n, "dtau")) P.dtau = (float)atof(optarg);
+    else if (!strcmp(n, "offx")) P.offx = (float)atof(optarg);
+    else if (!strcmp(n, "offy")) P.offy = (float)atof(optarg);
+    else if (!strcmp(n, "asym")) P.asym = (float)atof(optarg);
+    else if (!strcmp(n, "swirl")) P.swirl = (float)atof(optarg);
+    else if (!strcmp(n, "bsig")) P.bsig = (float)atof(optarg);
+    else if (!strcmp(n, "rc")) P.rc = (float)atof(optarg);
+    else if (!strcmp(n, "dump")) dump = optarg;
+    else if (!strcmp(n, "halfblocks")) { /* display only */ }
+#ifdef TAU_SW
+    else if (!strcmp(n, "g")) P.g = (float)atof(optarg);
+    else if (!strcmp(n, "f0")) { /* parsed and shown by the reference, never used by a kernel */ }
+    else if (!strcmp(n, "H0")) P.H0 = (float)atof(optarg);
+    else if (!strcmp(n, "bump")) P.amp = (float)atof(optarg);
+#else
+    else if (!strcmp(n, "u0")) P.u0 = (float)atof(optarg);
+    else if (!strcmp(n, "amp")) P.amp = (float)atof(optarg);
+    else if (!strcmp(n, "muscl")) P.muscl = 1;
+    else if (!strcmp(n, "visc_substeps")) P.visc_substeps = atoi(optarg);
+    else if (!strcmp(n, "colehopf")) { colehopf = 1; P.oneD = 1; }
+    else if (!strcmp(n, "ck")) P.ck = atoi(optarg);
+    else if (!strcmp(n, "ca")) P.ca = (float)atof(optarg);
+#endif
+  }
+  if (stride < 1) stride = 1;
+  if (colehopf) P.ny = 1; /* tau_burgers.cu:654-655 */
+  cli_need_gpu();
+  tauflow_t *h = NULL;
+  TAU_CK(tauflow_create(&h, &P, KIND, 0, NULL));
+  TAU_CK(tauflow_init(h));
+  const int nsteps = steps ? steps : 2000;
+  int frames = 0;
+  double elapsed = 0.0, t0 = cli_now();
+  for (int s = 0; s < nsteps; s++) {
+    TAU_CK(tauflow_step_async(h, 1));
+    if (colehopf) { float dt; TAU_CK(tauflow_get_clock(h, NULL, NULL, &dt, NULL, NULL)); elapsed += dt; }
+    if (s % stride == 0) frames++;
+  }
+  TAU_CK(tauflow_sync(h));
+  double secs = cli_now() - t0;
+  float t, tau, dt, w; int64_t st;
+  TAU_CK(tauflow_get_clock(h, &t, &tau, &dt, &w, &st));
+  printf("Headless (stride=%d):\n  Steps: %d\n  Wall:  %d frames in %.3f s -> %.1f FPS\n", stride, nsteps, frames, secs,
+         frames > 0 ? frames / secs : 0.0);
+  printf("  %s %dx%d: t=%.6g tau=%.6g dt=%.4g wavespeed=%.6g  %.3f Gcell-updates/s\n", PROG, P.nx, P.ny, t, tau, dt, w,
+         (double)P.nx * P.ny * nsteps / secs / 1e9);
+  if (colehopf) {
+    double rel;
+    TAU_CK(tauflow_colehopf_relL2(h, (float)elapsed, &rel));
+    printf("  Cole-Hopf relative L2 error at elapsed t=%.6g: %.3e\n", elapsed, rel);
+  }
+  if (dump) {
+    size_t n = (size_t)P.nx * P.ny;
+    float *f[3] = {(float *)malloc(n * 4), (float *)malloc(n * 4), (float *)malloc(n * 4)};
+    TAU_CK(tauflow_download(h, f));
+    char hdr[128];
+    snprintf(hdr, sizeof hdr, PROG " f32 %s nx=%d ny=%d steps=%d", KIND ? "sigma,u,v" : "phi_u,phi_v", P.nx, P.ny, nsteps);
+    const void *arrs[3] = {f[0], f[1], f[2]};
+    size_t by[3] = {n * 4, n * 4, n * 4};
+    if (!cli_dump(dump, hdr, arrs, by, KIND ? 3 : 2)) return 1;
+  }
+  tauflow_destroy(h);
+  return 0;
+}

@@ -1,0 +1,495 @@
+// flow2d.hip — full time step of the 2D viscous Burgers and shallow-water solvers for gfx950.
+//
+// Reference pipelines, per step:
+//   tau_burgers.cu:677-718        wavespeed_block_max + HOST max -> flux_x_kernel, flux_y_kernel ->
+//                                 update_convective -> K x viscosity_step          (6 arrays of scratch)
+//   tau_shallow_water.cu:671-705  wavespeed_block_max + HOST max -> flux_x_kernel, flux_y_kernel ->
+//                                 update_kernel -> viscosity_uv                     (6 arrays of scratch)
+// Here ONE kernel per step: a 256-thread workgroup stages its 32x8 tile (+halo) in LDS, every cell of
+// the tile + 1-cell ring forms its four face fluxes from LDS and takes the conservative update into
+// LDS, the tile then applies the first viscosity pass to those updated values (the race-free form of
+// the reference's in-place Laplacian), writes the new state and reduces the wavespeed of the NEW
+// state (wave64 butterfly + one atomicMax per workgroup) for the next step's dt — no flux arrays,
+// no separate reduction pass, no host round trip.  Compulsory traffic: Burgers 16 B/cell, shallow
+// water 24 B/cell (the reference moves ~100-130 B/cell).
+//
+// Deviation (rounding level): the reference re-encodes after the convective update and the viscosity
+// kernel decodes again (phi = asinh(u/u0); u = u0 sinh(phi)); the fused kernel keeps u between the two.
+
+#include "../../include/taueng.h"
+#include "tau_common.h"
+#include <cmath>
+#include <new>
+#include <vector>
+
+namespace fl2 {
+
+constexpr int TX = 32, TY = 8, NT = TX * TY;
+constexpr int HB = 3;                               // tile halo (MUSCL: faces of the ring need +-2 more)
+constexpr int UW = TX + 2 * HB, UH = TY + 2 * HB;   // 38 x 14
+constexpr int RW = TX + 2, RH = TY + 2;             // updated values: tile + ring 1
+enum { K_BURGERS = 0, K_SW = 1 };
+
+struct DevState {
+  unsigned maxbits[2];   // wavespeed metric of the state on each ping-pong side (float bits)
+  float dt_last;
+  int pad;
+};
+
+struct Args {
+  const float *in[3];
+  float *out[3];
+  DevState *st;
+  int nx, ny, ntx, nty, cur;
+  float dx, dy, invdx, invdy, invdx2, invdy2, nu, u0, inv_u0, g, CFL, dt_try, dt_explicit, cfl_len;
+  int muscl, oneD, do_visc, reduce;
+  float visc_frac;       // dt fraction of the fused viscosity pass (1/K)
+};
+
+__device__ __forceinline__ float fsinh(float x) {
+  float ax = fabsf(x), x2 = x * x;
+  float series = x * (1.f + x2 * (1.f / 6.f) * (1.f + x2 * (1.f / 20.f) * (1.f + x2 * (1.f / 42.f))));
+  float e = __builtin_amdgcn_exp2f(ax * 1.44269504088896341f);
+  float big = copysignf(0.5f * (e - __builtin_amdgcn_rcpf(e)), x);
+  return (ax < 0.5f) ? series : big;
+}
+__device__ __forceinline__ float fasinh(float x) {
+  float ax = fabsf(x), x2 = x * x;
+  float series = ax * (1.f + x2 * (-1.f / 6.f + x2 * (3.f / 40.f + x2 * (-15.f / 336.f + x2 * (105.f / 3456.f)))));
+  float big = __builtin_amdgcn_logf(ax + __builtin_amdgcn_sqrtf(x2 + 1.0f)) * 0.69314718055994531f;
+  return copysignf((ax < 0.125f) ? series : big, x);
+}
+__device__ __forceinline__ float minmodf(float a, float b) { // tau_burgers.cu:332-334
+  return (a * b <= 0.0f) ? 0.0f : copysignf(fminf(fabsf(a), fabsf(b)), a);
+}
+__device__ __forceinline__ int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
+
+// Rusanov flux of the Burgers system through one face along `ax`, from the four phi values
+// (m1, c | p1, p2) of each component around it; flux_x_kernel / flux_y_kernel, :364-455
+__device__ __forceinline__ void burgers_face(const Args &A, float um1, float uc, float up1, float up2, float vm1, float vc,
+                                             float vp1, float vp2, int ax, float &Fu, float &Fv) {
+  float pUL = uc, pUR = up1, pVL = vc, pVR = vp1;
+  if (A.muscl) {
+    pUL = uc + 0.5f * minmodf(uc - um1, up1 - uc);
+    pUR = up1 - 0.5f * minmodf(up2 - up1, up1 - uc);
+    pVL = vc + 0.5f * minmodf(vc - vm1, vp1 - vc);
+    pVR = vp1 - 0.5f * minmodf(vp2 - vp1, vp1 - vc);
+  }
+  // without MUSCL the face states are the cell values, which the staging loop has already decoded
+  const float uL = A.muscl ? A.u0 * fsinh(pUL) : pUL, vL = A.muscl ? A.u0 * fsinh(pVL) : pVL;
+  const float uR = A.muscl ? A.u0 * fsinh(pUR) : pUR, vR = A.muscl ? A.u0 * fsinh(pVR) : pVR;
+  if (ax == 0) {
+    const float a = fmaxf(fabsf(uL), fabsf(uR));
+    Fu = 0.5f * (0.5f * uL * uL + 0.5f * uR * uR) - 0.5f * a * (uR - uL);
+    Fv = 0.5f * (uL * vL + uR * vR) - 0.5f * a * (vR - vL);
+  } else {
+    const float a = fmaxf(fabsf(vL), fabsf(vR));
+    Fu = 0.5f * (uL * vL + uR * vR) - 0.5f * a * (uR - uL);
+    Fv = 0.5f * (0.5f * vL * vL + 0.5f * vR * vR) - 0.5f * a * (vR - vL);
+  }
+}
+
+// HLL flux of the shallow-water system (n = normal, t = tangential velocity), hll_x / hll_y, :327-390
+__device__ __forceinline__ void sw_face(float g, float hL, float unL, float utL, float hR, float unR, float utR, float &Fh,
+                                        float &Fn, float &Ft) {
+  const float cL = sqrtf(g * hL), cR = sqrtf(g * hR);
+  const float sL = fminf(unL - cL, unR - cR), sR = fmaxf(unL + cL, unR + cR);
+  const float mL = hL * unL, mR = hR * unR, nL = hL * utL, nR = hR * utR;
+  const float FLh = mL, FLn = mL * unL + 0.5f * g * hL * hL, FLt = mL * utL;
+  const float FRh = mR, FRn = mR * unR + 0.5f * g * hR * hR, FRt = mR * utR;
+  if (sL >= 0.0f) { Fh = FLh; Fn = FLn; Ft = FLt; return; }
+  if (sR <= 0.0f) { Fh = FRh; Fn = FRn; Ft = FRt; return; }
+  const float inv = 1.0f / (sR - sL), ss = sR * sL;
+  Fh = (sR * FLh - sL * FRh + ss * (hR - hL)) * inv;
+  Fn = (sR * FLn - sL * FRn + ss * (mR - mL)) * inv;
+  Ft = (sR * FLt - sL * FRt + ss * (nR - nL)) * inv;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(NT) void k_step(const Args A) {
+  constexpr int NF = (KIND == K_BURGERS) ? 2 : 3;
+  __shared__ float sU[NF][UH * UW];       // Burgers: phi_u, phi_v ; SW: h, u, v
+  __shared__ float sN[3][RH * RW];        // updated u, v (and h for shallow water) on tile + ring
+  __shared__ float sRed[NT / 64];
+
+  const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid >> 5, lane = tid & 63, wave = tid >> 6;
+  unsigned b = tau::xcd_swizzle(blockIdx.x, (unsigned)(A.ntx * A.nty));
+  const int bx0 = (int)(b % (unsigned)A.ntx) * TX, by0 = (int)(b / (unsigned)A.ntx) * TY;
+
+  float dt; // dt_eff = min(t*dtau, CFL*len/max), tau_burgers.cu:693-694, tau_shallow_water.cu:689-690
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float m = __uint_as_float(A.st->maxbits[A.cur]);
+    if (!(m >= 1e-12f)) m = 1e-12f;
+    dt = fminf(A.dt_try, A.CFL * A.cfl_len / m);
+  }
+
+  for (int t = tid; t < UH * UW; t += NT) {
+    const int ly = t / UW, lx = t - ly * UW;
+    const size_t gi = (size_t)wrapi(by0 - HB + ly, A.ny) * A.nx + wrapi(bx0 - HB + lx, A.nx);
+    if (KIND == K_BURGERS) { // MUSCL limits the encoded phi, so phi is staged raw; otherwise decode once here
+      const float a = A.in[0][gi], bb = A.in[1][gi];
+      sU[0][t] = A.muscl ? a : A.u0 * fsinh(a);
+      sU[1][t] = A.muscl ? bb : A.u0 * fsinh(bb);
+    }
+    else { sU[0][t] = expf(A.in[0][gi]); sU[1][t] = A.in[1][gi]; sU[NF - 1][t] = A.in[NF - 1][gi]; }
+  }
+  __syncthreads();
+
+  // ---- conservative update of every cell of tile + ring (each cell forms its own four face fluxes)
+  for (int t = tid; t < RH * RW; t += NT) {
+    const int ry = t / RW, rx = t - ry * RW;
+    const int c = (ry + HB - 1) * UW + (rx + HB - 1);
+    float un, vn;
+    if (KIND == K_BURGERS) {
+      const float *pu = sU[0], *pv = sU[1];
+      float Fu_lo, Fv_lo, Fu_hi, Fv_hi, Gu_lo = 0.f, Gv_lo = 0.f, Gu_hi = 0.f, Gv_hi = 0.f;
+      burgers_face(A, pu[c - 2], pu[c - 1], pu[c], pu[c + 1], pv[c - 2], pv[c - 1], pv[c], pv[c + 1], 0, Fu_lo, Fv_lo);
+      burgers_face(A, pu[c - 1], pu[c], pu[c + 1], pu[c + 2], pv[c - 1], pv[c], pv[c + 1], pv[c + 2], 0, Fu_hi, Fv_hi);
+      if (!A.oneD) {
+        burgers_face(A, pu[c - 2 * UW], pu[c - UW], pu[c], pu[c + UW], pv[c - 2 * UW], pv[c - UW], pv[c], pv[c + UW], 1, Gu_lo, Gv_lo);
+        burgers_face(A, pu[c - UW], pu[c], pu[c + UW], pu[c + 2 * UW], pv[c - UW], pv[c], pv[c + UW], pv[c + 2 * UW], 1, Gu_hi, Gv_hi);
+      }
+      const float invdy = A.oneD ? 0.0f : A.invdy;
+      const float uc0 = A.muscl ? A.u0 * fsinh(pu[c]) : pu[c], vc0 = A.muscl ? A.u0 * fsinh(pv[c]) : pv[c];
+      un = uc0 - dt * ((Fu_hi - Fu_lo) * A.invdx + (Gu_hi - Gu_lo) * invdy); // update_convective, :458-487
+      vn = vc0 - dt * ((Fv_hi - Fv_lo) * A.invdx + (Gv_hi - Gv_lo) * invdy);
+    } else {
+      const float *ph = sU[0], *pu = sU[1], *pv = sU[NF - 1];
+      float Fh_lo, Fmx_lo, Fmy_lo, Fh_hi, Fmx_hi, Fmy_hi, Gh_lo, Gmx_lo, Gmy_lo, Gh_hi, Gmx_hi, Gmy_hi;
+      sw_face(A.g, ph[c - 1], pu[c - 1], pv[c - 1], ph[c], pu[c], pv[c], Fh_lo, Fmx_lo, Fmy_lo);
+      sw_face(A.g, ph[c], pu[c], pv[c], ph[c + 1], pu[c + 1], pv[c + 1], Fh_hi, Fmx_hi, Fmy_hi);
+      sw_face(A.g, ph[c - UW], pv[c - UW], pu[c - UW], ph[c], pv[c], pu[c], Gh_lo, Gmy_lo, Gmx_lo);
+      sw_face(A.g, ph[c], pv[c], pu[c], ph[c + UW], pv[c + UW], pu[c + UW], Gh_hi, Gmy_hi, Gmx_hi);
+      float h = ph[c], mx = h * pu[c], my = h * pv[c]; // update_kernel, :474-513
+      h -= dt * ((Fh_hi - Fh_lo) * A.invdx + (Gh_hi - Gh_lo) * A.invdy);
+      mx -= dt * ((Fmx_hi - Fmx_lo) * A.invdx + (Gmx_hi - Gmx_lo) * A.invdy);
+      my -= dt * ((Fmy_hi - Fmy_lo) * A.invdx + (Gmy_hi - Gmy_lo) * A.invdy);
+      h = fmaxf(h, 1e-6f);
+      un = mx / h;
+      vn = my / h;
+      sN[2][t] = h;
+    }
+    sN[0][t] = un;
+    sN[1][t] = vn;
+  }
+  __syncthreads();
+
+  // ---- first viscosity pass on the updated values (viscosity_step :490-525 / viscosity_uv :516-547), store
+  const int x = bx0 + tx, y = by0 + ty;
+  float red = 0.f;
+  if (x < A.nx && y < A.ny) {
+    const int r = (ty + 1) * RW + (tx + 1);
+    float u = sN[0][r], v = sN[1][r];
+    if (A.do_visc) {
+      const float nudt = A.nu * (dt * A.visc_frac);
+      const float invdy2 = (KIND == K_BURGERS && A.oneD) ? 0.0f : A.invdy2;
+      const float lu = (sN[0][r + 1] - 2.0f * u + sN[0][r - 1]) * A.invdx2 + (sN[0][r + RW] - 2.0f * u + sN[0][r - RW]) * invdy2;
+      const float lv = (sN[1][r + 1] - 2.0f * v + sN[1][r - 1]) * A.invdx2 + (sN[1][r + RW] - 2.0f * v + sN[1][r - RW]) * invdy2;
+      u += nudt * lu;
+      v += nudt * lv;
+    }
+    const size_t gi = (size_t)y * A.nx + x;
+    if (KIND == K_BURGERS) {
+      A.out[0][gi] = fasinh(u * A.inv_u0);
+      A.out[1][gi] = fasinh(v * A.inv_u0);
+      red = fabsf(u) * A.invdx + fabsf(v) * ((A.ny > 1) ? A.invdy : 0.0f); // wavespeed_block_max, :337-361
+    } else {
+      const float own_h = sN[2][r];
+      A.out[0][gi] = logf(own_h);
+      A.out[1][gi] = u;
+      A.out[NF - 1][gi] = v;
+      const float c = sqrtf(A.g * own_h);
+      red = fmaxf(fabsf(u) + c, fabsf(v) + c); // :394-422
+    }
+  }
+  if (A.reduce) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) red = fmaxf(red, __shfl_xor(red, o, 64));
+    if (lane == 0) sRed[wave] = red;
+    __syncthreads();
+    if (tid == 0) {
+      float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+      tau::atomic_max_float_bits(&A.st->maxbits[A.cur ^ 1], m);
+    }
+  }
+}
+
+// wavespeed metric of a state (first step after init / upload, and after extra Burgers viscosity passes)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_metric(const Args A, int slot) {
+  __shared__ float sRed[4];
+  const size_t n = (size_t)A.nx * A.ny;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    if (KIND == K_BURGERS) {
+      float u = A.u0 * fsinh(A.in[0][i]), v = A.u0 * fsinh(A.in[1][i]);
+      m = fmaxf(m, fabsf(u) * A.invdx + fabsf(v) * ((A.ny > 1) ? A.invdy : 0.0f));
+    } else {
+      float c = sqrtf(A.g * expf(A.in[0][i]));
+      m = fmaxf(m, fmaxf(fabsf(A.in[1][i]) + c, fabsf(A.in[2][i]) + c));
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) sRed[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
+    tau::atomic_max_float_bits(&A.st->maxbits[slot], m);
+  }
+}
+
+__global__ void k_prepare(DevState *s, int cur, float dt_try, float CFLlen, float dt_explicit) {
+  float dt = dt_explicit;
+  if (!(dt > 0.f)) {
+    float m = __uint_as_float(s->maxbits[cur]);
+    if (!(m >= 1e-12f)) m = 1e-12f;
+    dt = fminf(dt_try, CFLlen / m);
+  }
+  s->dt_last = dt;
+  s->maxbits[cur ^ 1] = 0u;
+}
+
+} // namespace fl2
+
+// =====================================================================================
+// C-ABI
+// =====================================================================================
+struct tauflow {
+  tauflow_params p;
+  int kind, nf, device;
+  hipStream_t stream;
+  bool own_stream;
+  float *buf[2][3];
+  fl2::DevState *st;
+  int cur;
+  bool max_valid;
+  float t, tau;
+  long step;
+  taulap_t *visc;   // Burgers: extra viscosity passes (K > 1) through the marching kernel
+};
+
+extern "C" void tauflow_params_default(tauflow_params *P, int kind, int nx, int ny) {
+  memset(P, 0, sizeof(*P));
+  P->nx = nx; P->ny = ny; P->dx = 1.0f; P->dy = 1.0f;
+  if (kind == 0) { // tau_burgers.cu:56-91
+    P->nu = 0.1f; P->u0 = 1.0f; P->CFL = 0.45f; P->tau0 = 0.0f; P->t0 = 1.0f; P->dtau = 1.0f;
+    P->muscl = 0; P->visc_substeps = 1; P->oneD = 0;
+    P->amp = 1.0f; P->bsig = 16.0f; P->swirl = 10.0f; P->rc = 40.0f; P->offx = 0.0f; P->offy = 0.0f; P->asym = 0.0f;
+    P->ck = 4; P->ca = 0.5f;
+  } else { // tau_shallow_water.cu:54-88
+    P->g = 9.81f; P->nu = 0.001f; P->H0 = 1000.0f; P->amp = 1.0f; P->bsig = 1.0f; P->CFL = 0.5f;
+    P->offx = 100.0f; P->offy = 100.0f; P->asym = 10.0f; P->swirl = 1.0f; P->rc = 100.0f;
+    P->tau0 = 0.0f; P->t0 = 1.0f; P->dtau = 1.0f; P->u0 = 1.0f; P->visc_substeps = 1;
+  }
+}
+
+extern "C" int tauflow_create(tauflow_t **out, const tauflow_params *P, int kind, int device, void *stream) {
+  if (!out || !P) return tau::fail("tauflow_create: null argument");
+  if (kind != 0 && kind != 1) return tau::fail("tauflow_create: kind must be 0 (Burgers) or 1 (shallow water)");
+  if (P->nx < 1 || P->ny < 1) return tau::fail("tauflow_create: bad grid");
+  TAU_HIP(hipSetDevice(device));
+  tauflow *h = new (std::nothrow) tauflow();
+  if (!h) return tau::fail("tauflow_create: out of host memory");
+  h->p = *P; h->kind = kind; h->nf = kind == 0 ? 2 : 3; h->device = device; h->cur = 0; h->max_valid = false;
+  if (kind == 0 && h->p.oneD) h->p.ny = 1; // tau_burgers.cu:654-655
+  h->own_stream = (stream == nullptr);
+  if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  else h->stream = (hipStream_t)stream;
+  size_t n = (size_t)h->p.nx * h->p.ny;
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < h->nf; f++) TAU_HIP(hipMalloc(&h->buf[s][f], n * sizeof(float)));
+  TAU_HIP(hipMalloc(&h->st, sizeof(fl2::DevState)));
+  TAU_HIP(hipMemsetAsync(h->st, 0, sizeof(fl2::DevState), h->stream));
+  h->tau = P->tau0; h->t = P->t0; h->step = 0; h->visc = nullptr;
+  *out = h;
+  return 0;
+}
+extern "C" void tauflow_destroy(tauflow_t *h) {
+  if (!h) return;
+  hipSetDevice(h->device);
+  hipStreamSynchronize(h->stream);
+  for (int s = 0; s < 2; s++)
+    for (int f = 0; f < h->nf; f++) hipFree(h->buf[s][f]);
+  hipFree(h->st);
+  if (h->own_stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+extern "C" int tauflow_upload(tauflow_t *h, const float *const f[3]) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t b = (size_t)h->p.nx * h->p.ny * sizeof(float);
+  for (int k = 0; k < h->nf; k++) TAU_HIP(hipMemcpyAsync(h->buf[h->cur][k], f[k], b, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  h->max_valid = false;
+  return 0;
+}
+extern "C" int tauflow_download(tauflow_t *h, float *const f[3]) {
+  TAU_HIP(hipSetDevice(h->device));
+  size_t b = (size_t)h->p.nx * h->p.ny * sizeof(float);
+  for (int k = 0; k < h->nf; k++) TAU_HIP(hipMemcpyAsync(f[k], h->buf[h->cur][k], b, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tauflow_state_ptrs(tauflow_t *h, float *f[3]) {
+  for (int k = 0; k < 3; k++) f[k] = k < h->nf ? h->buf[h->cur][k] : nullptr;
+  return 0;
+}
+
+extern "C" int tauflow_init(tauflow_t *h) { // initialize_host: tau_burgers.cu:246-302 / tau_shallow_water.cu:238-276
+  const tauflow_params &P = h->p;
+  const int nx = P.nx, ny = P.ny;
+  size_t n = (size_t)nx * ny;
+  std::vector<float> a(n), b(n), c(n);
+  if (h->kind == 0) {
+    if (P.oneD) {
+      float Lx = P.dx * nx, k = 2.0f * (float)M_PI * P.ck / Lx;
+      for (int i = 0; i < nx; ++i) {
+        float x = (i + 0.5f) * P.dx, denom = 1.0f + P.ca * cosf(k * x);
+        float u = (denom != 0.0f) ? (2.0f * P.nu * P.ca * k * sinf(k * x) / denom) : 0.0f;
+        float phi = asinhf(u / P.u0);
+        for (int j = 0; j < ny; ++j) { a[(size_t)j * nx + i] = phi; b[(size_t)j * nx + i] = 0.0f; }
+      }
+    } else {
+      float cx = 0.5f * nx + P.offx, cy = 0.5f * ny + P.offy, sig2 = P.bsig * P.bsig, rc = P.rc * fminf(P.dx, P.dy);
+      for (int j = 0; j < ny; ++j)
+        for (int i = 0; i < nx; ++i) {
+          float dx = i - cx, dy = j - cy;
+          float r2 = (dx * dx + dy * dy) / fmaxf(sig2, 1e-6f);
+          float theta = atan2f(dy, dx), mod = 1.0f + P.asym * cosf(theta);
+          float rx = dx * P.dx, ry = dy * P.dy, r = sqrtf(rx * rx + ry * ry);
+          float u_theta = (r > 0.0f) ? (P.swirl * r * expf(-0.5f * (r / rc) * (r / rc))) : 0.0f;
+          float u = (r > 0.0f) ? (-u_theta * (ry / r)) : 0.0f, v = (r > 0.0f) ? (u_theta * (rx / r)) : 0.0f;
+          float g = P.amp * mod * expf(-0.5f * r2);
+          u += 0.5f * g; v += -0.5f * g;
+          a[(size_t)j * nx + i] = asinhf(u / P.u0);
+          b[(size_t)j * nx + i] = asinhf(v / P.u0);
+        }
+    }
+  } else {
+    float cx = 0.5f * nx + P.offx, cy = 0.5f * ny + P.offy, sig2 = P.bsig * P.bsig;
+    for (int j = 0; j < ny; ++j)
+      for (int i = 0; i < nx; ++i) {
+        float dx = i - cx, dy = j - cy;
+        float r2 = (dx * dx + dy * dy) / sig2;
+        float theta = atan2f(dy, dx), mod = 1.0f + P.asym * cosf(theta);
+        float hh = P.H0 + (P.amp * mod) * expf(-0.5f * r2);
+        size_t id = (size_t)j * nx + i;
+        a[id] = logf(fmaxf(hh, 1e-6f));
+        float rx = dx * P.dx, ry = dy * P.dy, r = sqrtf(rx * rx + ry * ry), rc = P.rc * fminf(P.dx, P.dy);
+        float u_theta = (r > 0.0f && P.swirl != 0.0f) ? (P.swirl * r * expf(-0.5f * (r / rc) * (r / rc))) : 0.0f;
+        b[id] = (r > 0.0f) ? (-u_theta * (ry / r)) : 0.0f;
+        c[id] = (r > 0.0f) ? (u_theta * (rx / r)) : 0.0f;
+      }
+  }
+  const float *f[3] = {a.data(), b.data(), c.data()};
+  h->tau = P.tau0; h->t = P.t0; h->step = 0;
+  return tauflow_upload(h, f);
+}
+
+static void flow_args(tauflow *h, fl2::Args &A, float dt_explicit) {
+  const tauflow_params &P = h->p;
+  memset(&A, 0, sizeof(A));
+  for (int f = 0; f < h->nf; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
+  A.st = h->st; A.nx = P.nx; A.ny = P.ny; A.ntx = (P.nx + fl2::TX - 1) / fl2::TX; A.nty = (P.ny + fl2::TY - 1) / fl2::TY;
+  A.cur = h->cur; A.dx = P.dx; A.dy = P.dy; A.invdx = 1.0f / P.dx; A.invdy = 1.0f / P.dy;
+  A.invdx2 = 1.0f / (P.dx * P.dx); A.invdy2 = 1.0f / (P.dy * P.dy);
+  A.nu = P.nu; A.u0 = P.u0; A.inv_u0 = 1.0f / P.u0; A.g = P.g; A.CFL = P.CFL;
+  A.dt_try = h->t * P.dtau; A.dt_explicit = dt_explicit;
+  A.cfl_len = (h->kind == 0) ? 1.0f : fminf(P.dx, P.dy);
+  A.muscl = P.muscl; A.oneD = (h->kind == 0) ? P.oneD : 0;
+  const int K = (h->kind == 0) ? (P.visc_substeps > 0 ? P.visc_substeps : 1) : 1;
+  A.do_visc = (h->kind == 0) ? 1 : (P.nu > 0.0f);
+  A.visc_frac = 1.0f / (float)K;
+  A.reduce = (K == 1);
+}
+
+static int flow_step_once(tauflow *h, float dt_explicit) {
+  fl2::Args A;
+  flow_args(h, A, dt_explicit);
+  const tauflow_params &P = h->p;
+  if (!h->max_valid) {
+    TAU_HIP(hipMemsetAsync(&h->st->maxbits[h->cur], 0, sizeof(unsigned), h->stream));
+    if (h->kind == 0) hipLaunchKernelGGL(fl2::k_metric<fl2::K_BURGERS>, dim3(1024), dim3(256), 0, h->stream, A, h->cur);
+    else hipLaunchKernelGGL(fl2::k_metric<fl2::K_SW>, dim3(1024), dim3(256), 0, h->stream, A, h->cur);
+    TAU_LAUNCH_CHECK("fl2::k_metric");
+    h->max_valid = true;
+  }
+  hipLaunchKernelGGL(fl2::k_prepare, dim3(1), dim3(1), 0, h->stream, h->st, h->cur, A.dt_try, A.CFL * A.cfl_len, dt_explicit);
+  TAU_LAUNCH_CHECK("fl2::k_prepare");
+  const unsigned nb = (unsigned)(A.ntx * A.nty);
+  if (h->kind == 0) hipLaunchKernelGGL(fl2::k_step<fl2::K_BURGERS>, dim3(nb), dim3(fl2::NT), 0, h->stream, A);
+  else hipLaunchKernelGGL(fl2::k_step<fl2::K_SW>, dim3(nb), dim3(fl2::NT), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("fl2::k_step");
+  h->cur ^= 1;
+  const int K = (h->kind == 0) ? (P.visc_substeps > 0 ? P.visc_substeps : 1) : 1;
+  if (K > 1) { // remaining viscosity passes (marching kernel), then the metric of the final state
+    for (int k = 1; k < K; k++) {
+      if (tau::st2_burgers_pass(h->buf[h->cur][0], h->buf[h->cur][1], h->buf[h->cur ^ 1][0], h->buf[h->cur ^ 1][1], P.nx,
+                                P.ny, P.dx, P.dy, P.nu, P.u0, P.oneD, h->st, 1.0f / (float)K, h->stream)) return 1;
+      h->cur ^= 1;
+    }
+    fl2::Args B;
+    flow_args(h, B, 0.f);
+    TAU_HIP(hipMemsetAsync(&h->st->maxbits[h->cur], 0, sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(fl2::k_metric<fl2::K_BURGERS>, dim3(1024), dim3(256), 0, h->stream, B, h->cur);
+    TAU_LAUNCH_CHECK("fl2::k_metric");
+  }
+  return 0;
+}
+
+extern "C" int tauflow_step_async(tauflow_t *h, int nsteps) { // headless loop body, tau_burgers.cu:797-803 / tau_shallow_water.cu
+  TAU_HIP(hipSetDevice(h->device));
+  for (int s = 0; s < nsteps; s++) {
+    if (flow_step_once(h, 0.f)) return 1;
+    h->tau += h->p.dtau;
+    h->t *= expf(h->p.dtau);
+    h->step++;
+  }
+  return 0;
+}
+extern "C" int tauflow_sync(tauflow_t *h) {
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tauflow_step(tauflow_t *h, int nsteps) {
+  if (tauflow_step_async(h, nsteps)) return 1;
+  return tauflow_sync(h);
+}
+extern "C" int tauflow_step_explicit(tauflow_t *h, float dt) {
+  if (!(dt > 0.f)) return tau::fail("tauflow_step_explicit: dt must be positive");
+  TAU_HIP(hipSetDevice(h->device));
+  if (flow_step_once(h, dt)) return 1;
+  return tauflow_sync(h);
+}
+extern "C" int tauflow_get_clock(tauflow_t *h, float *t, float *tau, float *dt_last, float *wavespeed, int64_t *step) {
+  TAU_HIP(hipSetDevice(h->device));
+  fl2::DevState s;
+  TAU_HIP(hipMemcpyAsync(&s, h->st, sizeof(s), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  if (t) *t = h->t;
+  if (tau) *tau = h->tau;
+  if (dt_last) *dt_last = s.dt_last;
+  if (wavespeed) memcpy(wavespeed, &s.maxbits[h->cur], 4);
+  if (step) *step = h->step;
+  return 0;
+}
+/* relative L2 error against the exact 1-D Cole-Hopf solution, tau_burgers.cu:720-736 */
+extern "C" int tauflow_colehopf_relL2(tauflow_t *h, float t_now, double *rel) {
+  if (h->kind != 0) return tau::fail("tauflow_colehopf_relL2: Burgers only");
+  const tauflow_params &P = h->p;
+  std::vector<float> a((size_t)P.nx * P.ny), b((size_t)P.nx * P.ny);
+  float *f[3] = {a.data(), b.data(), nullptr};
+  if (tauflow_download(h, f)) return 1;
+  float Lx = P.dx * P.nx, k = 2.0f * (float)M_PI * P.ck / Lx, decay = expf(-P.nu * k * k * t_now);
+  double num = 0.0, den = 0.0;
+  for (int i = 0; i < P.nx; ++i) {
+    float x = (i + 0.5f) * P.dx;
+    float u_ex = (2.0f * P.nu * P.ca * k * decay * sinf(k * x)) / (1.0f + P.ca * decay * cosf(k * x));
+    double diff = P.u0 * sinh((double)a[i]) - u_ex;
+    num += diff * diff; den += u_ex * u_ex;
+  }
+  *rel = (den > 0.0) ? sqrt(num / den) : sqrt(num);
+  return 0;
+}

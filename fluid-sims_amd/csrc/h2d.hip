@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
   __syncthreads();
   if (tid == 0) {
     float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-    if (m > 0.f) atomicMax(&A.st->maxs_bits[A.cur ^ 1], __float_as_uint(m));
+    tau::atomic_max_float_bits(&A.st->maxs_bits[A.cur ^ 1], m);
   }
 }
 
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void k_maxspeed(const Args A) {
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-    if (m > 0.f) atomicMax(&A.st->maxs_bits[A.cur], __float_as_uint(m));
+    tau::atomic_max_float_bits(&A.st->maxs_bits[A.cur], m);
   }
 }
 

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(NT, 3) void k_step(const Args A) {
   __syncthreads();
   if (tid == 0) {
     float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-    if (m > 0.f) atomicMax(&A.clk->maxs_bits, __float_as_uint(m));
+    tau::atomic_max_float_bits(&A.clk->maxs_bits, m);
   }
 }
 

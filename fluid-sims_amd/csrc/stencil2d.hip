@@ -36,6 +36,7 @@ struct Args {
   float dx2, dt, Du, Dv, feed, kill;
   // Laplacian passes
   float invdx2, invdy2, nudt, u0, inv_u0;
+  const float *dt_dev;   // when set: nudt = nudt * (*dt_dev)  (device-resident time step)
 };
 
 // -------- transcendental pair for the Burgers encoding, accurate to ~1e-7 relative
@@ -95,8 +96,9 @@ __device__ __forceinline__ void cell(const Args &A, float uc, float ul, float ur
   } else { // tau_shallow_water.cu:531-546 / tau_burgers.cu:513-521
     float du = (ur - 2.0f * uc + ul) * A.invdx2 + (ud - 2.0f * uc + uu) * A.invdy2;
     float dv = (vr - 2.0f * vc + vl) * A.invdx2 + (vd - 2.0f * vc + vu) * A.invdy2;
-    uo = uc + A.nudt * du;
-    vo = vc + A.nudt * dv;
+    const float nudt = A.dt_dev ? A.nudt * (*A.dt_dev) : A.nudt;
+    uo = uc + nudt * du;
+    vo = vc + nudt * dv;
     if (KIND == K_BURGERS) { uo = fasinh(uo * A.inv_u0); vo = fasinh(vo * A.inv_u0); }
   }
 }
@@ -241,6 +243,16 @@ static int pair_download(Pair *h, float *a, float *b) {
 }
 
 } // namespace st2
+
+int tau::st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,
+                          float u0, int oneD, const void *flow_state, float frac, hipStream_t stream) {
+  st2::Args A{};
+  A.a = a; A.b = b; A.oa = oa; A.ob = ob; A.nx = nx; A.ny = ny;
+  A.invdx2 = 1.0f / (dx * dx); A.invdy2 = oneD ? 0.0f : 1.0f / (dy * dy);
+  A.nudt = nu * frac; A.u0 = u0; A.inv_u0 = 1.0f / u0;
+  A.dt_dev = reinterpret_cast<const float *>(static_cast<const char *>(flow_state) + 2 * sizeof(unsigned)); // DevState::dt_last
+  return st2::launch<st2::K_BURGERS>(A, stream);
+}
 
 // =====================================================================================
 // Gray-Scott C-ABI

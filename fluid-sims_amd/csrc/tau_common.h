@@ -33,4 +33,21 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned nblocks) {
   return (b & 7u) * per + (b >> 3);
 }
 
+// Monotone max of positive floats kept as their bit pattern.  Every workgroup ends with one of these; a
+// same-address atomic costs ~12 ns at the L2 (MI355X_MICROARCH.md, row "fanin"), which at 10^5 workgroups
+// per launch is milliseconds — so first look (relaxed, agent scope: served by L2, never a stale L1 line)
+// and only issue the atomic when this value would raise the maximum.  Skipping on an observed value that
+// is already >= ours is exact because the word only ever grows within a launch.
+__device__ __forceinline__ void atomic_max_float_bits(unsigned *word, float v) {
+  if (!(v > 0.f)) return;
+  const unsigned bits = __float_as_uint(v);
+  if (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= bits) return;
+  atomicMax(word, bits);
+}
+
+// one Burgers viscosity pass through the row-marching kernel (stencil2d.hip) with the time step read
+// from a device word: nu * (*dt_dev) * frac  (used by flow2d.hip for visc_substeps > 1)
+int st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,
+                     float u0, int oneD, const void *flow_state, float frac, hipStream_t stream);
+
 } // namespace tau

@@ -57,6 +57,15 @@ class SphParams(C.Structure):
                 [(n, C.c_int32) for n in "useVisc useGrav viscSub seed".split()])
 
 
+class FlowParams(C.Structure):
+    """tauflow_params: Params of tau_burgers.cu:56-91 / tau_shallow_water.cu:54-88 in one block"""
+    _fields_ = ([("nx", C.c_int32), ("ny", C.c_int32)] +
+                [(n, C.c_float) for n in "dx dy nu u0 g H0 CFL tau0 t0 dtau".split()] +
+                [(n, C.c_int32) for n in "muscl visc_substeps oneD".split()] +
+                [(n, C.c_float) for n in "amp bsig swirl rc offx offy asym".split()] +
+                [("ck", C.c_int32), ("ca", C.c_float)])
+
+
 class LapParams(C.Structure):
     _fields_ = [("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dy nu dt u0".split()]
 
@@ -151,6 +160,19 @@ def load():
         "tausph_step_async": ([vp, i32], i32),
         "tausph_get_clock": ([vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64)], i32),
         "tausph_sync": ([vp], i32),
+        "tauflow_params_default": ([C.POINTER(FlowParams), i32, i32, i32], None),
+        "tauflow_create": ([C.POINTER(vp), C.POINTER(FlowParams), i32, i32, vp], i32),
+        "tauflow_destroy": ([vp], None),
+        "tauflow_init": ([vp], i32),
+        "tauflow_upload": ([vp, C.POINTER(vp)], i32),
+        "tauflow_download": ([vp, C.POINTER(vp)], i32),
+        "tauflow_state_ptrs": ([vp, C.POINTER(vp)], i32),
+        "tauflow_step": ([vp, i32], i32),
+        "tauflow_step_async": ([vp, i32], i32),
+        "tauflow_step_explicit": ([vp, f32], i32),
+        "tauflow_get_clock": ([vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64)], i32),
+        "tauflow_colehopf_relL2": ([vp, f32, C.POINTER(C.c_double)], i32),
+        "tauflow_sync": ([vp], i32),
         "taugs_params_default": ([C.POINTER(GSParams), i32, i32], None),
         "taugs_create": ([C.POINTER(vp), C.POINTER(GSParams), i32, vp], i32),
         "taugs_destroy": ([vp], None),
@@ -448,6 +470,72 @@ class Sph2D:
 
     def sync(self):
         _ck(self._L.tausph_sync(self._h))
+
+
+class Flow2D:
+    """Full Burgers ('burgers': phi_u, phi_v) or shallow-water ('sw': sigma, u, v) program (tauflow_*)."""
+
+    def __init__(self, kind, nx, ny, device=0, stream=None, **kw):
+        L = _require_device()
+        self.kind = {"burgers": 0, "sw": 1}[kind]
+        self.nf = 2 if self.kind == 0 else 3
+        p = FlowParams()
+        L.tauflow_params_default(C.byref(p), self.kind, nx, ny)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        if self.kind == 0 and p.oneD:
+            p.ny = 1
+        self.params = p
+        self._h = C.c_void_p()
+        _ck(L.tauflow_create(C.byref(self._h), C.byref(p), self.kind, device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.tauflow_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def shape(self):
+        return (self.params.ny, self.params.nx)
+
+    def init(self):
+        _ck(self._L.tauflow_init(self._h))
+
+    def upload(self, fields):
+        arrs = [_f32(f).reshape(-1) for f in fields]
+        ptrs = (C.c_void_p * 3)(*([a.ctypes.data for a in arrs] + [None] * (3 - len(arrs))))
+        _ck(self._L.tauflow_upload(self._h, ptrs))
+
+    def download(self):
+        arrs = [np.empty(self.shape, np.float32) for _ in range(self.nf)]
+        ptrs = (C.c_void_p * 3)(*([a.ctypes.data for a in arrs] + [None] * (3 - self.nf)))
+        _ck(self._L.tauflow_download(self._h, ptrs))
+        return arrs
+
+    def step(self, n=1):
+        _ck(self._L.tauflow_step(self._h, n))
+
+    def step_async(self, n=1):
+        _ck(self._L.tauflow_step_async(self._h, n))
+
+    def step_explicit(self, dt):
+        _ck(self._L.tauflow_step_explicit(self._h, dt))
+
+    def clock(self):
+        t, tau, dt, w, s = C.c_float(), C.c_float(), C.c_float(), C.c_float(), C.c_int64()
+        _ck(self._L.tauflow_get_clock(self._h, C.byref(t), C.byref(tau), C.byref(dt), C.byref(w), C.byref(s)))
+        return {"t": t.value, "tau": tau.value, "dt": dt.value, "wavespeed": w.value, "step": s.value}
+
+    def colehopf_relL2(self, t_now):
+        r = C.c_double()
+        _ck(self._L.tauflow_colehopf_relL2(self._h, t_now, C.byref(r)))
+        return r.value
+
+    def sync(self):
+        _ck(self._L.tauflow_sync(self._h))
 
 
 class GrayScott:

@@ -66,6 +66,31 @@ typedef struct taulap_params {
   float u0;      /* Burgers only: velocity scale of the asinh encoding */
 } taulap_params;
 
+/* ---- full Burgers / shallow-water programs (tau_burgers.cu:56-91, tau_shallow_water.cu:54-88).
+ * One block for both; fields a program does not have are ignored.  Same names where they exist. */
+typedef struct tauflow_params {
+  int32_t nx, ny;          /* 512, 512 */
+  float dx, dy;            /* 1, 1 */
+  float nu;                /* Burgers 0.1 ; SW 0.001 */
+  float u0;                /* Burgers: u = u0*sinh(phi), 1 */
+  float g;                 /* SW 9.81 */
+  float H0;                /* SW mean depth 1000 */
+  float CFL;               /* Burgers 0.45 ; SW 0.5 */
+  float tau0, t0, dtau;    /* 0, 1, 1 (log-time clock) */
+  int32_t muscl;           /* Burgers --muscl */
+  int32_t visc_substeps;   /* Burgers, 1 */
+  int32_t oneD;            /* Burgers --colehopf (forces ny = 1) */
+  /* initial field */
+  float amp;               /* Burgers amp 1 ; SW bumpAmp 1 */
+  float bsig;              /* Burgers bsig 16 ; SW bumpSigma 1 */
+  float swirl;             /* Burgers 10 ; SW 1 */
+  float rc;                /* Burgers rc 40 ; SW swirlRc 100 (cells) */
+  float offx, offy;        /* Burgers 0,0 ; SW 100,100 */
+  float asym;              /* Burgers 0 ; SW 10 */
+  int32_t ck;              /* Cole-Hopf mode number 4 */
+  float ca;                /* Cole-Hopf amplitude 0.5 */
+} tauflow_params;
+
 /* ---- 2D hypersonic Euler, GPU scheme (tau_hypersonic_cuda.cu:37-50, 1394-1409) ---- */
 typedef struct tauh2_params {
   int32_t W, H;              /* compile-time 8192 x 1024 in the reference (:28-29) */

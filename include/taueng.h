@@ -190,6 +190,27 @@ int taulap_step(taulap_t *h, int npasses);
 int taulap_step_async(taulap_t *h, int npasses);
 int taulap_sync(taulap_t *h);
 
+/* =====================================================================
+ * Full Burgers (kind 0) and shallow-water (kind 1) programs — replace do_step of
+ * tau_burgers.cu:677-718 and tau_shallow_water.cu:671-705 (wavespeed reduction + host max, flux
+ * kernels, update, viscosity) with one fused kernel per step; the log-time clock (t *= exp(dtau),
+ * :798-799) is advanced by the library.  State: Burgers phi_u, phi_v; shallow water sigma = ln h, u, v.
+ * ===================================================================== */
+typedef struct tauflow tauflow_t;
+void tauflow_params_default(tauflow_params *p, int kind, int nx, int ny);
+int tauflow_create(tauflow_t **out, const tauflow_params *p, int kind, int device, void *stream);
+void tauflow_destroy(tauflow_t *h);
+int tauflow_init(tauflow_t *h);                              /* initialize_host + H2D */
+int tauflow_upload(tauflow_t *h, const float *const f[3]);
+int tauflow_download(tauflow_t *h, float *const f[3]);
+int tauflow_state_ptrs(tauflow_t *h, float *f[3]);
+int tauflow_step(tauflow_t *h, int nsteps);
+int tauflow_step_async(tauflow_t *h, int nsteps);
+int tauflow_step_explicit(tauflow_t *h, float dt);          /* one do_step with a caller-chosen dt_eff */
+int tauflow_get_clock(tauflow_t *h, float *t, float *tau, float *dt_last, float *wavespeed, int64_t *step);
+int tauflow_colehopf_relL2(tauflow_t *h, float t_now, double *rel);   /* tau_burgers.cu:720-736 */
+int tauflow_sync(tauflow_t *h);
+
 #ifdef __cplusplus
 }
 #endif

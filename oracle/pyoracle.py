@@ -294,3 +294,72 @@ class OracleSph:
         t, tau, s = C.c_float(), C.c_float(), C.c_long()
         self.L.osph_get_clock(self.h, C.byref(t), C.byref(tau), C.byref(s))
         return {"t": t.value, "tau": tau.value, "step": s.value}
+
+
+class FlowOParams(C.Structure):
+    _fields_ = ([("nx", C.c_int32), ("ny", C.c_int32)] + [(n, C.c_float) for n in "dx dy nu u0 g CFL dtau".split()] +
+                [(n, C.c_int32) for n in "muscl visc_substeps oneD".split()])
+
+
+class OracleFlow:
+    """Full Burgers / shallow-water step oracle (oracle/stencil2d_oracle.c, second half)."""
+
+    def __init__(self, kind, nx, ny, **kw):
+        L = _lib("libtauoracle2d.so")
+        vp = C.c_void_p
+        PP = C.POINTER(FlowOParams)
+        L.o2_burgers_smax.restype = C.c_float
+        L.o2_burgers_smax.argtypes = [PP, vp, vp]
+        L.o2_burgers_step.argtypes = [PP, C.c_float, vp, vp, vp, vp]
+        L.o2_burgers_init.argtypes = [PP, C.c_int, C.c_int] + [C.c_float] * 8 + [vp, vp]
+        L.o2_burgers_colehopf_relL2.restype = C.c_double
+        L.o2_burgers_colehopf_relL2.argtypes = [PP, C.c_int, C.c_float, vp, C.c_float]
+        L.o2_sw_cmax.restype = C.c_float
+        L.o2_sw_cmax.argtypes = [PP, vp, vp, vp]
+        L.o2_sw_step.argtypes = [PP, C.c_float] + [vp] * 6
+        L.o2_sw_init.argtypes = [PP] + [C.c_float] * 8 + [vp] * 3
+        self.L, self.kind = L, kind
+        d = dict(dx=1.0, dy=1.0, nu=0.1, u0=1.0, g=9.81, CFL=0.45, dtau=1.0, muscl=0, visc_substeps=1, oneD=0)
+        if kind == "sw":
+            d.update(nu=0.001, CFL=0.5)
+        d.update(kw)
+        if kind == "burgers" and d["oneD"]:
+            ny = 1
+        self.p = FlowOParams(nx, ny, d["dx"], d["dy"], d["nu"], d["u0"], d["g"], d["CFL"], d["dtau"], d["muscl"],
+                             d["visc_substeps"], d["oneD"])
+        self.shape = (ny, nx)
+
+    def init_burgers(self, colehopf=0, ck=4, ca=0.5, amp=1.0, bsig=16.0, swirl=10.0, rc=40.0, offx=0.0, offy=0.0, asym=0.0):
+        a, b = np.empty(self.shape, np.float32), np.empty(self.shape, np.float32)
+        self.L.o2_burgers_init(C.byref(self.p), colehopf, ck, ca, amp, bsig, swirl, rc, offx, offy, asym, _vp(a), _vp(b))
+        return [a, b]
+
+    def init_sw(self, H0=1000.0, bumpAmp=1.0, bumpSigma=1.0, offx=100.0, offy=100.0, asym=10.0, swirl=1.0, swirlRc=100.0):
+        f = [np.empty(self.shape, np.float32) for _ in range(3)]
+        self.L.o2_sw_init(C.byref(self.p), H0, bumpAmp, bumpSigma, offx, offy, asym, swirl, swirlRc, _vp(f[0]), _vp(f[1]), _vp(f[2]))
+        return f
+
+    def metric(self, f):
+        f = [np.ascontiguousarray(a, np.float32) for a in f]
+        if self.kind == "burgers":
+            return self.L.o2_burgers_smax(C.byref(self.p), _vp(f[0]), _vp(f[1]))
+        return self.L.o2_sw_cmax(C.byref(self.p), _vp(f[0]), _vp(f[1]), _vp(f[2]))
+
+    def dt_eff(self, f, t):
+        """min(t*dtau, CFL*len/max) — tau_burgers.cu:693-694 / tau_shallow_water.cu:689-690"""
+        m = np.float32(self.metric(f))
+        length = np.float32(1.0) if self.kind == "burgers" else np.float32(min(self.p.dx, self.p.dy))
+        return float(min(np.float32(t) * np.float32(self.p.dtau), np.float32(self.p.CFL) * length / m))
+
+    def step(self, f, dt):
+        f = [np.ascontiguousarray(a, np.float32) for a in f]
+        out = [np.empty_like(a) for a in f]
+        if self.kind == "burgers":
+            self.L.o2_burgers_step(C.byref(self.p), dt, _vp(f[0]), _vp(f[1]), _vp(out[0]), _vp(out[1]))
+        else:
+            self.L.o2_sw_step(C.byref(self.p), dt, _vp(f[0]), _vp(f[1]), _vp(f[2]), _vp(out[0]), _vp(out[1]), _vp(out[2]))
+        return out
+
+    def colehopf_relL2(self, phu, ck, ca, t_now):
+        phu = np.ascontiguousarray(phu, np.float32)
+        return self.L.o2_burgers_colehopf_relL2(C.byref(self.p), ck, ca, _vp(phu), t_now)

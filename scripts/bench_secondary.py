@@ -57,6 +57,15 @@ def main():
         h.close()
     del fld
 
+    n = 8192
+    for kind, nbytes, kw in (("burgers", 16, {}), ("burgers", 16, {"muscl": 1}), ("sw", 24, {})):
+        fl = f.Flow2D(kind, n, n, dtau=0.01, **kw)
+        fl.init()
+        r, ms = timed(fl.step_async, fl.sync, n * n, int(200 * k), 10)
+        name = {"burgers": "tau_burgers", "sw": "tau_sw"}[kind] + (" --muscl" if kw else "")
+        line(f"{name} full step {n}^2", "cell-updates", r, ms, nbytes, "valu (sinh/asinh, sqrt, divides)", {"clock": fl.clock()})
+        fl.close()
+
     n = 4096
     e = f.Hypersonic2D(n, n)
     e.init()

@@ -26,7 +26,7 @@ def run(*args, **kw):
 
 def test_reference_target_names_exist(built):
     for t in ("tau_hypersonic", "tau_hypersonic_simd", "tau_2d_hypersonic_cuda", "tau_hypersonic_cuda_tests", "tau3d",
-              "tgs", "tau_sph"):
+              "tgs", "tau_sph", "tau_burgers", "tau_sw"):
         assert os.access(os.path.join(built, t), os.X_OK), t
 
 
@@ -116,3 +116,14 @@ def test_tau2d_and_sph_end_to_end(built):
     assert float(m.group(1)) == pytest.approx(GOLD["tau2d_cuda_512x256_4steps_tile32x4"]["t"], rel=1e-5)
     r = run(os.path.join(built, "tau_sph"), "--n", "4096", "--headless", "--steps", "3")
     assert r.returncode == 0 and "grid=16x16" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_burgers_and_sw_end_to_end(built):
+    r = run(os.path.join(built, "tau_burgers"), "--headless", "--colehopf", "--nx", "512", "--dtau", "1e-3", "--muscl",
+            "--steps", "1500")
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"relative L2 error at elapsed t=\S+: (\S+)", r.stdout)
+    assert float(m.group(1)) < 6e-5
+    r = run(os.path.join(built, "tau_sw"), "--headless", "--nx", "256", "--ny", "256", "--steps", "50", "--dtau", "0.01")
+    assert r.returncode == 0 and "Headless (stride=5):" in r.stdout and "Steps: 50" in r.stdout, r.stdout + r.stderr

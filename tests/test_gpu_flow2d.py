@@ -1,0 +1,140 @@
+"""GPU: fused Burgers / shallow-water steps (tauflow_*, through the C-ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def field_err(got, want, floor=0.0):
+    g, w = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    return float(np.abs(g - w).max() / max(np.abs(w).max(), floor, 1e-30))
+
+
+@pytest.mark.parametrize("nx,ny,muscl,warm", [(256, 128, 0, 0), (256, 128, 1, 40), (100, 60, 1, 25), (512, 512, 0, 60),
+                                              (67, 33, 1, 10)])
+def test_burgers_step_parity(eng, oracle_built, nx, ny, muscl, warm):
+    kw = dict(dtau=1e-2, muscl=muscl, nu=0.1)
+    e = eng.Flow2D("burgers", nx, ny, **kw)
+    o = oracle_built.OracleFlow("burgers", nx, ny, **kw)
+    e.init()
+    f0 = e.download()
+    for a, b in zip(f0, o.init_burgers()):
+        assert np.array_equal(a, b), "initial field must be bit-exact (host libm on both sides)"
+    if warm:
+        e.step(warm)
+    f = e.download()
+    dt = o.dt_eff(f, e.clock()["t"])
+    want = o.step(f, dt)
+    e.step_explicit(dt)
+    got = e.download()
+    u0 = 1.0
+    for g, w in zip(got, want):   # decoded velocity against the field scale, and the encoded array itself
+        assert field_err(u0 * np.sinh(g.astype(np.float64)), u0 * np.sinh(w.astype(np.float64))) <= TOL
+        assert np.abs(g - w).max() <= TOL
+    e.close()
+
+
+def test_burgers_device_dt_and_clock(eng, oracle_built):
+    kw = dict(dtau=1e-2, muscl=1)
+    e = eng.Flow2D("burgers", 256, 128, **kw)
+    o = oracle_built.OracleFlow("burgers", 256, 128, **kw)
+    e.init()
+    e.step(20)
+    f = e.download()
+    c0 = e.clock()
+    want_dt = o.dt_eff(f, c0["t"])
+    e.step(1)
+    c1 = e.clock()
+    assert c1["dt"] == pytest.approx(want_dt, rel=2e-6)
+    assert c1["t"] == pytest.approx(c0["t"] * np.exp(np.float32(1e-2)), rel=1e-6) and c1["step"] == 21
+
+
+def test_burgers_colehopf_harness(eng):
+    """the reference's accuracy harness (--colehopf): relative L2 error against the exact solution"""
+    e = eng.Flow2D("burgers", 512, 1, oneD=1, dtau=1e-3, muscl=1, nu=0.1)
+    e.init()
+    elapsed = 0.0
+    for _ in range(1500):
+        e.step(1)
+        elapsed += e.clock()["dt"]
+    assert e.colehopf_relL2(elapsed) < 6e-5
+    e.close()
+
+
+def test_burgers_visc_substeps(eng, oracle_built):
+    kw = dict(dtau=1e-2, muscl=1, visc_substeps=3)
+    e = eng.Flow2D("burgers", 256, 64, **kw)
+    o = oracle_built.OracleFlow("burgers", 256, 64, **kw)
+    e.init()
+    e.step(10)
+    f = e.download()
+    dt = o.dt_eff(f, e.clock()["t"])
+    want = o.step(f, dt)
+    e.step_explicit(dt)
+    for g, w in zip(e.download(), want):
+        assert np.abs(g - w).max() <= TOL
+    e.step(3)   # the metric of the final state feeds the next dt
+    assert np.isfinite(e.clock()["dt"]) and e.clock()["dt"] > 0
+    e.close()
+
+
+@pytest.mark.parametrize("nx,ny,nu,warm", [(256, 128, 0.001, 0), (256, 128, 0.05, 40), (100, 60, 0.0, 25), (512, 512, 0.001, 60)])
+def test_shallow_water_step_parity(eng, oracle_built, nx, ny, nu, warm):
+    kw = dict(dtau=1e-2, nu=nu)
+    ini = dict(H0=10.0, amp=0.5, bsig=6.0, offx=5.0, offy=-3.0, asym=0.3, swirl=0.05, rc=20.0)
+    e = eng.Flow2D("sw", nx, ny, **kw, **ini)
+    o = oracle_built.OracleFlow("sw", nx, ny, **kw)
+    e.init()
+    f0 = e.download()
+    for a, b in zip(f0, o.init_sw(H0=10.0, bumpAmp=0.5, bumpSigma=6.0, offx=5.0, offy=-3.0, asym=0.3, swirl=0.05, swirlRc=20.0)):
+        assert np.array_equal(a, b)
+    if warm:
+        e.step(warm)
+    f = e.download()
+    dt = o.dt_eff(f, e.clock()["t"])
+    want = o.step(f, dt)
+    e.step_explicit(dt)
+    got = e.download()
+    c = np.sqrt(9.81 * 10.0)   # gravity-wave speed: the velocity scale of the problem
+    assert np.abs(got[0] - want[0]).max() <= TOL                     # sigma = ln h: relative 1e-5 in depth
+    assert np.abs(got[1].astype(np.float64) - want[1]).max() <= TOL * c
+    assert np.abs(got[2].astype(np.float64) - want[2]).max() <= TOL * c
+    e.close()
+
+
+def test_shallow_water_mass_and_rest(eng):
+    e = eng.Flow2D("sw", 512, 256, dtau=1e-2, H0=10.0, amp=0.5, bsig=6.0, offx=5.0, offy=-3.0, asym=0.3, swirl=0.05, rc=20.0)
+    e.init()
+    m0 = np.exp(e.download()[0].astype(np.float64)).sum()
+    e.step(100)
+    assert np.exp(e.download()[0].astype(np.float64)).sum() == pytest.approx(m0, rel=5e-6)
+    rest = [np.full((256, 512), np.log(np.float32(7.0)), np.float32), np.zeros((256, 512), np.float32), np.zeros((256, 512), np.float32)]
+    e.upload(rest)
+    e.step(5)
+    out = e.download()
+    assert np.abs(out[1]).max() == 0 and np.abs(out[2]).max() == 0
+    np.testing.assert_allclose(out[0], rest[0], atol=2e-6)
+    e.close()
+
+
+def test_full_size_translation_invariance(eng):
+    """4096^2: both programs commute with periodic shifts to rounding —
+    every tile seam and both wrap-arounds at full size."""
+    n = 4096
+    rng = np.random.default_rng(11)
+    for kind, nf in (("burgers", 2), ("sw", 3)):
+        e = eng.Flow2D(kind, n, n, dtau=1e-2, muscl=1)
+        f = [(0.3 * rng.standard_normal((n, n))).astype(np.float32) for _ in range(nf)]
+        if kind == "sw":
+            f[0] = np.log(10.0 + f[0]).astype(np.float32)
+        e.upload(f)
+        e.step_explicit(0.01)
+        a = e.download()
+        sh = (123, 1027)
+        e.upload([np.roll(x, sh, (0, 1)) for x in f])
+        e.step_explicit(0.01)
+        b = e.download()
+        for x, y in zip(a, b):
+            assert np.array_equal(np.roll(x, sh, (0, 1)), y)
+        e.close()

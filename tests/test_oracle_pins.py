@@ -160,3 +160,35 @@ def test_sph_oracle_matches_reference(oracle_built):
     assert float("%.12g" % _sum(st["pos"][:, 0])) == g["sum_x"]
     assert float("%.12g" % _sum(st["pos"][:, 1])) == g["sum_y"]
     assert float("%.9g" % np.exp(st["s"].astype(np.float64)).mean()) == g["mean_rho"]
+
+
+@pytest.mark.parametrize("muscl,bound", [(0, 4e-4), (1, 6e-5)])
+def test_burgers_oracle_colehopf(oracle_built, muscl, bound):
+    """No reference output exists for tau_burgers; analytic pin: the reference's own Cole-Hopf harness
+    (tau_burgers.cu:256-273, 720-736) — the restated scheme converges to the exact 1-D solution."""
+    o = oracle_built.OracleFlow("burgers", 512, 1, oneD=1, dtau=1e-3, muscl=muscl)
+    f = o.init_burgers(colehopf=1, ck=4, ca=0.5)
+    t, elapsed = np.float32(1.0), 0.0
+    for _ in range(1500):
+        dt = o.dt_eff(f, t)
+        f = o.step(f, dt)
+        elapsed += dt
+        t = np.float32(t * np.exp(np.float32(1e-3)))
+    assert o.colehopf_relL2(f[0], 4, 0.5, elapsed) < bound
+
+
+def test_sw_oracle_conservation_and_rest(oracle_built):
+    """No reference output exists for tau_sw; analytic pins: sum(h) is conserved by the periodic flux
+    form, and a lake at rest stays exactly at rest."""
+    o = oracle_built.OracleFlow("sw", 96, 64, dtau=1e-2)
+    f = o.init_sw(H0=10.0, bumpAmp=0.5, bumpSigma=6.0, offx=5.0, offy=-3.0, asym=0.3, swirl=0.05, swirlRc=20.0)
+    m0 = np.exp(f[0].astype(np.float64)).sum()
+    t = np.float32(1.0)
+    for _ in range(30):
+        f = o.step(f, o.dt_eff(f, t))
+        t = np.float32(t * np.exp(np.float32(1e-2)))
+    assert np.exp(f[0].astype(np.float64)).sum() == pytest.approx(m0, rel=2e-6)
+    rest = [np.full((64, 96), np.log(np.float32(7.0)), np.float32), np.zeros((64, 96), np.float32), np.zeros((64, 96), np.float32)]
+    out = o.step(rest, 0.01)
+    assert np.abs(out[1]).max() == 0 and np.abs(out[2]).max() == 0
+    np.testing.assert_allclose(out[0], rest[0], atol=2e-7)
