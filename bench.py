@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=512, help="grid edge (headline: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-slab", action="store_true",
+                    help="run the Z-slab ring driver even on one GPU (self-neighbour halo copies): exercises the N>1 code path")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,7 +109,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not args.force_slab:
         eng = f.Tau3D(n, n, n, params=params, device=local)
         eng.init(1)
         eng.set_clock(0.02, 1e-4)

@@ -701,6 +701,26 @@ __global__ void k_halo_periodic(HaloArgs H) {
     dst[i] = src[i];
 }
 
+// packed halo exchange: boundary planes of 6 fields <-> one contiguous buffer per side
+struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; };
+// dir 0: pack (send side s <- first / last 3 interior planes); dir 1: unpack (recv side s -> halo planes)
+__global__ void k_halo_pack(PackArgs P, int dir) {
+  const size_t n3 = (size_t)HALO * P.plane_n;
+  const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
+  float *fld = P.f[f];
+  float *b = P.buf[side] + (size_t)f * n3;
+  float *planes = dir == 0 ? (side == 0 ? fld + (size_t)HALO * P.plane_n : fld + (size_t)P.nzl * P.plane_n)
+                           : (side == 0 ? fld : fld + (size_t)(P.nzl + HALO) * P.plane_n);
+  for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n3; i += (size_t)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n3) {
+      if (dir == 0) *reinterpret_cast<float4 *>(b + i) = *reinterpret_cast<const float4 *>(planes + i);
+      else *reinterpret_cast<float4 *>(planes + i) = *reinterpret_cast<const float4 *>(b + i);
+    } else {
+      for (size_t k = i; k < n3; k++) { if (dir == 0) b[k] = planes[k]; else planes[k] = b[k]; }
+    }
+  }
+}
+
 // log-time clock, :1680-1683 — runs before the step
 __global__ void k_clock_begin(DevClock *c) {
   c->t *= expf(c->d_tau);
@@ -740,6 +760,7 @@ struct tau3d {
   int cur;                  // which side holds the current state
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
+  float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
   // optional per-launch event timing
   bool timing;
   int n_ev;
@@ -810,6 +831,8 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     for (int f = 0; f < 6; f++) TAU_HIP(hipMalloc(&h->buf[s][f], h->field_n * sizeof(float)));
   TAU_HIP(hipMalloc(&h->solid, h->field_n));
   TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
+  for (int k = 0; k < 2; k++)
+    for (int sd = 0; sd < 2; sd++) TAU_HIP(hipMalloc(&h->xbuf[k][sd], 6 * (size_t)h3d::HALO * h->plane_n * sizeof(float)));
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
   fill_consts(h);
@@ -826,6 +849,8 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
     for (int f = 0; f < 6; f++) hipFree(h->buf[s][f]);
   hipFree(h->solid);
   hipFree(h->clk);
+  for (int k = 0; k < 2; k++)
+    for (int sd = 0; sd < 2; sd++) hipFree(h->xbuf[k][sd]);
   if (h->own_stream) hipStreamDestroy(h->stream);
   if (h->ev_made) for (int i = 0; i < 4096; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); }
   delete h;
@@ -1015,6 +1040,23 @@ extern "C" int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, f
   if (field < 0 || field > 5 || !p) return tau::fail("tau3d_halo_recv_ptr: bad argument");
   float *b = h->buf[h->cur ^ (which & 1)][field];
   *p = side == 0 ? b : b + (size_t)(h->nzl + h3d::HALO) * h->plane_n;
+  return 0;
+}
+static int halo_pack(tau3d_t *h, int which, int dir) {
+  h3d::PackArgs P;
+  for (int f = 0; f < 6; f++) P.f[f] = h->buf[h->cur ^ (which & 1)][f];
+  P.buf[0] = h->xbuf[dir][0]; P.buf[1] = h->xbuf[dir][1];
+  P.plane_n = h->plane_n; P.nzl = h->nzl;
+  hipLaunchKernelGGL(h3d::k_halo_pack, dim3(32, 12), dim3(256), 0, h->stream, P, dir);
+  TAU_LAUNCH_CHECK("k_halo_pack");
+  return 0;
+}
+extern "C" int tau3d_pack_halos_async(tau3d_t *h, int which) { return halo_pack(h, which, 0); }
+extern "C" int tau3d_unpack_halos_async(tau3d_t *h, int which) { return halo_pack(h, which, 1); }
+extern "C" int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, size_t *nfloats) {
+  if ((kind | 1) != 1 || (side | 1) != 1 || !p) return tau::fail("tau3d_halo_buf_ptr: bad argument");
+  *p = h->xbuf[kind][side];
+  if (nfloats) *nfloats = 6 * (size_t)h3d::HALO * h->plane_n;
   return 0;
 }
 extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {

@@ -104,11 +104,12 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
     const int cy = gy + oy;
     if ((unsigned)cy >= (unsigned)A.Gy) continue;
     const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
+#pragma unroll 4
     for (int j = j0; j < j1; j++) {
       const float4 o = A.recA[j];
       const float dx = me.x - o.x, dy = me.y - o.y;
       const float r2 = dx * dx + dy * dy;
-      if (r2 < twoh2) rho += A.mass * W_cubic(sqrtf(r2), ih, alpha);
+      if (r2 < twoh2) rho += A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
     }
   }
   const float si = logf(fmaxf(rho, 1e-6f));
@@ -139,13 +140,14 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
     const int cy = gy + oy;
     if ((unsigned)cy >= (unsigned)A.Gy) continue;
     const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
+#pragma unroll 4
     for (int j = j0; j < j1; j++) {
       if (j == k) continue;
       const float4 o = A.recA[j];
       const float dx = me.x - o.x, dy = me.y - o.y;
       const float r2 = dx * dx + dy * dy;
       if (r2 >= twoh2 || r2 <= 1e-16f) continue;
-      const float r = sqrtf(r2);
+      const float r = __builtin_amdgcn_sqrtf(r2);
       if (r <= 1e-8f) continue;              // gradW_cubic's own guard, :119
       const float2 oB = A.recB[j];
       // gradW_cubic, :118-133

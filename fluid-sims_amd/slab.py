@@ -6,9 +6,9 @@ The reference is single-GPU (no NCCL/MPI anywhere); this layer is ne
 (tau_hypersonic_3d_cuda.cu:1029-1030) so the neighbours form a ring.  Per step and rank:
 
     clock_begin                          t *= exp(d_tau), dt, gain              (device)
-    wait halos(n)                        sent while step n-1 computed its interior
+    wait + unpack halos(n)               received while step n-1 computed its interior
     step edge planes [0,3) , [nzl-3,nzl) need the halos; produce next state's boundary planes
-    isend/irecv next-state boundary planes -> neighbours' next-state halos  (comm stream, async)
+    pack those planes, isend/irecv       2 sends + 2 recvs of one packed buffer each (comm stream, async)
     step interior planes [3, nzl-3)      overlaps the exchange
     all_reduce(MAX) of the max-wavespeed word (4 bytes)
     clock_end                            d_tau controller (device) + swap
@@ -47,35 +47,35 @@ class _DevMem:
 
 
 class EngineSlabBackend:
-    """The HIP engine (libtaueng) as the slab stepper: halo / max words are aliased as torch
-    tensors so torch.distributed can move them; all launches go to torch's current stream."""
+    """The HIP engine (libtaueng) as the slab stepper: the packed exchange buffers and the max word are
+    aliased as torch tensors so torch.distributed can move them; all launches go to ONE explicit stream
+    that is also torch's current stream (copies, RCCL hand-offs)."""
 
     def __init__(self, taueng, params, z0, nzl, device):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
-        # one explicit (non-default) stream shared by the engine launches, torch copies and the
-        # RCCL hand-offs; the default stream's handle is NULL, which the C-ABI reads as "make your own"
+        # the default stream's handle is NULL, which the C-ABI reads as "make your own": use a real one
         self.stream = torch.cuda.Stream(self.dev)
         torch.cuda.set_stream(self.stream)
         assert self.stream.cuda_stream != 0
         self.h = taueng.Tau3D(params.nx, params.ny, params.nz, params=params, z0=z0, nzl=nzl, device=device,
                               stream=C.c_void_p(self.stream.cuda_stream))
         self.nzl = nzl
-        n = 3 * params.ny * params.nx
-        self._n = n
-        self._t = {}
-        for which in (0, 1):
-            for f in range(6):
-                for side in (0, 1):
-                    for kind in ("send", "recv"):
-                        p = self.h.halo_ptr(kind, which, f, side)
-                        self._t[(kind, which, f, side)] = torch.as_tensor(_DevMem(p, (n,)), device=self.dev)
+        self._buf = {}
+        for kind in ("send", "recv"):
+            for side in (0, 1):
+                p, n = self.h.halo_buf(kind, side)
+                self._buf[(kind, side)] = torch.as_tensor(_DevMem(p, (n,)), device=self.dev)
         self._max = torch.as_tensor(_DevMem(self.h.max_ptr(), (1,)), device=self.dev)
-        self._flip = 0
 
-    # the engine swaps its ping-pong sides in clock_end; `which` is relative to the CURRENT side
-    def halo_tensor(self, kind, which, field, side):
-        return self._t[(kind, which ^ self._flip, field, side)]
+    def buf(self, kind, side):
+        return self._buf[(kind, side)]
+
+    def pack(self, which):
+        self.h.pack_halos_async(which)
+
+    def unpack(self, which):
+        self.h.unpack_halos_async(which)
 
     def max_tensor(self):
         return self._max
@@ -88,7 +88,6 @@ class EngineSlabBackend:
 
     def clock_end(self):
         self.h.clock_end_async()
-        self._flip ^= 1
 
     def sync(self):
         self.h.sync()
@@ -98,60 +97,62 @@ class EngineSlabBackend:
 
 
 class SlabRing:
-    """Steps a Z-slab with ring halo exchange; `backend` implements the five calls above."""
+    """Steps a Z-slab with ring halo exchange.  `backend` provides buf(kind, side) (flat tensors: the packed
+    3 planes x 6 fields a side sends / receives), pack(which), unpack(which), max_tensor(), clock_begin(),
+    step_range(lo, hi), clock_end(), sync(); `which` = 0 current state, 1 next state."""
 
     def __init__(self, backend, rank, world, group=None):
         self.b, self.rank, self.world, self.group = backend, rank, world, group
         self.lo = (rank - 1) % world
         self.hi = (rank + 1) % world
-        self._pending = []
+        self._pending = None
 
-    # ---- exchange of the boundary planes of state `which` (0 = current, 1 = next)
-    def _post_exchange(self, which):
-        if self.world == 1:
-            # periodic self-neighbour: plain device copies, no communicator involved
-            for f in range(6):
-                self.b.halo_tensor("recv", which, f, 1).copy_(self.b.halo_tensor("send", which, f, 0))
-                self.b.halo_tensor("recv", which, f, 0).copy_(self.b.halo_tensor("send", which, f, 1))
+    def _post_exchange(self):
+        b = self.b
+        if self.world == 1:  # periodic self-neighbour: my low planes are my own high halo and vice versa
+            b.buf("recv", 1).copy_(b.buf("send", 0))
+            b.buf("recv", 0).copy_(b.buf("send", 1))
             return []
-        ops = []
-        for f in range(6):
-            # my low-z interior planes -> low neighbour's high halo; my high planes -> high neighbour's low halo
-            ops.append(dist.P2POp(dist.isend, self.b.halo_tensor("send", which, f, 0), self.lo, self.group, tag=f))
-            ops.append(dist.P2POp(dist.isend, self.b.halo_tensor("send", which, f, 1), self.hi, self.group, tag=6 + f))
-        for f in range(6):
-            ops.append(dist.P2POp(dist.irecv, self.b.halo_tensor("recv", which, f, 1), self.hi, self.group, tag=f))
-            ops.append(dist.P2POp(dist.irecv, self.b.halo_tensor("recv", which, f, 0), self.lo, self.group, tag=6 + f))
-        if self.world == 2:
-            # both neighbours are the same peer: order the ops so sends/recvs pair up by tag
-            pass
+        # low-z boundary planes -> low neighbour (they are ITS high halo); high planes -> high neighbour.
+        # Order matters for RCCL when both neighbours are the same peer (world = 2): ops between one pair
+        # match in issue order, so sends go (side 0, side 1) and receives (side 1, side 0).
+        ops = [dist.P2POp(dist.isend, b.buf("send", 0), self.lo, self.group, tag=0),
+               dist.P2POp(dist.isend, b.buf("send", 1), self.hi, self.group, tag=1),
+               dist.P2POp(dist.irecv, b.buf("recv", 1), self.hi, self.group, tag=0),
+               dist.P2POp(dist.irecv, b.buf("recv", 0), self.lo, self.group, tag=1)]
         return dist.batch_isend_irecv(ops)
 
-    def _wait(self):
+    def _land(self, which):
+        """wait for the exchange in flight and unpack it into the halos of state `which`"""
+        if self._pending is None:
+            return
         for r in self._pending:
             r.wait()
-        self._pending = []
+        self._pending = None
+        self.b.unpack(which)
 
     def prime(self):
         """exchange the halos of the current state (after init / upload)"""
-        self._pending = self._post_exchange(0)
-        self._wait()
+        self.b.pack(0)
+        self._pending = self._post_exchange()
+        self._land(0)
 
     def step(self, n=1):
         b, nzl = self.b, self.b.nzl
         for _ in range(n):
             b.clock_begin()
-            self._wait()                              # halos of the current state have landed
+            self._land(0)                              # halos of the current state
             b.step_range(0, 3)
             b.step_range(nzl - 3, nzl)
-            self._pending = self._post_exchange(1)    # next state's boundary planes, async
+            b.pack(1)                                  # next state's boundary planes
+            self._pending = self._post_exchange()      # async; lands at the start of the next step
             if nzl > 6:
-                b.step_range(3, nzl - 3)              # overlaps the exchange
+                b.step_range(3, nzl - 3)               # overlaps the exchange
             if self.world > 1:
                 dist.all_reduce(b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
             b.clock_end()
         return self
 
     def finish(self):
-        self._wait()
+        self._land(0)
         self.b.sync()

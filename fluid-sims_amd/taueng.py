@@ -128,6 +128,9 @@ def load():
         "tau3d_fill_halo_periodic_async": ([vp], i32),
         "tau3d_halo_send_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
         "tau3d_halo_recv_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
+        "tau3d_pack_halos_async": ([vp, i32], i32),
+        "tau3d_unpack_halos_async": ([vp, i32], i32),
+        "tau3d_halo_buf_ptr": ([vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)], i32),
         "tau3d_max_ptr": ([vp, C.POINTER(vp)], i32),
         "tau3d_sync": ([vp], i32),
         "tau3d_timing_enable": ([vp, i32], i32),
@@ -322,6 +325,17 @@ class Tau3D:
         fn = self._L.tau3d_halo_send_ptr if kind == "send" else self._L.tau3d_halo_recv_ptr
         _ck(fn(self._h, which, field, side, C.byref(p)))
         return p.value
+
+    def pack_halos_async(self, which):
+        _ck(self._L.tau3d_pack_halos_async(self._h, which))
+
+    def unpack_halos_async(self, which):
+        _ck(self._L.tau3d_unpack_halos_async(self._h, which))
+
+    def halo_buf(self, kind, side):
+        p, n = C.c_void_p(), C.c_size_t()
+        _ck(self._L.tau3d_halo_buf_ptr(self._h, {"send": 0, "recv": 1}[kind], side, C.byref(p), C.byref(n)))
+        return p.value, n.value
 
     def max_ptr(self):
         p = C.c_void_p()

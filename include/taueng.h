@@ -100,6 +100,12 @@ int tau3d_fill_halo_periodic_async(tau3d_t *h);
  * send: first/last 3 INTERIOR planes; recv: the halo planes.  Each is 3*ny*nx floats. */
 int tau3d_halo_send_ptr(tau3d_t *h, int which, int field, int side, float **p);
 int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p);
+/* Packed exchange buffers: 6 fields x 3 planes contiguous, one send and one recv buffer per side, so
+ * a step needs 2 sends + 2 recvs instead of 24.  pack: boundary planes of state `which` -> send buffers of
+ * both sides; unpack: recv buffers -> halo planes of state `which`.  kind 0 = send, 1 = recv. */
+int tau3d_pack_halos_async(tau3d_t *h, int which);
+int tau3d_unpack_halos_async(tau3d_t *h, int which);
+int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, size_t *nfloats);
 int tau3d_max_ptr(tau3d_t *h, float **p);
 int tau3d_sync(tau3d_t *h);
 /* Per-launch timing of k_step with HIP events on the launch stream (for bench.py's roofline

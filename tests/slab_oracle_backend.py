@@ -15,18 +15,26 @@ class OracleSlabBackend:
         self.nxt = self.o.new_state()
         self._max = torch.zeros(1, dtype=torch.float32)
         self.plane = params.nx * params.ny
+        self._xn = {(k, sd): np.zeros((6, 3 * self.plane), np.float32) for k in ("send", "recv") for sd in (0, 1)}
+        self._x = {key: torch.from_numpy(a.reshape(-1)) for key, a in self._xn.items()}
 
     def init(self, mode):
         self.cur = self.o.init(mode)
 
-    def halo_tensor(self, kind, which, field, side):
-        a = (self.cur if which == 0 else self.nxt)[field]
-        n = self.nzl
-        if kind == "send":
-            sl = a[3:6] if side == 0 else a[n:n + 3]
-        else:
-            sl = a[0:3] if side == 0 else a[n + 3:n + 6]
-        return torch.from_numpy(sl.reshape(-1))   # view on the numpy buffer
+    def buf(self, kind, side):
+        return self._x[(kind, side)]
+
+    def pack(self, which):
+        st, n = (self.cur if which == 0 else self.nxt), self.nzl
+        for f in range(6):
+            self._xn[("send", 0)][f] = st[f][3:6].reshape(-1)
+            self._xn[("send", 1)][f] = st[f][n:n + 3].reshape(-1)
+
+    def unpack(self, which):
+        st, n = (self.cur if which == 0 else self.nxt), self.nzl
+        for f in range(6):
+            st[f][0:3] = self._xn[("recv", 0)][f].reshape(3, *st[f].shape[1:])
+            st[f][n + 3:n + 6] = self._xn[("recv", 1)][f].reshape(3, *st[f].shape[1:])
 
     def max_tensor(self):
         return self._max

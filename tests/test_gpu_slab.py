@@ -38,11 +38,13 @@ def test_ring_world1_equals_step(eng):
         assert np.array_equal(a, b)
     c = be.clock()
     assert (c.t, c.d_tau, c.maxs, c.step) == (c_ref.t, c_ref.d_tau, c_ref.maxs, c_ref.step)
-    # halo tensors alias the engine's planes
-    lo_send = be.halo_tensor("send", 0, 0, 0).cpu().numpy().reshape(3, n[1], n[0])
-    assert np.array_equal(lo_send, got[0][0:3])
-    hi_recv = be.halo_tensor("recv", 0, 2, 1).cpu().numpy().reshape(3, n[1], n[0])
-    assert np.array_equal(hi_recv, be.h.download_planes(n[2], n[2] + 3)[2])
+    # the packed buffers alias engine memory: pack the current state and read it back through torch
+    be.pack(0)
+    be.sync()
+    lo = be.buf("send", 0).cpu().numpy().reshape(6, 3, n[1], n[0])
+    hi = be.buf("send", 1).cpu().numpy().reshape(6, 3, n[1], n[0])
+    for f in range(6):
+        assert np.array_equal(lo[f], got[f][0:3]) and np.array_equal(hi[f], got[f][n[2] - 3:])
     torch.cuda.synchronize()
 
 
@@ -65,7 +67,7 @@ def test_rccl_on_aliased_tensors(eng):
         m = be.max_tensor()
         before = float(m.item())
         dist.all_reduce(m, op=dist.ReduceOp.MAX)
-        dist.broadcast(be.halo_tensor("send", 1, 0, 0), src=0)
+        dist.broadcast(be.buf("send", 0), src=0)
         torch.cuda.synchronize()
         assert before > 0 and float(m.item()) == before
         be.clock_end()
