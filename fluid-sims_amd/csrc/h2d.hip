@@ -479,9 +479,8 @@ static void h2_consts(tauh2 *h) {
   const tauh2_params &P = h->p;
   h2d::Args &A = h->base;
   memset(&A, 0, sizeof(A));
-  A.W = P.W; A.H = P.H; A.ntx = (P.W + 1 + h2d::TX - 1) / h2d::TX; A.nty = (P.H + 1 + h2d::TY - 1) / h2d::TY;
-  // (+1: the last x / y face of the domain must belong to some tile even when W, H divide evenly —
-  //  the far-edge round covers it, so plain ceil is enough)
+  A.W = P.W; A.H = P.H;
+  // the last x / y face of the domain (fx = W, fy = H) is the far edge of the last tile: plain ceil suffices
   A.ntx = (P.W + h2d::TX - 1) / h2d::TX; A.nty = (P.H + h2d::TY - 1) / h2d::TY;
   A.gamma = (float)P.gamma; A.gm1 = (float)(P.gamma - 1.0); A.inv_gm1 = (float)(1.0 / (P.gamma - 1.0));
   A.cfl = (float)P.cfl;

@@ -201,7 +201,6 @@ struct tausph {
   int key_bits;
   float tau, t;
   long step;
-  double pair_range_sum; // not used on the hot path
 };
 
 extern "C" void tausph_params_default(tausph_params *P, int N) { // tau_sph.cu:49-85

@@ -23,7 +23,6 @@ code in this file never touches the oracle.
 """
 import ctypes as C
 
-import numpy as np
 import torch
 import torch.distributed as dist
 
