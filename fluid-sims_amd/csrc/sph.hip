@@ -201,14 +201,15 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
     for (int w = 0; w < WPR; w++) {
       const int base = wk.jb[r] + 32 * w;
       const int cnt = min(max(wk.jn[r] - 32 * w, 0), 32);
-      unsigned m = 0u;
-#pragma unroll 8
+      unsigned m = 0u;                     // built MSB-last: m = 2 m + hit is one add-with-carry per candidate
+#pragma unroll 4
       for (int b = 0; b < cnt; b++) {
         const float2 o = P[base + b];
         const float dx = me.x - o.x, dy = me.y - o.y;
         const float r2 = dx * dx + dy * dy;
-        m |= (r2 < twoh2) ? (1u << b) : 0u;
+        m = m + m + ((r2 < twoh2) ? 1u : 0u);
       }
+      m = cnt ? (__builtin_bitreverse32(m) >> (32 - cnt)) : 0u;   // candidate b -> bit b
       sM[r * WPR + w][tid] = m;
       A.nbrMask[(size_t)(r * WPR + w) * A.N + k] = m;
     }
