@@ -8,13 +8,19 @@
  *   --n N | --nx/--ny/--nz   grid (64)         --frames F   frames of 2 steps (60)
  *   --start 0|1              0 = reference k_init, 1 = developed-flow start
  *   --dump PATH              raw dump of xi,phix,phiy,phiz,lam,zet after the run
+ *   --ppm PATH               image of one z-slice of the visualisation field after the run (k_vis +
+ *                            slice_to_rgba, :800-905, 1416-1442) — the headless stand-in for the viewer
+ *   --vis 0..7               VisMode (:784-794; default 0 = |grad rho|, the reference's start-up mode)
+ *   --slice Z  --log  --again G   slice (nz/2), log scaling (key L), opacity gain (keys +/-, 1.0)
  */
 #include "tau_cli.h"
 
 int main(int argc, char **argv) {
   int nx = 64, ny = 64, nz = 64, frames = 60, start = 0;
   const int steps_per_frame = 2; /* :1643 */
-  const char *dump = NULL;
+  const char *dump = NULL, *ppm = NULL;
+  int vis = 0, slice = -1, logs = 0;
+  double again = 1.0;
   for (int i = 1; i < argc; i++) {
     const char *a = argv[i];
     int v;
@@ -25,6 +31,11 @@ int main(int argc, char **argv) {
     else if (!strcmp(a, "--frames") && i + 1 < argc) { if (!cli_int(a, argv[++i], &frames)) return 1; }
     else if (!strcmp(a, "--start") && i + 1 < argc) { if (!cli_int(a, argv[++i], &start)) return 1; }
     else if (!strcmp(a, "--dump") && i + 1 < argc) dump = argv[++i];
+    else if (!strcmp(a, "--ppm") && i + 1 < argc) ppm = argv[++i];
+    else if (!strcmp(a, "--vis") && i + 1 < argc) { if (!cli_int(a, argv[++i], &vis)) return 1; }
+    else if (!strcmp(a, "--slice") && i + 1 < argc) { if (!cli_int(a, argv[++i], &slice)) return 1; }
+    else if (!strcmp(a, "--again") && i + 1 < argc) { if (!cli_double(a, argv[++i], &again)) return 1; }
+    else if (!strcmp(a, "--log")) logs = 1;
     else { fprintf(stderr, "Unknown or incomplete argument: %s\n", a); return 1; }
   }
   cli_need_gpu();
@@ -47,6 +58,16 @@ int main(int argc, char **argv) {
   double cells = (double)nx * ny * nz * (double)frames * steps_per_frame;
   printf("%d steps on %dx%dx%d in %.3f s: %.3f Gcell-updates/s\n", frames * steps_per_frame, nx, ny, nz, el, cells / el / 1e9);
 
+  if (ppm) { /* the reference's per-frame tail, :1715-1739 */
+    float refl = 0.f, mn = 0.f, mx = 0.f;
+    uint32_t *px = (uint32_t *)malloc((size_t)nx * ny * sizeof(uint32_t));
+    TAU_CK(tau3d_vis(h, vis, NULL));
+    TAU_CK(tau3d_outflow_reflection(h, 6, &refl));
+    TAU_CK(tau3d_slice_rgba(h, slice < 0 ? nz / 2 : slice, logs, (float)again, px, &mn, &mx));
+    if (!cli_write_ppm(ppm, nx, ny, px, 1)) return 1;
+    printf("vis mode %d slice %d: min %.6g max %.6g  outflow |dp|=%.6g -> %s\n", vis, slice < 0 ? nz / 2 : slice, mn, mx, refl, ppm);
+    free(px);
+  }
   if (dump) {
     size_t n = (size_t)nx * ny * nz;
     float *buf[6];

@@ -2,8 +2,9 @@
  *
  * Stands where the reference's target of the same name does (Makefile:84-85,
  * tau_hypersonic_cuda.cu): same flags, same validation rules and messages (:1458-1639), same step
- * loop (:1833-1888) — one fused HIP kernel per step behind tauh2_step.  The raylib window and the
- * 7 view modes are out of scope.  Additive: --W / --H (compile-time 8192 x 1024 in the reference),
+ * loop (:1833-1888) — one fused HIP kernel per step behind tauh2_step.  The raylib window is replaced by
+ * a headless image: --ppm PATH writes the final frame in view mode --view 0..6 (the reference's keys 1-7,
+ * :1896-1909; render kernels :1178-1334).  Additive: --W / --H (compile-time 8192 x 1024 in the reference),
  * --frames F (frames of --steps-per-frame steps, default 30), --dump PATH.
  * --tile-bx / --tile-by are parsed and validated for compatibility; the engine's tile is fixed.
  */
@@ -18,13 +19,14 @@ static void print_usage(const char *argv0) { /* :1448-1456 */
           "          [--geom-x0 X0] [--geom-cy CY] [--geom-rb RB]\n"
           "          [--geom-rn RN] [--geom-theta THETA]\n"
           "          [--tile-bx BX] [--tile-by BY]\n"
-          "          [--W W] [--H H] [--frames F] [--dump PATH]\n",
+          "          [--W W] [--H H] [--frames F] [--dump PATH] [--ppm PATH] [--view 0..6]\n",
           argv0);
 }
 
 int main(int argc, char **argv) {
   int W = 8192, H = 1024, frames = 30, steps_per_frame = 2, tile_bx = -1, tile_by = -1, bx_set = 0, by_set = 0;
-  const char *dump = NULL;
+  const char *dump = NULL, *ppm = NULL;
+  int view = 0;
   /* first pass: the grid (the geometry defaults depend on H, :1403-1406) */
   for (int i = 1; i + 1 < argc; i++) {
     if (!strcmp(argv[i], "--W")) { if (!cli_int("--W", argv[i + 1], &W)) return 1; }
@@ -49,6 +51,8 @@ int main(int argc, char **argv) {
       if (!strcmp(a, "--W") || !strcmp(a, "--H")) { i++; continue; }
       if (!strcmp(a, "--frames")) { if (!cli_int(a, argv[++i], &frames)) return 1; continue; }
       if (!strcmp(a, "--dump")) { dump = argv[++i]; continue; }
+      if (!strcmp(a, "--ppm")) { ppm = argv[++i]; continue; }
+      if (!strcmp(a, "--view")) { if (!cli_int(a, argv[++i], &view)) return 1; continue; }
     }
     fprintf(stderr, "Unknown or incomplete argument: %s\n", a);
     print_usage(argv[0]);
@@ -108,6 +112,14 @@ int main(int argc, char **argv) {
   double el = cli_now() - t0;
   printf("%d steps on %dx%d in %.3f s: %.3f Gcell-updates/s\n", frames * steps_per_frame, W, H, el,
          (double)W * H * frames * steps_per_frame / el / 1e9);
+  if (ppm) {
+    uint32_t *px = (uint32_t *)malloc((size_t)W * H * sizeof(uint32_t));
+    double vmin, vmax;
+    TAU_CK(tauh2_render(h, view, px, NULL, &vmin, &vmax));
+    if (!cli_write_ppm(ppm, W, H, px, 0)) return 1;
+    printf("view mode %d: range [%.6g, %.6g] -> %s\n", view, vmin, vmax, ppm);
+    free(px);
+  }
   if (dump) {
     size_t n = (size_t)W * H;
     float *b[4];

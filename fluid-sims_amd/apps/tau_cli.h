@@ -56,6 +56,26 @@ static inline int cli_dump(const char *path, const char *header, const void *con
   fclose(f);
   return 1;
 }
+/* binary PPM (P6) from RGBA8 pixels (R in the lowest byte, as the reference uploads to raylib); flip = 1
+ * writes the rows bottom-up (the reference draws its textures with y up) */
+static inline int cli_write_ppm(const char *path, int w, int h, const uint32_t *rgba, int flip) {
+  FILE *f = fopen(path, "wb");
+  if (!f) { fprintf(stderr, "cannot open %s for writing\n", path); return 0; }
+  fprintf(f, "P6\n%d %d\n255\n", w, h);
+  unsigned char *row = (unsigned char *)malloc((size_t)w * 3);
+  for (int y = 0; y < h; y++) {
+    const uint32_t *src = rgba + (size_t)(flip ? h - 1 - y : y) * w;
+    for (int x = 0; x < w; x++) {
+      row[3 * x] = (unsigned char)(src[x] & 255u);
+      row[3 * x + 1] = (unsigned char)((src[x] >> 8) & 255u);
+      row[3 * x + 2] = (unsigned char)((src[x] >> 16) & 255u);
+    }
+    if (fwrite(row, 3, (size_t)w, f) != (size_t)w) { free(row); fclose(f); return 0; }
+  }
+  free(row);
+  fclose(f);
+  return 1;
+}
 static inline void cli_need_gpu(void) {
   if (!tau_device_available()) {
     fprintf(stderr, "no gfx950 (MI355X) device visible: this program has no CPU path\n");

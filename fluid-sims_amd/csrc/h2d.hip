@@ -418,6 +418,74 @@ __global__ void k_unit(const Args A, float *out) {
   { C4 g = p2c(A, P4{1.0f, -3.0f, 0.5f, 1.0f}); C4 w = p2c(A, P4{1.0f, 3.0f, -0.5f, 1.0f}); out[41] = g.mx + w.mx; out[42] = g.my + w.my; } // no-slip ghost, :262-264
 }
 
+// ---------------------------------------------------------------- rendering
+// k_render_vals / k_reduce_minmax / k_compute_inv_range / k_render_pixels, tau_hypersonic_cuda.cu:1178-1334:
+// a scalar per fluid cell (7 view modes), its min/max over the fluid, then the blue-green-red ramp.
+// Here: one pass writes the scalar and folds the wave's min/max into two order-preserving integer keys
+// (no block arrays, no second reduction kernel); one pass maps to pixels.
+__device__ __forceinline__ unsigned fkey(float v) { unsigned b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float funkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ P4 sample_prim_bc(const Args &A, int xc, int yc, int x, int y) { // :706-727
+  y = max(0, min(y, A.H - 1));
+  if (x < 0) return P4{A.in_r, A.in_u, 0.f, A.in_p};
+  auto ld = [&](int i) { return c2p(A, C4{A.in[0][i], A.in[1][i], A.in[2][i], A.in[3][i]}); };
+  if (x >= A.W) return ld(y * A.W + (A.W - 1));
+  const int i = y * A.W + x;
+  if (A.mask[i]) { const P4 c = ld(yc * A.W + xc); return P4{c.r, -c.u, -c.v, c.p}; }   // wall_ghost_prim
+  return ld(i);
+}
+
+__global__ __launch_bounds__(256) void k_render_vals(const Args A, int view_mode, float *__restrict__ val, unsigned *mm) {
+  const int N = A.W * A.H;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float mn = 3.0e38f, mx = -3.0e38f;
+  if (i < N) {
+    float v = 0.f;
+    if (!A.mask[i]) {
+      const int x = i % A.W, y = i / A.W;
+      const P4 p = c2p(A, C4{A.in[0][i], A.in[1][i], A.in[2][i], A.in[3][i]});
+      if (view_mode == 0) v = logf(p.r);
+      else if (view_mode == 1) v = logf(p.p);
+      else if (view_mode == 2) v = sqrtf(p.u * p.u + p.v * p.v);
+      else if (view_mode == 3) {
+        const float gx = 0.5f * (sample_prim_bc(A, x, y, x + 1, y).r - sample_prim_bc(A, x, y, x - 1, y).r);
+        const float gy = 0.5f * (sample_prim_bc(A, x, y, x, y + 1).r - sample_prim_bc(A, x, y, x, y - 1).r);
+        v = logf(1e-12f + sqrtf(gx * gx + gy * gy));
+      } else if (view_mode == 4) {
+        const float dv_dx = 0.5f * (sample_prim_bc(A, x, y, x + 1, y).v - sample_prim_bc(A, x, y, x - 1, y).v);
+        const float du_dy = 0.5f * (sample_prim_bc(A, x, y, x, y + 1).u - sample_prim_bc(A, x, y, x, y - 1).u);
+        v = asinhf(dv_dx - du_dy);
+      } else if (view_mode == 5) {
+        v = sqrtf(p.u * p.u + p.v * p.v) / fmaxf(sqrtf(A.gamma * fmaxf(p.p, EPS_P) / fmaxf(p.r, EPS_RHO)), 1e-30f);
+      } else {
+        v = logf(fmaxf(p.p / fmaxf(p.r, EPS_RHO), 1e-30f));
+      }
+      if (!isfinite(v)) v = 0.f;
+      mn = v; mx = v;
+    }
+    val[i] = v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  if ((threadIdx.x & 63) == 0 && mn <= mx) { atomicMin(&mm[0], fkey(mn)); atomicMax(&mm[1], fkey(mx)); }
+}
+
+__global__ __launch_bounds__(256) void k_render_pixels(const uint8_t *__restrict__ mask, const float *__restrict__ val, int N,
+                                                       const unsigned *mm, uint32_t *__restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  if (mask[i]) { out[i] = 0xff000000u | (110u << 16) | (110u << 8) | 110u; return; }   // pack_rgba(110,110,110)
+  const float mn = funkey(mm[0]), mx = funkey(mm[1]);
+  const float inv = 1.0f / fmaxf(mx - mn, 1e-30f);                                       // k_compute_inv_range
+  float t = (val[i] - mn) * inv;
+  t = fminf(fmaxf(t, 0.f), 1.f);                                                         // get_color, :692-704
+  const float rr = 255.0f * fminf(1.0f, fmaxf(0.0f, 3.0f * t - 1.0f));
+  const float gg = 255.0f * fminf(1.0f, fmaxf(0.0f, 2.0f - 4.0f * fabsf(t - 0.5f)));
+  const float bb = 255.0f * fminf(1.0f, fmaxf(0.0f, 2.0f - 3.0f * t));
+  out[i] = 0xff000000u | ((uint32_t)(uint8_t)bb << 16) | ((uint32_t)(uint8_t)gg << 8) | (uint32_t)(uint8_t)rr;
+}
+
 } // namespace h2d
 
 // =====================================================================================
@@ -434,6 +502,9 @@ struct tauh2 {
   int cur;
   bool maxs_valid;
   h2d::Args base;
+  float *rval;              // render scalar per cell (lazy)
+  uint32_t *rpix;           // render pixels (lazy)
+  unsigned *rmm;            // min / max keys
 };
 
 namespace {
@@ -523,6 +594,7 @@ extern "C" void tauh2_destroy(tauh2_t *h) {
   for (int s = 0; s < 2; s++)
     for (int f = 0; f < 4; f++) hipFree(h->buf[s][f]);
   hipFree(h->mask); hipFree(h->st);
+  hipFree(h->rval); hipFree(h->rpix); hipFree(h->rmm);
   if (h->own_stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -638,6 +710,35 @@ extern "C" int tauh2_unit_eval(tauh2_t *h, float out[48]) {
 }
 /* signed distance of the rounded sphere-cone body (host fp64, the expression k_init evaluates) */
 extern "C" double tauh2_body_sdf(double x, double y, double Rb, double Rn, double theta) { return sdBody(x, y, Rb, Rn, theta); }
+
+// ---- rendering (tau_hypersonic_cuda.cu:1871-1888: render_vals -> min/max -> inv range -> pixels) ----
+extern "C" int tauh2_render(tauh2_t *h, int view_mode, uint32_t *host_rgba, float *host_vals, double *vmin, double *vmax) {
+  if (view_mode < 0 || view_mode > 6) return tau::fail("tauh2_render: view mode %d outside 0..6", view_mode);
+  TAU_HIP(hipSetDevice(h->device));
+  const int N = h->p.W * h->p.H;
+  if (!h->rval) TAU_HIP(hipMalloc(&h->rval, (size_t)N * sizeof(float)));
+  if (!h->rpix) TAU_HIP(hipMalloc(&h->rpix, (size_t)N * sizeof(uint32_t)));
+  if (!h->rmm) TAU_HIP(hipMalloc(&h->rmm, 2 * sizeof(unsigned)));
+  h2d::Args A = h->base;
+  for (int f = 0; f < 4; f++) A.in[f] = h->buf[h->cur][f];
+  const unsigned init[2] = {0xffffffffu, 0u};
+  TAU_HIP(hipMemcpyAsync(h->rmm, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  const unsigned nb = (unsigned)((N + 255) / 256);
+  hipLaunchKernelGGL(h2d::k_render_vals, dim3(nb), dim3(256), 0, h->stream, A, view_mode, h->rval, h->rmm);
+  TAU_LAUNCH_CHECK("k_render_vals");
+  hipLaunchKernelGGL(h2d::k_render_pixels, dim3(nb), dim3(256), 0, h->stream, (const uint8_t *)h->mask, (const float *)h->rval, N,
+                     (const unsigned *)h->rmm, h->rpix);
+  TAU_LAUNCH_CHECK("k_render_pixels");
+  unsigned keys[2];
+  TAU_HIP(hipMemcpyAsync(keys, h->rmm, sizeof(keys), hipMemcpyDeviceToHost, h->stream));
+  if (host_rgba) TAU_HIP(hipMemcpyAsync(host_rgba, h->rpix, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+  if (host_vals) TAU_HIP(hipMemcpyAsync(host_vals, h->rval, (size_t)N * 4, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  auto unkey = [](unsigned k) { unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return (double)f; };
+  if (vmin) *vmin = unkey(keys[0]);
+  if (vmax) *vmax = unkey(keys[1]);
+  return 0;
+}
 
 extern "C" int tauh2_step_explicit(tauh2_t *h, double dt) {
   if (!(dt > 0.0)) return tau::fail("tauh2_step_explicit: dt must be positive");

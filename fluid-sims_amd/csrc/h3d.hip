@@ -743,6 +743,127 @@ __global__ void k_clock_set_explicit(DevClock *c, float dt, float gain) {
   c->dt = dt; c->gain = gain; c->maxs_bits = 0u;
 }
 
+
+// ---------------------------------------------------------------- visualisation fields
+// k_vis, tau_hypersonic_3d_cuda.cu:800-905: one scalar per cell from the primitives of the cell and its six
+// neighbours (prim_at_xbc, :724-751: inflow ghost left, transmissive ghost right, y/z periodic, solid
+// neighbours at the wall state).  One thread per cell, x fastest (a wave reads 64 consecutive floats of each
+// field; the y/z neighbours are the same lines again from L2).  MODE is a template parameter so that each
+// variant decodes only the fields it uses (the point modes read 1-3 arrays, the gradient modes all but Ev).
+__device__ __forceinline__ void apply_wall(const Args &A, Prim &q) { // :511-521
+  const float p_keep = fmaxf(q.q[IP], RHO_P_FLOOR);
+  q.q[IU] = 0.f; q.q[IV] = 0.f; q.q[IW] = 0.f;
+  q.q[IP] = p_keep;
+  q.q[IR] = fmaxf(p_keep / (A.R * fmaxf(A.Twall, NEWTON_TEMP_FLOOR)), RHO_P_FLOOR);
+  q.q[IE] = evib_eq(A, A.Twall);
+}
+__device__ __forceinline__ Prim prim_at_xbc(const Args &A, int x, int y, int zh, int zg) {
+  y = wrapi(y, A.ny);
+  Prim q;
+  if (x < 0) {
+    q = inflow_prim(A);
+    if (sdf_solid(A, x, y, zg)) apply_wall(A, q);
+    return q;
+  }
+  if (x >= A.nx) return outflow_prim(A, decode(A, ((size_t)zh * A.ny + y) * A.nx + (A.nx - 1)));
+  const size_t gi = ((size_t)zh * A.ny + y) * A.nx + x;
+  q = decode(A, gi);
+  if (A.solid[gi]) apply_wall(A, q);
+  return q;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_vis(const Args A, float *__restrict__ out) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int zl = blockIdx.z;
+  if (x >= A.nx || y >= A.ny) return;
+  const int zh = zl + HALO;
+  const size_t oi = ((size_t)zl * A.ny + y) * A.nx + x;
+  if (A.solid[((size_t)zh * A.ny + y) * A.nx + x]) { out[oi] = 0.f; return; }
+  const int zg = wrapi(A.z0 + zl, A.nz);
+  const Prim q0 = prim_at_xbc(A, x, y, zh, zg);
+  if (MODE == 1) { out[oi] = logf(1.0f + fmaxf(q0.q[IR], 0.0f)); return; }
+  if (MODE == 2) { out[oi] = logf(1.0f + fmaxf(q0.q[IP], 0.0f)); return; }
+  const float sp = sqrtf(q0.q[IU] * q0.q[IU] + q0.q[IV] * q0.q[IV] + q0.q[IW] * q0.q[IW]);
+  if (MODE == 3) { out[oi] = sp; return; }
+  if (MODE == 4) { out[oi] = sp / fmaxf(sqrtf(fmaxf(A.gamma * q0.q[IP] / q0.q[IR], DENOM_EPS)), DENOM_EPS); return; }
+  const Prim qxm = prim_at_xbc(A, x - 1, y, zh, zg), qxp = prim_at_xbc(A, x + 1, y, zh, zg);
+  const Prim qym = prim_at_xbc(A, x, y - 1, zh, zg), qyp = prim_at_xbc(A, x, y + 1, zh, zg);
+  const Prim qzm = prim_at_xbc(A, x, y, zh - 1, wrapi(A.z0 + zl - 1, A.nz));
+  const Prim qzp = prim_at_xbc(A, x, y, zh + 1, wrapi(A.z0 + zl + 1, A.nz));
+  const float inv2dx = 0.5f / A.dx, inv2dy = 0.5f / A.dy, inv2dz = 0.5f / A.dz;
+  if (MODE == 0) {
+    const float drdx = (qxp.q[IR] - qxm.q[IR]) * inv2dx, drdy = (qyp.q[IR] - qym.q[IR]) * inv2dy;
+    const float drdz = (qzp.q[IR] - qzm.q[IR]) * inv2dz;
+    out[oi] = sqrtf(drdx * drdx + drdy * drdy + drdz * drdz);
+    return;
+  }
+  const float dudx = (qxp.q[IU] - qxm.q[IU]) * inv2dx, dudy = (qyp.q[IU] - qym.q[IU]) * inv2dy, dudz = (qzp.q[IU] - qzm.q[IU]) * inv2dz;
+  const float dvdx = (qxp.q[IV] - qxm.q[IV]) * inv2dx, dvdy = (qyp.q[IV] - qym.q[IV]) * inv2dy, dvdz = (qzp.q[IV] - qzm.q[IV]) * inv2dz;
+  const float dwdx = (qxp.q[IW] - qxm.q[IW]) * inv2dx, dwdy = (qyp.q[IW] - qym.q[IW]) * inv2dy, dwdz = (qzp.q[IW] - qzm.q[IW]) * inv2dz;
+  if (MODE == 6) { out[oi] = dudx + dvdy + dwdz; return; }
+  if (MODE == 5) {
+    const float wx = dwdy - dvdz, wy = dudz - dwdx, wz = dvdx - dudy;
+    out[oi] = sqrtf(wx * wx + wy * wy + wz * wz);
+    return;
+  }
+  // Q = (||Omega||^2 - ||S||^2) / 2, :881-899
+  const float O12 = 0.5f * (dudy - dvdx), O13 = 0.5f * (dudz - dwdx), O23 = 0.5f * (dvdz - dwdy);
+  const float Om2 = 2.0f * (O12 * O12 + O13 * O13 + O23 * O23);
+  const float S12 = 0.5f * (dudy + dvdx), S13 = 0.5f * (dudz + dwdx), S23 = 0.5f * (dvdz + dwdy);
+  const float Sm2 = (dudx * dudx + dvdy * dvdy + dwdz * dwdz) + 2.0f * (S12 * S12 + S13 * S13 + S23 * S23);
+  out[oi] = 0.5f * (Om2 - Sm2);
+}
+
+// slice_to_rgba, :1416-1442, as two passes over one plane of the vis volume: min/max (order-preserving
+// integer keys so that atomicMin/Max work on signed floats), then the grey ramp with t^2 opacity.
+__device__ __forceinline__ unsigned fkey(float v) { unsigned b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float funkey(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+__device__ __forceinline__ float safe_log1pf(float x) { return logf(1.0f + fmaxf(x, 0.0f)); }
+
+__global__ __launch_bounds__(256) void k_slice_minmax(const float *__restrict__ s, int n, int log_scale, unsigned *mm) {
+  float mn = 1e30f, mx = -1e30f;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float v = s[i];
+    v = log_scale ? safe_log1pf(v) : v;
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], fkey(mn)); atomicMax(&mm[1], fkey(mx)); }
+}
+__global__ __launch_bounds__(256) void k_slice_rgba(const float *__restrict__ s, int n, int log_scale, float a_gain,
+                                                    const unsigned *mm, uint32_t *__restrict__ dst) {
+  const float mn = funkey(mm[0]), mx = funkey(mm[1]);
+  const float inv = 1.0f / fmaxf(mx - mn, 1e-20f);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    float v = s[i];
+    v = log_scale ? safe_log1pf(v) : v;
+    const float t = clampf((v - mn) * inv, 0.f, 1.f);
+    const float a = clampf(a_gain * (t * t), 0.f, 1.f);
+    const uint32_t c = (uint32_t)(unsigned char)(t * 255.0f), al = (uint32_t)(unsigned char)(a * 255.0f);
+    dst[i] = (al << 24) | (c << 16) | (c << 8) | c;
+  }
+}
+
+// k_outflow_reflection_metric, :1389-1408: max |p - p_inflow| over the last nprobe columns
+__global__ __launch_bounds__(256) void k_outflow_reflection(const Args A, int x0, unsigned *out_bits) {
+  const int ncol = A.nx - x0;
+  const size_t n = (size_t)ncol * A.ny * A.nzl;
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const int x = x0 + (int)(i % ncol);
+    const size_t r = i / ncol;
+    const int y = (int)(r % A.ny), zl = (int)(r / A.ny);
+    const float p = fexp(A.in[4][((size_t)(zl + HALO) * A.ny + y) * A.nx + x]);
+    m = fmaxf(m, fabsf(p - A.in_p));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) tau::atomic_max_float_bits(out_bits, m);
+}
+
 } // namespace h3d
 
 // =====================================================================================
@@ -761,6 +882,9 @@ struct tau3d {
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
   float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
+  float *vis;               // nx*ny*nzl scalar field of the last tau3d_vis (lazy)
+  uint32_t *rgba;           // one slice of pixels (lazy)
+  unsigned *scratch;        // 4 words: slice min/max keys, reflection metric bits
   // optional per-launch event timing
   bool timing;
   int n_ev;
@@ -849,6 +973,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
     for (int f = 0; f < 6; f++) hipFree(h->buf[s][f]);
   hipFree(h->solid);
   hipFree(h->clk);
+  hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch);
   for (int k = 0; k < 2; k++)
     for (int sd = 0; sd < 2; sd++) hipFree(h->xbuf[k][sd]);
   if (h->own_stream) hipStreamDestroy(h->stream);
@@ -1086,6 +1211,78 @@ extern "C" int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, do
   if (cells) *cells = h->ev_cells;
   return 0;
 }
+// ---- visualisation (tau_hypersonic_3d_cuda.cu:1715-1739) ----
+static int vis_buffers(tau3d *h) {
+  if (!h->vis) TAU_HIP(hipMalloc(&h->vis, h->plane_n * (size_t)h->nzl * sizeof(float)));
+  if (!h->rgba) TAU_HIP(hipMalloc(&h->rgba, h->plane_n * sizeof(uint32_t)));
+  if (!h->scratch) TAU_HIP(hipMalloc(&h->scratch, 4 * sizeof(unsigned)));
+  return 0;
+}
+extern "C" int tau3d_vis_async(tau3d_t *h, int mode, float *out_dev) {
+  if (mode < 0 || mode > 7) return tau::fail("tau3d_vis: mode %d outside 0..7", mode);
+  TAU_HIP(hipSetDevice(h->device));
+  if (vis_buffers(h)) return 1;
+  if (h->nzl == h->p.nz && tau3d_fill_halo_periodic_async(h)) return 1;   // slabs: the caller's exchange did this
+  h3d::Args A = h->base;
+  for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = nullptr; }
+  float *out = out_dev ? out_dev : h->vis;
+  dim3 g((A.nx + 63) / 64, (A.ny + 3) / 4, h->nzl), b(256);
+  switch (mode) {
+#define TAU_VIS_CASE(M) case M: hipLaunchKernelGGL(h3d::k_vis<M>, g, b, 0, h->stream, A, out); break;
+    TAU_VIS_CASE(0) TAU_VIS_CASE(1) TAU_VIS_CASE(2) TAU_VIS_CASE(3) TAU_VIS_CASE(4) TAU_VIS_CASE(5) TAU_VIS_CASE(6) TAU_VIS_CASE(7)
+#undef TAU_VIS_CASE
+  }
+  TAU_LAUNCH_CHECK("k_vis");
+  return 0;
+}
+extern "C" int tau3d_vis(tau3d_t *h, int mode, float *host_out) {
+  if (tau3d_vis_async(h, mode, nullptr)) return 1;
+  if (host_out)
+    TAU_HIP(hipMemcpyAsync(host_out, h->vis, h->plane_n * (size_t)h->nzl * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int tau3d_slice_rgba(tau3d_t *h, int zslice, int log_scale, float a_gain, uint32_t *host_rgba, float *mn,
+                                float *mx) {
+  TAU_HIP(hipSetDevice(h->device));
+  if (!h->vis) return tau::fail("tau3d_slice_rgba: no visualisation field yet (call tau3d_vis first)");
+  zslice = zslice < 0 ? 0 : (zslice >= h->nzl ? h->nzl - 1 : zslice);   // :1418
+  const float *s = h->vis + (size_t)zslice * h->plane_n;
+  const int n = (int)h->plane_n;
+  const unsigned init[2] = {0xffffffffu, 0u};
+  TAU_HIP(hipMemcpyAsync(h->scratch, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  const int nb = n / 256 < 1 ? 1 : (n / 256 > 1024 ? 1024 : n / 256);
+  hipLaunchKernelGGL(h3d::k_slice_minmax, dim3(nb), dim3(256), 0, h->stream, s, n, log_scale, h->scratch);
+  TAU_LAUNCH_CHECK("k_slice_minmax");
+  hipLaunchKernelGGL(h3d::k_slice_rgba, dim3(nb), dim3(256), 0, h->stream, s, n, log_scale, a_gain,
+                     (const unsigned *)h->scratch, h->rgba);
+  TAU_LAUNCH_CHECK("k_slice_rgba");
+  unsigned keys[2];
+  TAU_HIP(hipMemcpyAsync(keys, h->scratch, sizeof(keys), hipMemcpyDeviceToHost, h->stream));
+  if (host_rgba) TAU_HIP(hipMemcpyAsync(host_rgba, h->rgba, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  auto unkey = [](unsigned k) { unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
+  if (mn) *mn = unkey(keys[0]);
+  if (mx) *mx = unkey(keys[1]);
+  return 0;
+}
+extern "C" int tau3d_outflow_reflection(tau3d_t *h, int nprobe, float *max_dp) {
+  TAU_HIP(hipSetDevice(h->device));
+  if (vis_buffers(h)) return 1;
+  h3d::Args A = h->base;
+  for (int f = 0; f < 6; f++) A.in[f] = h->buf[h->cur][f];
+  int x0 = A.nx - (nprobe > 1 ? nprobe : 1);
+  if (x0 < 0) x0 = 0;
+  TAU_HIP(hipMemsetAsync(h->scratch + 2, 0, sizeof(unsigned), h->stream));
+  hipLaunchKernelGGL(h3d::k_outflow_reflection, dim3(256), dim3(256), 0, h->stream, A, x0, h->scratch + 2);
+  TAU_LAUNCH_CHECK("k_outflow_reflection");
+  float v = 0.f;
+  TAU_HIP(hipMemcpyAsync(&v, h->scratch + 2, 4, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  if (max_dp) *max_dp = v;
+  return 0;
+}
+
 extern "C" int tau3d_sync(tau3d_t *h) {
   TAU_HIP(hipSetDevice(h->device));
   TAU_HIP(hipStreamSynchronize(h->stream));

@@ -133,11 +133,16 @@ def load():
         "tau3d_halo_buf_ptr": ([vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)], i32),
         "tau3d_max_ptr": ([vp, C.POINTER(vp)], i32),
         "tau3d_sync": ([vp], i32),
+        "tau3d_vis": ([vp, i32, vp], i32),
+        "tau3d_vis_async": ([vp, i32, vp], i32),
+        "tau3d_slice_rgba": ([vp, i32, i32, f32, vp, C.POINTER(f32), C.POINTER(f32)], i32),
+        "tau3d_outflow_reflection": ([vp, i32, C.POINTER(f32)], i32),
         "tau3d_timing_enable": ([vp, i32], i32),
         "tau3d_timing_read": ([vp, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_double)], i32),
         "tauh2_params_default": ([C.POINTER(H2Params), i32, i32], None),
         "tauh2_create": ([C.POINTER(vp), C.POINTER(H2Params), i32, vp], i32),
         "tauh2_destroy": ([vp], None),
+        "tauh2_render": ([vp, i32, vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_double)], i32),
         "tauh2_init": ([vp], i32),
         "tauh2_upload": ([vp, C.POINTER(vp), vp], i32),
         "tauh2_download": ([vp, C.POINTER(vp), vp], i32),
@@ -345,6 +350,28 @@ class Tau3D:
     def sync(self):
         _ck(self._L.tau3d_sync(self._h))
 
+    VIS_MODES = ("schlieren_rho", "log_rho", "log_p", "speed", "mach", "vort_mag", "div", "q_criterion")
+
+    def vis(self, mode):
+        """the reference's k_vis field (mode 0..7 or a name from VIS_MODES) of the local planes, (nzl, ny, nx)"""
+        mode = self.VIS_MODES.index(mode) if isinstance(mode, str) else int(mode)
+        out = np.empty((self.nzl, self.params.ny, self.params.nx), np.float32)
+        _ck(self._L.tau3d_vis(self._h, mode, out.ctypes.data))
+        return out
+
+    def slice_rgba(self, zslice, log_scale=False, a_gain=1.0):
+        """slice_to_rgba of the last vis() field: (ny, nx, 4) uint8 RGBA, plus the slice's (min, max)"""
+        px = np.empty((self.params.ny, self.params.nx), np.uint32)
+        mn, mx = C.c_float(), C.c_float()
+        _ck(self._L.tau3d_slice_rgba(self._h, int(zslice), int(bool(log_scale)), float(a_gain), px.ctypes.data,
+                                     C.byref(mn), C.byref(mx)))
+        return px.view(np.uint8).reshape(self.params.ny, self.params.nx, 4), mn.value, mx.value
+
+    def outflow_reflection(self, nprobe=6):
+        v = C.c_float()
+        _ck(self._L.tau3d_outflow_reflection(self._h, int(nprobe), C.byref(v)))
+        return v.value
+
     def timing_enable(self, on=True):
         _ck(self._L.tau3d_timing_enable(self._h, int(on)))
 
@@ -405,6 +432,18 @@ class Hypersonic2D:
 
     def step_explicit(self, dt):
         _ck(self._L.tauh2_step_explicit(self._h, dt))
+
+    VIEW_MODES = ("log_rho", "log_p", "speed", "log_grad_rho", "asinh_vorticity", "mach", "log_p_over_rho")
+
+    def render(self, view_mode=0):
+        """the reference's frame tail (render_vals -> min/max -> pixels): (H, W, 4) uint8 RGBA, the scalar field
+        (H, W) float32 and its (min, max) over the fluid"""
+        view_mode = self.VIEW_MODES.index(view_mode) if isinstance(view_mode, str) else int(view_mode)
+        H, W = self.shape
+        px, val = np.empty((H, W), np.uint32), np.empty((H, W), np.float32)
+        mn, mx = C.c_double(), C.c_double()
+        _ck(self._L.tauh2_render(self._h, view_mode, px.ctypes.data, val.ctypes.data, C.byref(mn), C.byref(mx)))
+        return px.view(np.uint8).reshape(H, W, 4), val, mn.value, mx.value
 
     def unit_eval(self):
         out = (C.c_float * 48)()

@@ -108,6 +108,22 @@ int tau3d_unpack_halos_async(tau3d_t *h, int which);
 int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, size_t *nfloats);
 int tau3d_max_ptr(tau3d_t *h, float **p);
 int tau3d_sync(tau3d_t *h);
+
+/* Visualisation fields — replaces k_vis (tau_hypersonic_3d_cuda.cu:800-905, launched :1715-1716),
+ * slice_to_rgba (:1416-1442, called per slice :1735-1739) and k_outflow_reflection_metric (:1389-1408,
+ * launched :1724-1731).  mode = the reference's VisMode (:784-794): 0 |grad rho|, 1 log(1+rho),
+ * 2 log(1+p), 3 |u|, 4 Mach, 5 |curl u|, 6 div u, 7 Q.  The field covers the handle's nzl planes
+ * (nx*ny*nzl floats, reference layout, no halo).  A single-domain handle refreshes its periodic halo
+ * itself; a slab handle needs current halo planes (one exchange) before the call.
+ *   tau3d_vis        computes the field into the handle's buffer and, if host_out != NULL, copies it out
+ *   tau3d_vis_async  same without the copy; out_dev != NULL writes to caller's device memory instead
+ *   tau3d_slice_rgba pixels of local plane `zslice` (clamped) of the LAST field: grey = t, alpha =
+ *                    clamp(a_gain t^2), t normalised by that slice's own min/max, 0xAABBGGRR words
+ *   tau3d_outflow_reflection  max |p - p_inflow| over the last nprobe x-columns of the slab */
+int tau3d_vis(tau3d_t *h, int mode, float *host_out);
+int tau3d_vis_async(tau3d_t *h, int mode, float *out_dev);
+int tau3d_slice_rgba(tau3d_t *h, int zslice, int log_scale, float a_gain, uint32_t *host_rgba, float *mn, float *mx);
+int tau3d_outflow_reflection(tau3d_t *h, int nprobe, float *max_dp);
 /* Per-launch timing of k_step with HIP events on the launch stream (for bench.py's roofline
  * figure).  enable(1) starts collecting (up to 4096 launches), read() synchronises and returns
  * the summed duration in ms, the number of launches and the cells they updated. */
@@ -134,6 +150,12 @@ int tauh2_step(tauh2_t *h, int nsteps, double *t_out);
 int tauh2_step_async(tauh2_t *h, int nsteps);
 /* one step with a caller-chosen dt (parity tests) */
 int tauh2_step_explicit(tauh2_t *h, double dt);
+/* Rendering — replaces k_render_vals, k_reduce_minmax, k_compute_inv_range and k_render_pixels
+ * (tau_hypersonic_cuda.cu:1178-1334; frame loop :1871-1888).  view_mode as the reference's keys 1-7:
+ * 0 log rho, 1 log p, 2 speed, 3 log |grad rho|, 4 asinh(vorticity), 5 Mach, 6 log(p/rho).
+ * host_rgba: W*H words, bytes R,G,B,255 in memory order (uchar4), body cells grey 110; host_vals: the
+ * scalar per cell (0 in the body); vmin/vmax: its range over the fluid.  Any output may be NULL. */
+int tauh2_render(tauh2_t *h, int view_mode, uint32_t *host_rgba, float *host_vals, double *vmin, double *vmax);
 /* test seam (the reference's is the NO_MAIN/NO_RAYLIB include boundary, tau_hypersonic_cuda.cu:16-18):
  * evaluates the kernel's device helpers on the known answers of tau_hypersonic_cuda_tests.cu:245-346;
  * out[48] layout is documented at h2d::k_unit */

@@ -111,6 +111,26 @@ class Oracle3D:
         self.L.o3_run(C.byref(self.p), _ptrs(st), _ptrs(other), _vp(self.solid), C.byref(self.clock), nsteps)
         return st if nsteps % 2 == 0 else other
 
+    def vis(self, st, mode):
+        """k_vis over the interior planes; the halo planes of st must be current"""
+        out = np.empty((self.nzl, self.p.ny, self.p.nx), np.float32)
+        scale = np.empty_like(out)
+        self.L.o3_vis(C.byref(self.p), self.z0, self.nzl, _ptrs(st), _vp(self.solid), int(mode), _vp(out), _vp(scale))
+        return out, scale
+
+    def slice_rgba(self, vol, zslice, log_scale=False, a_gain=1.0):
+        vol = np.ascontiguousarray(vol, np.float32)
+        nz, ny, nx = vol.shape
+        px = np.empty((ny, nx), np.uint32)
+        mn, mx = C.c_float(), C.c_float()
+        self.L.o3_slice_to_rgba(_vp(px), _vp(vol), nx, ny, nz, int(zslice), int(bool(log_scale)), C.c_float(a_gain),
+                                C.byref(mn), C.byref(mx))
+        return px.view(np.uint8).reshape(ny, nx, 4), mn.value, mx.value
+
+    def outflow_reflection(self, st, nprobe=6):
+        self.L.o3_outflow_reflection.restype = C.c_float
+        return self.L.o3_outflow_reflection(C.byref(self.p), self.nzl, _ptrs(st), int(nprobe))
+
     @staticmethod
     def interior(st):
         return [a[HALO:-HALO] for a in st]
@@ -213,6 +233,20 @@ class OracleH2:
         out = [np.empty_like(a) for a in st]
         self.L.o2h_step_dt(C.byref(self.p), self._p4(st), self._p4(out), _vp(self.mask), dt)
         return out
+
+    def render(self, st, view_mode):
+        st = [np.ascontiguousarray(a, np.float64) for a in st]
+        val = np.empty((self.H, self.W))
+        mn, mx = C.c_double(), C.c_double()
+        self.L.o2h_render_vals(C.byref(self.p), _vp(st[0]), _vp(st[1]), _vp(st[2]), _vp(st[3]), _vp(self.mask),
+                               int(view_mode), _vp(val), C.byref(mn), C.byref(mx))
+        return val, mn.value, mx.value
+
+    def render_pixels(self, val, vmin, vmax):
+        val = np.ascontiguousarray(val, np.float64)
+        px = np.empty((self.H, self.W), np.uint32)
+        self.L.o2h_render_pixels(self.W, self.H, _vp(self.mask), _vp(val), C.c_double(vmin), C.c_double(vmax), _vp(px))
+        return px.view(np.uint8).reshape(self.H, self.W, 4)
 
     def run(self, st, n):
         other = [np.empty_like(a) for a in st]

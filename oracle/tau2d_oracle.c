@@ -428,3 +428,66 @@ void o2h_unit_inflow(double gamma, double mach, double out[4]) {
   prim_t p = inflow_state(&X);
   out[0] = p.rho; out[1] = p.u; out[2] = p.v; out[3] = p.p;
 }
+
+/* ---------------------------------------------------------------- rendering */
+
+/* sample_prim_bc, :706-727 */
+static prim_t sample_prim_bc(const ctx_t *X, int xc, int yc, int x, int y) {
+  if (y < 0) y = 0;
+  if (y >= X->H) y = X->H - 1;
+  if (x < 0) return inflow_state(X);
+  if (x >= X->W) return cons_to_prim(X, load_cons(X, y * X->W + (X->W - 1)));
+  int i = y * X->W + x;
+  if (X->mask[i]) return wall_ghost_prim(cons_to_prim(X, load_cons(X, yc * X->W + xc)));
+  return cons_to_prim(X, load_cons(X, i));
+}
+
+/* k_render_vals (:1178-1255) + the two-level min/max reduction (:1276-1327) collapsed into one loop */
+void o2h_render_vals(const tauh2_params *c, const double *rho, const double *mx, const double *my, const double *E,
+                     const uint8_t *mask, int view_mode, double *val, double *vmin, double *vmax) {
+  ctx_t X = {c->W, c->H, *c, rho, mx, my, E, mask};
+  double mn = 1e300, mxv = -1e300;
+  for (int i = 0; i < c->W * c->H; i++) {
+    val[i] = 0.0;
+    if (mask[i]) continue;
+    int x = i % c->W, y = i / c->W;
+    prim_t p = cons_to_prim(&X, load_cons(&X, i));
+    double v;
+    if (view_mode == 0) v = log(p.rho);
+    else if (view_mode == 1) v = log(p.p);
+    else if (view_mode == 2) v = sqrt(p.u * p.u + p.v * p.v);
+    else if (view_mode == 3) {
+      double gx = 0.5 * (sample_prim_bc(&X, x, y, x + 1, y).rho - sample_prim_bc(&X, x, y, x - 1, y).rho);
+      double gy = 0.5 * (sample_prim_bc(&X, x, y, x, y + 1).rho - sample_prim_bc(&X, x, y, x, y - 1).rho);
+      v = log(1e-12 + sqrt(gx * gx + gy * gy));
+    } else if (view_mode == 4) {
+      double dv_dx = 0.5 * (sample_prim_bc(&X, x, y, x + 1, y).v - sample_prim_bc(&X, x, y, x - 1, y).v);
+      double du_dy = 0.5 * (sample_prim_bc(&X, x, y, x, y + 1).u - sample_prim_bc(&X, x, y, x, y - 1).u);
+      v = asinh(dv_dx - du_dy);
+    } else if (view_mode == 5) {
+      v = sqrt(p.u * p.u + p.v * p.v) / d_fmax(sound_speed(&X, p), 1e-30);
+    } else {
+      v = log(d_fmax(p.p / d_fmax(p.rho, EPS_RHO), 1e-30));
+    }
+    if (!isfinite(v)) v = 0.0;
+    val[i] = v;
+    if (v < mn) mn = v;
+    if (v > mxv) mxv = v;
+  }
+  *vmin = mn; *vmax = mxv;
+}
+
+/* k_compute_inv_range (:1329-1333) + k_render_pixels (:1257-1274) + get_color (:692-704) */
+void o2h_render_pixels(int W, int H, const uint8_t *mask, const double *val, double vmin, double vmax, uint32_t *out) {
+  double inv = 1.0 / d_fmax(vmax - vmin, 1e-30);
+  for (int i = 0; i < W * H; i++) {
+    if (mask[i]) { out[i] = 0xff000000u | (110u << 16) | (110u << 8) | 110u; continue; }
+    double t = (val[i] - vmin) * inv;
+    if (t < 0) t = 0;
+    if (t > 1) t = 1;
+    double rr = 255.0 * d_fmin(1.0, d_fmax(0.0, 3.0 * t - 1.0));
+    double gg = 255.0 * d_fmin(1.0, d_fmax(0.0, 2.0 - 4.0 * d_fabs(t - 0.5)));
+    double bb = 255.0 * d_fmin(1.0, d_fmax(0.0, 2.0 - 3.0 * t));
+    out[i] = 0xff000000u | ((uint32_t)(uint8_t)bb << 16) | ((uint32_t)(uint8_t)gg << 8) | (uint32_t)(uint8_t)rr;
+  }
+}

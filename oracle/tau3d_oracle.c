@@ -564,3 +564,130 @@ int o3_run(const tau3d_params *P, float *const a[6], float *const b[6], const ui
   }
   return 0;
 }
+
+/* ---------------------------------------------------------------- visualisation */
+
+/* prim_at_xbc, :724-751, on the slab layout (zh = plane index incl. halo, zg = wrapped global plane) */
+static prim_t prim_at_xbc(const tau3d_params *P, const float *const st[6], const uint8_t *solid, int x, int y,
+                          int zh, int zg) {
+  const int nx = P->nx, ny = P->ny;
+  y = wrapi(y, ny);
+  prim_t q;
+  if (x < 0) {
+    q = inflow_prim(P);
+    if (sdf_solid(P, x, y, zg)) apply_wall(P, &q);
+    return q;
+  }
+  if (x >= nx) { /* outflow_prim_transmissive reads cell nx-1 of the same (y, z), :696-698 */
+    size_t gi = ((size_t)zh * ny + y) * nx + (nx - 1);
+    prim_t qR = decode(P, st[0][gi], st[1][gi], st[2][gi], st[3][gi], st[4][gi], st[5][gi]);
+    return outflow_prim(P, qR);
+  }
+  size_t gi = ((size_t)zh * ny + y) * nx + x;
+  q = decode(P, st[0][gi], st[1][gi], st[2][gi], st[3][gi], st[4][gi], st[5][gi]);
+  if (solid[gi]) apply_wall(P, &q);
+  return q;
+}
+
+static inline float safe_log1pf(float x) { return logf(1.0f + fmaxf(x, 0.0f)); } /* :796-798 */
+
+/* k_vis, :800-905 — one scalar per cell of the slab's interior planes; out has nx*ny*nzl floats
+ * (no halo).  The z neighbours come from the halo planes, which must be current. */
+/* scale (may be NULL): per cell, the magnitude of the operands the value was formed from — |value| for the
+ * point modes (1 + |value| for the two log(1 + x) modes: the operand 1 + x is rounded at eps(1), which is
+ * an ABSOLUTE 6e-8 on a value that may itself be 1e-3), sum over the differenced pairs of (|q+| + |q-|) / (2 d) for the gradient modes (squared
+ * for Q).  A second fp32 evaluation agrees with this one to a few eps of THAT, not of a difference that
+ * may cancel to nothing in smooth flow; tests state their 1e-5 against it. */
+void o3_vis(const tau3d_params *P, int z0, int nzl, const float *const st[6], const uint8_t *solid, int mode,
+            float *out, float *scale) {
+  const int nx = P->nx, ny = P->ny;
+  for (int zl = 0; zl < nzl; zl++)
+    for (int y = 0; y < ny; y++)
+      for (int x = 0; x < nx; x++) {
+        const int zh = zl + HALO;
+        size_t oi = ((size_t)zl * ny + y) * nx + x;
+        size_t gi = ((size_t)zh * ny + y) * nx + x;
+        if (scale) scale[oi] = 0.f;
+        if (solid[gi]) { out[oi] = 0.f; continue; }
+#define QAT(dx_, dy_, dz_) prim_at_xbc(P, st, solid, x + (dx_), y + (dy_), zh + (dz_), wrapi(z0 + zl + (dz_), P->nz))
+        prim_t q0 = QAT(0, 0, 0);
+        if (mode == 1) { out[oi] = safe_log1pf(q0.r); if (scale) scale[oi] = 1.f + fabsf(out[oi]); continue; }
+        if (mode == 2) { out[oi] = safe_log1pf(q0.p); if (scale) scale[oi] = 1.f + fabsf(out[oi]); continue; }
+        if (mode == 3) { out[oi] = sqrtf(q0.u * q0.u + q0.v * q0.v + q0.w * q0.w); if (scale) scale[oi] = out[oi]; continue; }
+        if (mode == 4) {
+          float a = soundspeed(P, &q0);
+          float s = sqrtf(q0.u * q0.u + q0.v * q0.v + q0.w * q0.w);
+          out[oi] = s / fmaxf(a, DENOM_EPS);
+          if (scale) scale[oi] = out[oi];
+          continue;
+        }
+        prim_t qxm = QAT(-1, 0, 0), qxp = QAT(1, 0, 0), qym = QAT(0, -1, 0), qyp = QAT(0, 1, 0);
+        prim_t qzm = QAT(0, 0, -1), qzp = QAT(0, 0, 1);
+#undef QAT
+        float inv2dx = 0.5f / P->dx, inv2dy = 0.5f / P->dy, inv2dz = 0.5f / P->dz;
+        float dudx = (qxp.u - qxm.u) * inv2dx, dudy = (qyp.u - qym.u) * inv2dy, dudz = (qzp.u - qzm.u) * inv2dz;
+        float dvdx = (qxp.v - qxm.v) * inv2dx, dvdy = (qyp.v - qym.v) * inv2dy, dvdz = (qzp.v - qzm.v) * inv2dz;
+        float dwdx = (qxp.w - qxm.w) * inv2dx, dwdy = (qyp.w - qym.w) * inv2dy, dwdz = (qzp.w - qzm.w) * inv2dz;
+        if (scale) {
+#define MAG(f_) ((fabsf(qxp.f_) + fabsf(qxm.f_)) * inv2dx + (fabsf(qyp.f_) + fabsf(qym.f_)) * inv2dy + \
+                 (fabsf(qzp.f_) + fabsf(qzm.f_)) * inv2dz)
+          float sv = MAG(u) + MAG(v) + MAG(w);
+          scale[oi] = (mode == 0) ? MAG(r) : (mode == 7) ? sv * sv : sv;
+#undef MAG
+        }
+        if (mode == 6) { out[oi] = dudx + dvdy + dwdz; continue; }
+        float wx = dwdy - dvdz, wy = dudz - dwdx, wz = dvdx - dudy;
+        if (mode == 5) { out[oi] = sqrtf(wx * wx + wy * wy + wz * wz); continue; }
+        if (mode == 7) {
+          float O12 = 0.5f * (dudy - dvdx), O13 = 0.5f * (dudz - dwdx), O23 = 0.5f * (dvdz - dwdy);
+          float Om2 = 2.0f * (O12 * O12 + O13 * O13 + O23 * O23);
+          float S12 = 0.5f * (dudy + dvdx), S13 = 0.5f * (dudz + dwdx), S23 = 0.5f * (dvdz + dwdy);
+          float Sm2 = (dudx * dudx + dvdy * dvdy + dwdz * dwdz) + 2.0f * (S12 * S12 + S13 * S13 + S23 * S23);
+          out[oi] = 0.5f * (Om2 - Sm2);
+          continue;
+        }
+        float drdx = (qxp.r - qxm.r) * inv2dx, drdy = (qyp.r - qym.r) * inv2dy, drdz = (qzp.r - qzm.r) * inv2dz;
+        out[oi] = sqrtf(drdx * drdx + drdy * drdy + drdz * drdz);
+      }
+}
+
+/* slice_to_rgba, :1416-1442 — grey ramp with t^2 opacity, per-slice min/max normalisation */
+void o3_slice_to_rgba(uint32_t *dst, const float *vol, int nx, int ny, int nz, int zslice, int log_scale,
+                      float a_gain, float *mn_out, float *mx_out) {
+  zslice = (zslice < 0) ? 0 : (zslice >= nz ? (nz - 1) : zslice);
+  const float *s = vol + (size_t)zslice * (size_t)nx * (size_t)ny;
+  float mn = 1e30f, mx = -1e30f;
+  for (int i = 0; i < nx * ny; i++) {
+    float v = s[i];
+    v = log_scale ? safe_log1pf(v) : v;
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  float inv = 1.0f / fmaxf(mx - mn, 1e-20f);
+  for (int i = 0; i < nx * ny; i++) {
+    float v = s[i];
+    v = log_scale ? safe_log1pf(v) : v;
+    float t = clampf((v - mn) * inv, 0.f, 1.f);
+    float a = clampf(a_gain * (t * t), 0.f, 1.f);
+    unsigned char c = (unsigned char)(t * 255.0f);
+    unsigned char A = (unsigned char)(a * 255.0f);
+    dst[i] = ((uint32_t)A << 24) | ((uint32_t)c << 16) | ((uint32_t)c << 8) | (uint32_t)c;
+  }
+  if (mn_out) *mn_out = mn;
+  if (mx_out) *mx_out = mx;
+}
+
+/* k_outflow_reflection_metric, :1389-1408 — max |p - p_inflow| over the last nprobe x-columns */
+float o3_outflow_reflection(const tau3d_params *P, int nzl, const float *const st[6], int nprobe) {
+  const int nx = P->nx, ny = P->ny;
+  int x0 = nx - ((nprobe > 1) ? nprobe : 1);
+  float p_ref = fmaxf(P->inflow_p, RHO_P_FLOOR), m = 0.f;
+  for (int zl = 0; zl < nzl; zl++)
+    for (int y = 0; y < ny; y++)
+      for (int x = (x0 < 0 ? 0 : x0); x < nx; x++) {
+        size_t gi = ((size_t)(zl + HALO) * ny + y) * nx + x;
+        float d = fabsf(expf(st[4][gi]) - p_ref);
+        if (d > m) m = d;
+      }
+  return m;
+}

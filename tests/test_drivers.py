@@ -127,3 +127,34 @@ def test_burgers_and_sw_end_to_end(built):
     assert float(m.group(1)) < 6e-5
     r = run(os.path.join(built, "tau_sw"), "--headless", "--nx", "256", "--ny", "256", "--steps", "50", "--dtau", "0.01")
     assert r.returncode == 0 and "Headless (stride=5):" in r.stdout and "Steps: 50" in r.stdout, r.stdout + r.stderr
+
+
+def read_ppm(path):
+    raw = open(path, "rb").read()
+    magic, dims, maxv, body = raw.split(b"\n", 3)
+    w, h = map(int, dims.split())
+    assert magic == b"P6" and maxv == b"255" and len(body) == 3 * w * h
+    return np.frombuffer(body, np.uint8).reshape(h, w, 3)
+
+
+@pytest.mark.gpu
+def test_headless_images(built, tmp_path):
+    """--ppm stands in for the raylib window: the 3D slice is the grey ramp of slice_to_rgba, the 2D frame
+    the blue-green-red ramp with the body in grey 110 (tau_hypersonic_cuda.cu:692-704, 1265-1268)."""
+    p3 = str(tmp_path / "s.ppm")
+    r = run(os.path.join(built, "tau3d"), "--n", "32", "--frames", "15", "--start", "1", "--vis", "0", "--ppm", p3)
+    assert r.returncode == 0 and "outflow |dp|=" in r.stdout, r.stdout + r.stderr
+    im = read_ppm(p3)
+    assert im.shape == (32, 32, 3) and (im[..., 0] == im[..., 1]).all() and im.max() == 255 and im.min() == 0
+    p2 = str(tmp_path / "f.ppm")
+    r = run(os.path.join(built, "tau_2d_hypersonic_cuda"), "--W", "512", "--H", "256", "--frames", "30", "--view", "5",
+            "--ppm", p2)
+    assert r.returncode == 0 and "view mode 5" in r.stdout, r.stdout + r.stderr
+    im = read_ppm(p2)
+    assert im.shape == (256, 512, 3)
+    body = (im == 110).all(axis=2)
+    assert 0 < body.sum() < 0.2 * body.size            # the sphere-cone body is there, in grey
+    assert (im[:, 0, 0] == 255).all() and (im[:, 0, 2] == 0).all()   # Mach view: the inflow column sits at the red end
+    r = run(os.path.join(built, "tau_2d_hypersonic_cuda"), "--W", "64", "--H", "64", "--frames", "1", "--view", "9",
+            "--ppm", p2)
+    assert r.returncode == 1 and "view mode 9 outside 0..6" in r.stderr
