@@ -42,6 +42,9 @@ struct Args {
   float2 *recB;       // sorted: p / rho^2, rho
   float2 *recP;       // sorted: x, y once more (the scan only needs 8 B per candidate)
   unsigned *nbrMask;  // [NW][N] in-range bitmasks, written by k_density, read by k_forces
+  float4 *recA2;      // sorted: x, y, vx, vy AFTER the integrate (only when XSPH is on)
+  int *rainWinner;    // per particle: highest drop index that picked it this launch, else -1 (only with rain)
+  float xsphEps;
 };
 
 __device__ __forceinline__ int grid_c(float x, float cell, int G) { // grid_x / grid_y, :141-157
@@ -351,6 +354,80 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   if (y > A.boxY) { y = A.boxY; vy = -e * vy; }
   A.pos[id] = make_float2(x, y);
   A.vel[id] = make_float2(vx, vy);
+  if (A.recA2) A.recA2[k] = make_float4(x, y, vx, vy);
+}
+
+// XSPH velocity smoothing, k_xsph_cell + k_apply_xsph (:274-322; launched after the integrate, :698-704).
+// The reference walks the cell lists built BEFORE the integrate with the positions and velocities from AFTER
+// it; the sorted arrays are those lists, recA2 the moved records.  Off by default: a plain range walk.
+__global__ __launch_bounds__(256) void k_xsph(const Args A) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= A.N) return;
+  const float4 me = A.recA2[k];
+  const float rhoi = A.recB[k].y;
+  const int gx = grid_c(me.x, A.cell, A.Gx), gy = grid_c(me.y, A.cell, A.Gy);   // the cell it moved to
+  const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
+  const float twoh = 2.f * A.h, twoh2 = twoh * twoh, ih = 1.0f / A.h;
+  float dvx = 0.f, dvy = 0.f;
+  for (int oy = -1; oy <= 1; ++oy) {
+    const int cy = gy + oy;
+    if ((unsigned)cy >= (unsigned)A.Gy) continue;
+    const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
+    for (int j = j0; j < j1; j++) {
+      const float4 o = A.recA2[j];
+      const float dx = me.x - o.x, dy = me.y - o.y;
+      const float r2 = dx * dx + dy * dy;
+      const float w = (j != k && r2 < twoh2) ? W_cubic(__builtin_amdgcn_sqrtf(r2), ih, A.alpha) : 0.f;
+      const float c = (A.mass / (0.5f * (rhoi + A.recB[j].y))) * w;
+      dvx += c * (o.z - me.z);
+      dvy += c * (o.w - me.w);
+    }
+  }
+  const unsigned id = A.ids_s[k];
+  const float2 d = make_float2(A.xsphEps * dvx, A.xsphEps * dvy);
+  A.acc[id] = d;                                           // the reference parks dvel in acc, :699
+  A.vel[id] = make_float2(me.z + d.x, me.w + d.y);
+}
+
+// Rain, k_rain (:377-392).  Two drops may pick the same particle; the reference leaves the winner to the
+// hardware.  Here the HIGHEST drop index wins (what an in-order launch would give): claim, then apply.
+__device__ __forceinline__ unsigned rain_draw(unsigned seed, int k, float boxX, float boxY, float &x, float &y) {
+  unsigned s = seed ^ ((unsigned)k * 1664525u + 1013904223u);
+  s = s * 1664525u + 1013904223u;
+  const float rx = (s & 0x00FFFFFF) / 16777216.f;
+  s = s * 1664525u + 1013904223u;
+  x = rx * (boxX * 0.8f) + 0.1f * boxX;
+  const float ry = (s & 0x00FFFFFF) / 16777216.f;
+  y = boxY * (0.9f + 0.08f * ry);
+  return s;
+}
+__global__ void k_rain_claim(const Args A, int nspawn, unsigned seed) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nspawn) return;
+  float x, y;
+  const unsigned s = rain_draw(seed, k, A.boxX, A.boxY, x, y);
+  atomicMax(&A.rainWinner[s % (unsigned)A.N], k);
+}
+__global__ void k_rain_apply(const Args A, int nspawn, unsigned seed) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nspawn) return;
+  float x, y;
+  const unsigned s = rain_draw(seed, k, A.boxX, A.boxY, x, y);
+  const int i = (int)(s % (unsigned)A.N);
+  if (A.rainWinner[i] != k) return;
+  A.pos[i] = make_float2(x, y);
+  A.vel[i] = make_float2(0.f, -0.5f * A.c0);
+  A.rainWinner[i] = -1;
+}
+
+// k_rasterize, :363-374: particle counts on a W x 2H raster, y flipped
+__global__ void k_rasterize(const float2 *__restrict__ pos, int N, int *grid2, int W, int H, float boxX, float boxY) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float2 p = pos[i];
+  const int cx = (int)(p.x / boxX * (W - 1));
+  const int sy = (int)((boxY - p.y) / boxY * (2 * H - 1));
+  if ((unsigned)cx < (unsigned)W && (unsigned)sy < (unsigned)(2 * H)) atomicAdd(&grid2[sy * W + cx], 1);
 }
 
 } // namespace sph
@@ -369,12 +446,17 @@ struct tausph {
   int key_bits;
   float tau, t;
   long step;
+  float rain_carry;
+  long rain_spawned;
+  int *raster;
+  size_t raster_n;
 };
 
 extern "C" void tausph_params_default(tausph_params *P, int N) { // tau_sph.cu:49-85
   P->N = N; P->boxX = 1.0f; P->boxY = 1.0f; P->dTau = 1.0f; P->t0 = 1.0f; P->CFL = 1.0f;
   P->rho0 = 1.0f; P->c0 = 1.0f; P->gammaEOS = 1.0f; P->hMul = 2.0f; P->viscAlpha = 0.25f; P->gravity = 9.81f;
   P->useVisc = 1; P->useGrav = 1; P->viscSub = 1; P->seed = 69420;
+  P->useXSPH = 0; P->xsphEps = 0.25f; P->rain = 0;   // rain: see tau_params.h (the reference's own default is on)
 }
 
 extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device, void *stream) {
@@ -413,6 +495,12 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipMalloc(&A.recA, N * sizeof(float4))); TAU_HIP(hipMalloc(&A.recB, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.recP, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.nbrMask, N * sizeof(unsigned) * 12));
+  A.xsphEps = P->xsphEps;
+  if (P->useXSPH && P->xsphEps > 0.f) TAU_HIP(hipMalloc(&A.recA2, N * sizeof(float4)));
+  if (P->rain) {
+    TAU_HIP(hipMalloc(&A.rainWinner, N * sizeof(int)));
+    TAU_HIP(hipMemsetAsync(A.rainWinner, 0xff, N * sizeof(int), h->stream));
+  }
   TAU_HIP(hipMemsetAsync(A.acc, 0, N * sizeof(float2), h->stream));
   TAU_HIP(hipMemsetAsync(A.s, 0, N * sizeof(float), h->stream));
   TAU_HIP(hipMemsetAsync(A.press, 0, N * sizeof(float), h->stream));
@@ -433,7 +521,7 @@ extern "C" void tausph_destroy(tausph_t *h) {
   sph::Args &A = h->a;
   hipFree(A.pos); hipFree(A.vel); hipFree(A.acc); hipFree(A.s); hipFree(A.press); hipFree(A.cellOf);
   hipFree(A.keys); hipFree(A.ids); hipFree(A.keys_s); hipFree(A.ids_s); hipFree(A.cellStart);
-  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(h->cub_tmp);
+  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(A.recA2); hipFree(A.rainWinner); hipFree(h->raster); hipFree(h->cub_tmp);
   if (h->own_stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -515,6 +603,23 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
   TAU_LAUNCH_CHECK("sph::k_density");
   hipLaunchKernelGGL(sph::k_forces, dim3(gs), dim3(256), 0, h->stream, A);
   TAU_LAUNCH_CHECK("sph::k_forces");
+  if (A.recA2) { // :698-704
+    hipLaunchKernelGGL(sph::k_xsph, dim3(gs), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_xsph");
+  }
+  if (h->p.rain) { // :706-716
+    h->rain_carry += 0.02f * h->p.N * dt;
+    int nspawn = (int)h->rain_carry;
+    h->rain_carry -= nspawn;
+    if (nspawn > 0) {
+      const unsigned seed = (unsigned)(h->p.seed + (int)h->step), gr = (unsigned)((nspawn + 127) / 128);
+      hipLaunchKernelGGL(sph::k_rain_claim, dim3(gr), dim3(128), 0, h->stream, A, nspawn, seed);
+      TAU_LAUNCH_CHECK("sph::k_rain_claim");
+      hipLaunchKernelGGL(sph::k_rain_apply, dim3(gr), dim3(128), 0, h->stream, A, nspawn, seed);
+      TAU_LAUNCH_CHECK("sph::k_rain_apply");
+      h->rain_spawned += nspawn;
+    }
+  }
   return 0;
 }
 
@@ -540,6 +645,20 @@ extern "C" int tausph_step_async(tausph_t *h, int nsteps) { // host loop body, :
   }
   return 0;
 }
+extern "C" int tausph_rasterize(tausph_t *h, int W, int H, int32_t *host_grid2) { // k_clear_grid + k_rasterize, :357-374
+  if (W < 1 || H < 1 || !host_grid2) return tau::fail("tausph_rasterize: bad raster %dx%d", W, H);
+  TAU_HIP(hipSetDevice(h->device));
+  const size_t n = (size_t)W * 2 * (size_t)H;
+  if (h->raster_n < n) { hipFree(h->raster); h->raster = nullptr; TAU_HIP(hipMalloc(&h->raster, n * sizeof(int))); h->raster_n = n; }
+  TAU_HIP(hipMemsetAsync(h->raster, 0, n * sizeof(int), h->stream));
+  hipLaunchKernelGGL(sph::k_rasterize, dim3((unsigned)((h->p.N + 255) / 256)), dim3(256), 0, h->stream, (const float2 *)h->a.pos,
+                     h->p.N, h->raster, W, H, h->p.boxX, h->p.boxY);
+  TAU_LAUNCH_CHECK("sph::k_rasterize");
+  TAU_HIP(hipMemcpyAsync(host_grid2, h->raster, n * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  return 0;
+}
+extern "C" int64_t tausph_rain_spawned(tausph_t *h) { return (int64_t)h->rain_spawned; }
 extern "C" int tausph_sync(tausph_t *h) {
   TAU_HIP(hipSetDevice(h->device));
   TAU_HIP(hipStreamSynchronize(h->stream));

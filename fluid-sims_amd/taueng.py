@@ -54,7 +54,8 @@ class SphParams(C.Structure):
     """tausph_params == reference Params (tau_sph.cu:49-85)"""
     _fields_ = ([("N", C.c_int32)] + [(n, C.c_float) for n in
                 "boxX boxY dTau t0 CFL rho0 c0 gammaEOS hMul viscAlpha gravity".split()] +
-                [(n, C.c_int32) for n in "useVisc useGrav viscSub seed".split()])
+                [(n, C.c_int32) for n in "useVisc useGrav viscSub seed useXSPH".split()] +
+                [("xsphEps", C.c_float), ("rain", C.c_int32)])
 
 
 class FlowParams(C.Structure):
@@ -168,6 +169,8 @@ def load():
         "tausph_step_async": ([vp, i32], i32),
         "tausph_get_clock": ([vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64)], i32),
         "tausph_sync": ([vp], i32),
+        "tausph_rasterize": ([vp, i32, i32, vp], i32),
+        "tausph_rain_spawned": ([vp], C.c_int64),
         "tauflow_params_default": ([C.POINTER(FlowParams), i32, i32, i32], None),
         "tauflow_create": ([C.POINTER(vp), C.POINTER(FlowParams), i32, i32, vp], i32),
         "tauflow_destroy": ([vp], None),
@@ -523,6 +526,15 @@ class Sph2D:
 
     def sync(self):
         _ck(self._L.tausph_sync(self._h))
+
+    def rasterize(self, W, H):
+        """k_rasterize: particle counts on a (2H, W) raster, y flipped (the ncurses view's input)"""
+        g = np.empty((2 * H, W), np.int32)
+        _ck(self._L.tausph_rasterize(self._h, W, H, g.ctypes.data))
+        return g
+
+    def rain_spawned(self):
+        return int(self._L.tausph_rain_spawned(self._h))
 
 
 class Flow2D:

@@ -124,6 +124,11 @@ typedef struct tausph_params {
   int32_t useGrav;      /* 1 */
   int32_t viscSub;      /* 1: sub-steps per step */
   int32_t seed;         /* 69420 */
+  int32_t useXSPH;      /* 0: XSPH velocity smoothing after the integrate (--muscl / --xsph_eps, :81, 481-485) */
+  float xsphEps;        /* 0.25 (:82) */
+  int32_t rain;         /* rain inflow (:377-392, 706-716).  The reference's default is ON (:76) and it has no flag to
+                           turn it off; the parameter default here is 0 because every recorded reference check-value
+                           and BASELINE's SPH config are rain-off — the tau_sph driver sets 1 like the reference. */
 } tausph_params;
 
 #ifdef __cplusplus

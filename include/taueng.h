@@ -186,6 +186,11 @@ int tausph_step(tausph_t *h, int nsteps);                                   /* :
 int tausph_step_async(tausph_t *h, int nsteps);
 int tausph_get_clock(tausph_t *h, float *t, float *tau, int64_t *step);
 int tausph_sync(tausph_t *h);
+/* XSPH (k_xsph_cell + k_apply_xsph, :274-322) and rain (k_rain :377-392 + host bookkeeping :706-716) run inside
+ * tausph_substep_async when tausph_params.useXSPH / .rain are set at create.  Rain collisions (two drops on one
+ * particle) are resolved deterministically: the highest drop index wins. */
+int tausph_rasterize(tausph_t *h, int W, int H, int32_t *host_grid2);        /* k_clear_grid + k_rasterize, :357-374: W x 2H counts */
+int64_t tausph_rain_spawned(tausph_t *h);                                    /* drops spawned so far */
 
 /* =====================================================================
  * Gray-Scott — replaces step_kernel launch + swap, tau_gray_scott.cu:321-329

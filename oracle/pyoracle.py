@@ -259,7 +259,8 @@ class OracleH2:
 class SphParams(C.Structure):
     _fields_ = ([("N", C.c_int32)] + [(n, C.c_float) for n in
                 "boxX boxY dTau t0 CFL rho0 c0 gammaEOS hMul viscAlpha gravity".split()] +
-                [(n, C.c_int32) for n in "useVisc useGrav viscSub seed".split()])
+                [(n, C.c_int32) for n in "useVisc useGrav viscSub seed useXSPH".split()] +
+                [("xsphEps", C.c_float), ("rain", C.c_int32)])
 
 
 class OracleSph:
@@ -297,6 +298,17 @@ class OracleSph:
         cell, h, m = C.c_float(), C.c_float(), C.c_float()
         self.L.osph_grid(self.h, C.byref(gx), C.byref(gy), C.byref(cell), C.byref(h), C.byref(m))
         return {"Gx": gx.value, "Gy": gy.value, "cell": cell.value, "h": h.value, "mass": m.value}
+
+    def rasterize(self, W, H):
+        g = np.empty((2 * H, W), np.int32)
+        self.L.osph_rasterize.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.L.osph_rasterize(self.h, W, H, g.ctypes.data)
+        return g
+
+    def rain_spawned(self):
+        self.L.osph_rain_spawned.restype = C.c_long
+        self.L.osph_rain_spawned.argtypes = [C.c_void_p]
+        return int(self.L.osph_rain_spawned(self.h))
 
     def set_state(self, pos, vel):
         pos = np.ascontiguousarray(pos, np.float32)

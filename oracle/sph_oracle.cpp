@@ -60,6 +60,8 @@ struct osph {
   std::vector<float> accAbs; /* diagnostic: sum over pairs of |term| + pressure-scale term = conditioning scale of acc */
   std::vector<float> s, press;
   std::vector<int> head, next, cellOf;
+  float rain_carry;
+  long rain_spawned;
 };
 
 extern "C" {
@@ -68,6 +70,7 @@ void osph_params_default(tausph_params *P, int N) { /* :49-85 */
   P->N = N; P->boxX = 1.0f; P->boxY = 1.0f; P->dTau = 1.0f; P->t0 = 1.0f; P->CFL = 1.0f;
   P->rho0 = 1.0f; P->c0 = 1.0f; P->gammaEOS = 1.0f; P->hMul = 2.0f; P->viscAlpha = 0.25f; P->gravity = 9.81f;
   P->useVisc = 1; P->useGrav = 1; P->viscSub = 1; P->seed = 69420;
+  P->useXSPH = 0; P->xsphEps = 0.25f; P->rain = 0;
 }
 
 /* reset_particles, :493-510 — jittered lattice in the lower 60 % of the box */
@@ -229,7 +232,73 @@ void osph_substep(osph *S, float dt) {
     if (x.y > P.boxY) { x.y = P.boxY; v.y = -e * v.y; }
     S->pos[i] = x; S->vel[i] = v;
   }
+  if (P.useXSPH && P.xsphEps > 0.f) { /* k_xsph_cell + k_apply_xsph, :274-322, launched :698-704: the lists are the
+                                         ones built BEFORE the integrate, positions / velocities are the new ones */
+    std::vector<f2> dvel(N);
+    for (int i = 0; i < N; i++) {
+      f2 xi = S->pos[i], vi = S->vel[i];
+      float rhoi = expf(S->s[i]);
+      f2 dv{0.f, 0.f};
+      int gx_i = grid_c(xi.x, cell, Gx), gy_i = grid_c(xi.y, cell, Gy);
+      for (int oy = -1; oy <= 1; ++oy)
+        for (int ox = -1; ox <= 1; ++ox) {
+          int cx = gx_i + ox, cy = gy_i + oy;
+          if ((unsigned)cx >= (unsigned)Gx || (unsigned)cy >= (unsigned)Gy) continue;
+          for (int j = S->head[cy * Gx + cx]; j != -1; j = S->next[j])
+            if (j != i) {
+              f2 rij{xi.x - S->pos[j].x, xi.y - S->pos[j].y};
+              float r2 = rij.x * rij.x + rij.y * rij.y;
+              if (r2 >= twoh2) continue;
+              float r = sqrtf(r2);
+              float w = W_cubic(r, h);
+              float rhoj = expf(S->s[j]);
+              float rhoBar = 0.5f * (rhoi + rhoj);
+              f2 vij{S->vel[j].x - vi.x, S->vel[j].y - vi.y};
+              dv.x += (mass / rhoBar) * vij.x * w;
+              dv.y += (mass / rhoBar) * vij.y * w;
+            }
+        }
+      dvel[i] = f2{P.xsphEps * dv.x, P.xsphEps * dv.y};
+    }
+    for (int i = 0; i < N; i++) { /* the reference parks dvel in acc (:699) */
+      S->acc[i] = dvel[i];
+      S->vel[i].x += dvel[i].x; S->vel[i].y += dvel[i].y;
+    }
+  }
+  if (P.rain) { /* host bookkeeping :706-716 + k_rain :377-392.  Two drops may pick the same particle; the
+                   reference leaves the winner to the hardware, here (and in the engine) the HIGHEST drop index
+                   wins — what a launch that retires its threads in order would produce. */
+    S->rain_carry += 0.02f * P.N * dt;
+    int nspawn = (int)S->rain_carry;
+    S->rain_carry -= nspawn;
+    unsigned seed = (unsigned)(P.seed + (int)S->step);
+    for (int k = 0; k < nspawn; k++) {
+      unsigned s = seed ^ ((unsigned)k * 1664525u + 1013904223u);
+      s = s * 1664525u + 1013904223u;
+      float rx = (s & 0x00FFFFFF) / 16777216.f;
+      s = s * 1664525u + 1013904223u;
+      float x = rx * (P.boxX * 0.8f) + 0.1f * P.boxX;
+      float ry = (s & 0x00FFFFFF) / 16777216.f;
+      float y = P.boxY * (0.9f + 0.08f * ry);
+      int i = (int)(s % (unsigned)N);
+      S->pos[i] = f2{x, y};
+      S->vel[i] = f2{0.f, -0.5f * P.c0};
+    }
+    S->rain_spawned += nspawn;
+  }
 }
+
+/* k_rasterize, :363-374: particle counts on a W x 2H raster (y flipped), the ncurses view's input */
+void osph_rasterize(const osph *S, int W, int H, int *grid2) {
+  memset(grid2, 0, sizeof(int) * (size_t)W * 2 * H);
+  for (int i = 0; i < S->P.N; i++) {
+    f2 p = S->pos[i];
+    int cx = (int)(p.x / S->P.boxX * (W - 1));
+    int sy = (int)((S->P.boxY - p.y) / S->P.boxY * (2 * H - 1));
+    if ((unsigned)cx < (unsigned)W && (unsigned)sy < (unsigned)(2 * H)) grid2[sy * W + cx] += 1;
+  }
+}
+long osph_rain_spawned(const osph *S) { return S->rain_spawned; }
 
 /* one step of the host loop (:665-721): K sub-steps + log-time bookkeeping */
 void osph_step(osph *S, int nsteps) {

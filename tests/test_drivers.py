@@ -115,7 +115,7 @@ def test_tau2d_and_sph_end_to_end(built):
     m = re.search(r"step 4  t=(\S+)", r.stdout)
     assert float(m.group(1)) == pytest.approx(GOLD["tau2d_cuda_512x256_4steps_tile32x4"]["t"], rel=1e-5)
     r = run(os.path.join(built, "tau_sph"), "--n", "4096", "--headless", "--steps", "3")
-    assert r.returncode == 0 and "grid=16x16" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "grid=16x16" in r.stdout and "rain=on" in r.stdout, r.stdout + r.stderr
 
 
 @pytest.mark.gpu
@@ -158,3 +158,19 @@ def test_headless_images(built, tmp_path):
     r = run(os.path.join(built, "tau_2d_hypersonic_cuda"), "--W", "64", "--H", "64", "--frames", "1", "--view", "9",
             "--ppm", p2)
     assert r.returncode == 1 and "view mode 9 outside 0..6" in r.stderr
+
+
+@pytest.mark.gpu
+def test_tau_sph_rain_xsph_and_raster(built, tmp_path):
+    """reference defaults: rain on (tau_sph.cu:76); --muscl switches XSPH on (:480-482); --pgm = the ncurses raster"""
+    pg = str(tmp_path / "r.pgm")
+    r = run(os.path.join(built, "tau_sph"), "--n", "16384", "--headless", "--steps", "40", "--muscl", "--pgm", pg)
+    assert r.returncode == 0 and "rain=on xsph=on eps=0.25" in r.stdout, r.stdout + r.stderr
+    assert int(re.search(r"rain: (\d+) drops", r.stdout).group(1)) > 0
+    raw = open(pg, "rb").read()
+    magic, dims, maxv, body = raw.split(b"\n", 3)
+    assert magic == b"P5" and dims == b"80 48" and len(body) == 80 * 48
+    im = np.frombuffer(body, np.uint8).reshape(48, 80)
+    assert im[30:].mean() > 10 * max(im[:10].mean(), 0.1)      # the fluid sits at the bottom (y flipped), rain is sparse
+    r = run(os.path.join(built, "tau_sph"), "--n", "4096", "--headless", "--steps", "3", "--no-rain")
+    assert "rain=off xsph=off" in r.stdout

@@ -133,3 +133,74 @@ def test_large_substep_vs_oracle(eng, oracle_built, N):
     e.substep(dt)
     compare_substep(e.download(), o.state(), what=f"N={N}", dt=dt)
     e.close()
+
+
+# ------------------------------------------------------------------ XSPH, rain, rasterize
+@pytest.mark.parametrize("N,warm,eps", [(4096, 20, 0.25), (16384, 60, 0.5)])
+def test_xsph_substep_parity(eng, oracle_built, N, warm, eps):
+    """XSPH smoothing (k_xsph_cell + k_apply_xsph) after the integrate: velocities and the dvel the reference
+    parks in `acc`.  dvel is a sum of (m / rhoBar) (v_j - v_i) W over ~100 neighbours: compared at 1e-5 of
+    the sum of |terms|, bounded here by eps * 2 max|v| * sum(m W / rhoBar) ~ eps * 2 max|v|."""
+    kw = dict(useXSPH=1, xsphEps=eps)
+    o = oracle_built.OracleSph(N, **kw)
+    e = eng.Sph2D(N, **kw)
+    e.reset_particles()
+    e.step(warm)
+    st = e.download()
+    o.set_state(st["pos"], st["vel"])
+    dt = e.dt()
+    o.substep(dt)
+    e.substep(dt)
+    got, want = e.download(), o.state()
+    assert np.array_equal(got["cell"], want["cell"])
+    vmax = float(np.linalg.norm(want["vel"], axis=1).max())
+    e_d = float(np.abs(got["acc"].astype(np.float64) - want["acc"]).max() / (eps * 2 * vmax))
+    e_v = float(np.abs(got["vel"].astype(np.float64) - want["vel"]).max() / (vmax + 1.0))
+    e_x = float(np.abs(got["pos"].astype(np.float64) - want["pos"]).max())
+    print("xsph parity", N, {"dvel": "%.2e" % e_d, "vel": "%.2e" % e_v, "pos": "%.2e" % e_x},
+          "max|dvel| %.3g max|v| %.3g" % (np.abs(want["acc"]).max(), vmax))
+    assert np.abs(want["acc"]).max() > 1e-3 * eps * vmax      # the smoothing is doing something
+    assert e_d <= TOL and e_v <= TOL and e_x <= 1e-5
+    e.close()
+
+
+def test_rain_is_deterministic_and_matches_oracle(eng, oracle_built):
+    """k_rain re-seeds particles near the top of the box.  Drop positions, target particles and the winner of a
+    collision (highest drop index — the reference leaves it to the hardware) are integer/bit-level facts:
+    the rained particles must match the oracle exactly; the rest of the fluid at the usual tolerance."""
+    N = 16384
+    kw = dict(rain=1)
+    o = oracle_built.OracleSph(N, **kw)
+    e = eng.Sph2D(N, **kw)
+    e.reset_particles()
+    before = e.download()["pos"].copy()
+    e.step(30)
+    o.step(30)
+    assert e.rain_spawned() == o.rain_spawned() > 0
+    got, want = e.download(), o.state()
+    top = want["pos"][:, 1] > 0.8          # only rain gets there this early (the dam fills y < 0.6)
+    assert top.sum() > 0 and np.array_equal(got["pos"][:, 1] > 0.8, top)
+    fresh = want["vel"][:, 0] == 0.0       # drops of the last sub-step: untouched by the fluid since
+    sel = top & fresh & (want["vel"][:, 1] == np.float32(-0.5))
+    assert sel.sum() > 0
+    assert np.array_equal(got["pos"][sel], want["pos"][sel]) and np.array_equal(got["vel"][sel], want["vel"][sel])
+    e2 = eng.Sph2D(N, **kw)
+    e2.reset_particles()
+    e2.step(30)
+    again = e2.download()
+    assert np.array_equal(again["pos"], got["pos"]) and np.array_equal(again["vel"], got["vel"])   # run-to-run identical
+    e.close(); e2.close()
+
+
+@pytest.mark.parametrize("W,H", [(80, 24), (200, 50), (7, 3)])
+def test_rasterize_bit_exact(eng, oracle_built, W, H):
+    N = 16384
+    o = oracle_built.OracleSph(N)
+    e = eng.Sph2D(N)
+    e.reset_particles()
+    e.step(25)
+    st = e.download()
+    o.set_state(st["pos"], st["vel"])
+    g, w = e.rasterize(W, H), o.rasterize(W, H)
+    assert g.sum() == N and np.array_equal(g, w)
+    e.close()

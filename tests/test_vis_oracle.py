@@ -90,3 +90,36 @@ def test_render2d_closed_forms(oracle_built):
     assert tuple(px[0, 0]) == (0, 0, 255, 255) and tuple(px[0, 1]) == (127, 255, 127, 255) and tuple(px[0, 2]) == (255, 0, 0, 255)
     o.mask[3, 3] = 1
     assert tuple(o.render_pixels(ramp, 0.0, 1.0)[3, 3]) == (110, 110, 110, 255)
+
+
+def test_sph_extras_oracle_closed_forms(oracle_built):
+    """XSPH, rain and rasterize restatements (oracle/sph_oracle.cpp) have no reference check-values either."""
+    N = 4096
+    # XSPH: dvel_i = eps sum_j (m / rhoBar_ij) (v_j - v_i) W_ij is antisymmetric in (i, j), so it adds no net
+    # momentum, and it is a smoothing: it cannot increase the velocity variance.  It is parked in acc (:699).
+    o = oracle_built.OracleSph(N, useXSPH=1, xsphEps=0.5)
+    p = oracle_built.OracleSph(N)
+    for k in range(30):
+        p.step(1)
+    st = p.state()
+    o.set_state(st["pos"], st["vel"])
+    dt = p.dt()
+    o.substep(dt); p.substep(dt)
+    a, b = o.state(), p.state()
+    dvel = a["vel"].astype(np.float64) - b["vel"]
+    assert np.array_equal(a["pos"], b["pos"])                 # XSPH acts after the position update
+    assert np.allclose(dvel, a["acc"], rtol=0, atol=2e-7) and np.abs(dvel).max() > 1e-4
+    assert np.abs(dvel.sum(axis=0)).max() <= 1e-3 * np.abs(dvel).sum()
+    assert a["vel"].astype(np.float64).var(axis=0).sum() < b["vel"].astype(np.float64).var(axis=0).sum()
+    # rain: 0.02 N dt drops per sub-step accumulate in a carry (:707-709); drops land in the top band, moving down
+    r = oracle_built.OracleSph(N, rain=1)
+    r.step(40)
+    s = r.state()
+    n = r.rain_spawned()
+    assert n > 0
+    top = s["pos"][:, 1] > 0.85
+    assert 0 < top.sum() <= n
+    assert (s["pos"][top, 0] >= 0.1).all() and (s["pos"][top, 0] <= 0.9).all() and (s["vel"][top, 1] < 0).all()
+    # rasterize: counts sum to N, y flipped (the dam sits at the bottom of the picture)
+    g = oracle_built.OracleSph(N).rasterize(40, 12)
+    assert g.shape == (24, 40) and g.sum() == N and g[:8].sum() == 0 and g[-6:].sum() > 0
