@@ -204,3 +204,34 @@ def test_rasterize_bit_exact(eng, oracle_built, W, H):
     g, w = e.rasterize(W, H), o.rasterize(W, H)
     assert g.sum() == N and np.array_equal(g, w)
     e.close()
+
+
+def test_dense_cluster_takes_the_overflow_path(eng, oracle_built):
+    """600 particles packed into 2 x 2 cells: every row range holds ~300 candidates, far beyond the 128 the
+    neighbour bitmask covers, so most pairs go through the direct-evaluation tail (and the 256-particle
+    workgroups straddle grid rows, so the LDS stage is bypassed too).  One missed neighbour would change rho by
+    ~1/600; sums of ~600 fp32 terms in a different order agree to n * eps = 4e-5."""
+    N = 600
+    rng = np.random.default_rng(7)
+    pos = (0.4 + 0.2 * rng.random((N, 2))).astype(np.float32)
+    vel = (0.05 * rng.standard_normal((N, 2))).astype(np.float32)
+    o = oracle_built.OracleSph(N)
+    e = eng.Sph2D(N)
+    e.upload(pos, vel)
+    o.set_state(pos, vel)
+    g = e.grid()
+    cells = (np.floor(pos[:, 1] / np.float32(g["cell"])).astype(int) * g["Gx"] + np.floor(pos[:, 0] / np.float32(g["cell"])).astype(int))
+    assert np.bincount(cells).max() > 128                      # a single cell already overflows the mask
+    dt = 1e-4
+    o.substep(dt)
+    e.substep(dt)
+    got, want = e.download(), o.state()
+    assert np.array_equal(got["cell"], want["cell"])
+    tol = N * 2.0 ** -24
+    rho_w, rho_g = np.exp(want["s"].astype(np.float64)), np.exp(got["s"].astype(np.float64))
+    e_rho = float((np.abs(rho_g - rho_w) / rho_w).max())
+    scale = np.maximum(want["acc_abs"].astype(np.float64), 1e-30)
+    e_a = float((np.linalg.norm(got["acc"].astype(np.float64) - want["acc"], axis=1) / scale).max())
+    print("cluster parity rho %.2e acc %.2e (tol %.1e), rho range %.3g..%.3g" % (e_rho, e_a, tol, rho_w.min(), rho_w.max()))
+    assert e_rho <= tol and e_a <= tol
+    e.close()
