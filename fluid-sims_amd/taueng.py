@@ -58,6 +58,12 @@ class SphParams(C.Structure):
                 [("xsphEps", C.c_float), ("rain", C.c_int32)])
 
 
+class LbmParams(C.Structure):
+    """taulbm_params == reference Params (tau_lbm.cu:43-55), physics fields only"""
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("obstacle", C.c_int32), ("tau", C.c_float), ("drive", C.c_float),
+                ("rho0", C.c_float), ("obstacle_radius", C.c_float)]
+
+
 class FlowParams(C.Structure):
     """tauflow_params: Params of tau_burgers.cu:56-91 / tau_shallow_water.cu:54-88 in one block"""
     _fields_ = ([("nx", C.c_int32), ("ny", C.c_int32)] +
@@ -169,6 +175,19 @@ def load():
         "tausph_step_async": ([vp, i32], i32),
         "tausph_get_clock": ([vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64)], i32),
         "tausph_sync": ([vp], i32),
+        "taulbm_params_default": ([C.POINTER(LbmParams)], None),
+        "taulbm_create": ([C.POINTER(vp), C.POINTER(LbmParams), i32, vp], i32),
+        "taulbm_destroy": ([vp], None),
+        "taulbm_init": ([vp], i32),
+        "taulbm_upload": ([vp, vp, vp], i32),
+        "taulbm_download": ([vp, vp, vp], i32),
+        "taulbm_state_ptrs": ([vp, C.POINTER(vp), C.POINTER(vp)], i32),
+        "taulbm_set_drive": ([vp, f32], i32),
+        "taulbm_step": ([vp, i32], i32),
+        "taulbm_step_async": ([vp, i32], i32),
+        "taulbm_speed": ([vp, vp], i32),
+        "taulbm_steps_done": ([vp], C.c_int64),
+        "taulbm_sync": ([vp], i32),
         "tausph_rasterize": ([vp, i32, i32, vp], i32),
         "tausph_rain_spawned": ([vp], C.c_int64),
         "tauflow_params_default": ([C.POINTER(FlowParams), i32, i32, i32], None),
@@ -535,6 +554,60 @@ class Sph2D:
 
     def rain_spawned(self):
         return int(self._L.tausph_rain_spawned(self._h))
+
+
+class Lbm2D:
+    """D2Q9 BGK lattice Boltzmann handle (taulbm_*): populations as (9, ny, nx) float32, solid mask (ny, nx) uint8."""
+
+    def __init__(self, nx=512, ny=256, device=0, stream=None, **kw):
+        L = _require_device()
+        p = LbmParams()
+        L.taulbm_params_default(C.byref(p))
+        p.nx, p.ny = nx, ny
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self.params = p
+        self._h = C.c_void_p()
+        _ck(L.taulbm_create(C.byref(self._h), C.byref(p), device, stream))
+        self._L = L
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.taulbm_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def init(self):
+        _ck(self._L.taulbm_init(self._h))
+
+    def upload(self, f=None, solid=None):
+        f = None if f is None else _f32(f)
+        solid = None if solid is None else np.ascontiguousarray(solid, np.uint8)
+        _ck(self._L.taulbm_upload(self._h, None if f is None else f.ctypes.data, None if solid is None else solid.ctypes.data))
+
+    def download(self):
+        f = np.empty((9, self.params.ny, self.params.nx), np.float32)
+        solid = np.empty((self.params.ny, self.params.nx), np.uint8)
+        _ck(self._L.taulbm_download(self._h, f.ctypes.data, solid.ctypes.data))
+        return f, solid
+
+    def set_drive(self, drive):
+        _ck(self._L.taulbm_set_drive(self._h, float(drive)))
+
+    def step(self, n=1):
+        _ck(self._L.taulbm_step(self._h, n))
+
+    def step_async(self, n=1):
+        _ck(self._L.taulbm_step_async(self._h, n))
+
+    def speed(self):
+        s = np.empty((self.params.ny, self.params.nx), np.float32)
+        _ck(self._L.taulbm_speed(self._h, s.ctypes.data))
+        return s
+
+    def sync(self):
+        _ck(self._L.taulbm_sync(self._h))
 
 
 class Flow2D:

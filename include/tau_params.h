@@ -131,6 +131,16 @@ typedef struct tausph_params {
                            and BASELINE's SPH config are rain-off — the tau_sph driver sets 1 like the reference. */
 } tausph_params;
 
+/* ---- D2Q9 BGK lattice Boltzmann (tau_lbm.cu:43-55; same names and defaults) ---- */
+typedef struct taulbm_params {
+  int32_t nx, ny;          /* 512, 256 (the program clamps both to >= 16, :204-205) */
+  int32_t obstacle;        /* 1: cylinder at (0.28 nx, 0.5 ny) */
+  float tau;               /* 0.56: BGK relaxation time, viscosity = (tau - 1/2)/3 */
+  float drive;             /* 1e-6: body-force-like x acceleration */
+  float rho0;              /* 1 */
+  float obstacle_radius;   /* 32 */
+} taulbm_params;
+
 #ifdef __cplusplus
 }
 #endif

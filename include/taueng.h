@@ -244,6 +244,26 @@ int tauflow_get_clock(tauflow_t *h, float *t, float *tau, float *dt_last, float 
 int tauflow_colehopf_relL2(tauflow_t *h, float t_now, double *rel);   /* tau_burgers.cu:720-736 */
 int tauflow_sync(tauflow_t *h);
 
+/* =====================================================================
+ * D2Q9 BGK lattice Boltzmann — replaces the launches of tau_lbm.cu:245-247 (init) and the loop body
+ * :262-269 (collide_stream_kernel, pointer swap, render_kernel).  State: nine populations as nine
+ * row-major j*nx+i fp32 planes back to back (fidx, :62-64) + a u8 solid mask; ping-pong inside the handle.
+ * ===================================================================== */
+typedef struct taulbm taulbm_t;
+void taulbm_params_default(taulbm_params *p);                               /* Params, :43-55 */
+int taulbm_create(taulbm_t **out, const taulbm_params *p, int device, void *stream);
+void taulbm_destroy(taulbm_t *h);
+int taulbm_init(taulbm_t *h);                                               /* init_kernel :72-92 + D2D copy :247 */
+int taulbm_upload(taulbm_t *h, const float *f9 /* 9*nx*ny or NULL */, const uint8_t *solid /* or NULL */);
+int taulbm_download(taulbm_t *h, float *f9, uint8_t *solid);                /* either may be NULL */
+int taulbm_state_ptrs(taulbm_t *h, float **f9, uint8_t **solid);
+int taulbm_set_drive(taulbm_t *h, float drive);                             /* keys '+' / '-', :283-284 */
+int taulbm_step(taulbm_t *h, int nsteps);                                   /* :262-265 */
+int taulbm_step_async(taulbm_t *h, int nsteps);
+int taulbm_speed(taulbm_t *h, float *host_speed);                           /* render_kernel :134-153: |u|, -1 in solids */
+int64_t taulbm_steps_done(taulbm_t *h);
+int taulbm_sync(taulbm_t *h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -409,3 +409,40 @@ class OracleFlow:
     def colehopf_relL2(self, phu, ck, ca, t_now):
         phu = np.ascontiguousarray(phu, np.float32)
         return self.L.o2_burgers_colehopf_relL2(C.byref(self.p), ck, ca, _vp(phu), t_now)
+
+
+class LbmParams(C.Structure):
+    _fields_ = [("nx", C.c_int32), ("ny", C.c_int32), ("obstacle", C.c_int32), ("tau", C.c_float), ("drive", C.c_float),
+                ("rho0", C.c_float), ("obstacle_radius", C.c_float)]
+
+
+class OracleLbm:
+    """D2Q9 BGK oracle (tau_lbm.cu): populations (9, ny, nx) float32, solid (ny, nx) uint8."""
+
+    def __init__(self, nx=512, ny=256, **kw):
+        self.L = _lib("libtauoraclelbm.so")
+        self.p = LbmParams()
+        self.L.olbm_params_default(C.byref(self.p))
+        self.p.nx, self.p.ny = nx, ny
+        for k, v in kw.items():
+            setattr(self.p, k, v)
+        self.solid = np.zeros((ny, nx), np.uint8)
+
+    def init(self):
+        f = np.empty((9, self.p.ny, self.p.nx), np.float32)
+        self.L.olbm_init(C.byref(self.p), _vp(f), _vp(self.solid))
+        return f
+
+    def step(self, f, n=1):
+        f = np.ascontiguousarray(f, np.float32)
+        g = np.empty_like(f)
+        for _ in range(n):
+            self.L.olbm_step(C.byref(self.p), _vp(f), _vp(g), _vp(self.solid))
+            f, g = g, f
+        return f
+
+    def speed(self, f):
+        f = np.ascontiguousarray(f, np.float32)
+        s = np.empty((self.p.ny, self.p.nx), np.float32)
+        self.L.olbm_speed(C.byref(self.p), _vp(f), _vp(self.solid), _vp(s))
+        return s

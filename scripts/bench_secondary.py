@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Throughput of the non-headline configs of BASELINE.json on one MI355X (inputs resident in HBM):
-Gray-Scott 8192^2, Burgers / shallow-water viscosity passes 8192^2, 2D Euler 4096^2 fp32, SPH 4M particles.
+Gray-Scott 8192^2, Burgers / shallow-water viscosity passes and full steps 8192^2, 2D Euler 4096^2 fp32, SPH 4M
+particles, D2Q9 LBM 8192^2.
 Prints one JSON line per workload with the algorithmic-bytes roofline fraction."""
 import argparse
 import json
@@ -77,8 +78,15 @@ def main():
     s = f.Sph2D(N)
     s.reset_particles()
     r, ms = timed(s.step_async, s.sync, N, int(100 * k), 20)
-    line(f"tau_sph {N} particles", "particle-substeps", r, ms, 100, "pair-evaluation valu/latency", {"grid": s.grid()})
+    line(f"tau_sph {N} particles", "particle-substeps", r, ms, 100, "pair-evaluation valu", {"grid": s.grid()})
     s.close()
+
+    n = 8192
+    lb = f.Lbm2D(n, n, obstacle_radius=n / 8)
+    lb.init()
+    r, ms = timed(lb.step_async, lb.sync, n * n, int(200 * k), 20)
+    line(f"tau_lbm D2Q9 {n}^2", "cell-updates", r, ms, 72, "hbm")
+    lb.close()
 
 
 if __name__ == "__main__":

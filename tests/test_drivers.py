@@ -174,3 +174,19 @@ def test_tau_sph_rain_xsph_and_raster(built, tmp_path):
     assert im[30:].mean() > 10 * max(im[:10].mean(), 0.1)      # the fluid sits at the bottom (y flipped), rain is sparse
     r = run(os.path.join(built, "tau_sph"), "--n", "4096", "--headless", "--steps", "3", "--no-rain")
     assert "rain=off xsph=off" in r.stdout
+
+
+@pytest.mark.gpu
+def test_tau_lbm_end_to_end(built, tmp_path):
+    pg = str(tmp_path / "l.pgm")
+    r = run(os.path.join(built, "tau_lbm"), "--nx", "256", "--ny", "128", "--headless", "--steps", "400", "--radius", "16",
+            "--drive", "1e-4", "--pgm", pg)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert re.search(r"LBM D2Q9: 400 steps, 32768 cells, [0-9.]+ MLUPS", r.stdout)     # tau_lbm.cu:297-299
+    raw = open(pg, "rb").read()
+    magic, dims, maxv, body = raw.split(b"\n", 3)
+    im = np.frombuffer(body, np.uint8).reshape(128, 256)
+    assert dims == b"256 128" and (im[0] == 255).all() and (im[-1] == 255).all()        # channel walls
+    assert im[64, 72] == 255 and im[64, 200] < 255                                       # cylinder at 0.28 nx; fluid behind it
+    r = run(os.path.join(built, "tau_lbm"), "--nx", "4", "--tau", "0.1", "--headless", "--steps", "2")
+    assert "2 steps, 4096 cells" in r.stdout                                             # nx, ny clamp to >= 16 ... ny default 256

@@ -1,0 +1,80 @@
+"""GPU: D2Q9 BGK lattice Boltzmann (taulbm_*, through the C-ABI) against the CPU oracle — bit-exact: every slot
+of the streamed array has one writer and both sides are compiled without FMA contraction."""
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("nx,ny,kw", [(512, 256, {}), (100, 60, dict(obstacle_radius=9.0)), (257, 33, dict(obstacle=0)),
+                                      (16, 16, dict(obstacle_radius=3.0)), (1024, 64, dict(tau=0.8, drive=1e-4))])
+def test_init_and_steps_bit_exact(eng, oracle_built, nx, ny, kw):
+    o = oracle_built.OracleLbm(nx, ny, **kw)
+    e = eng.Lbm2D(nx, ny, **kw)
+    f0 = o.init()
+    e.init()
+    g0, solid = e.download()
+    assert np.array_equal(solid, o.solid) and np.array_equal(g0, f0)
+    for n in (1, 2, 7):
+        f0 = o.step(f0, n)
+        e.step(n)
+        g, _ = e.download()
+        assert np.array_equal(g, f0), f"after {n} more steps"
+    e.close()
+
+
+def test_random_state_and_mask_bit_exact(eng, oracle_built):
+    """arbitrary populations and an arbitrary solid mask (isolated solid cells, solid columns through the
+    periodic seam, fluid cells on the first and last row): every bounce-back / wrap branch in one step"""
+    nx, ny = 96, 40
+    rng = np.random.default_rng(11)
+    f = (0.05 + rng.random((9, ny, nx))).astype(np.float32)
+    solid = (rng.random((ny, nx)) < 0.15).astype(np.uint8)
+    solid[:, 0] = 1
+    solid[5:9, nx - 1] = 1
+    solid[0, 10:20] = 0
+    o = oracle_built.OracleLbm(nx, ny, drive=3e-3)
+    o.solid[:] = solid
+    e = eng.Lbm2D(nx, ny, drive=3e-3)
+    e.upload(f, solid)
+    want = o.step(f, 3)
+    e.step(3)
+    got, m = e.download()
+    assert np.array_equal(m, solid) and np.array_equal(got, want)
+    e.close()
+
+
+def test_speed_field(eng, oracle_built):
+    o = oracle_built.OracleLbm(256, 128)
+    e = eng.Lbm2D(256, 128)
+    f = o.init()
+    e.init()
+    f = o.step(f, 50)
+    e.step(50)
+    s, w = e.speed(), o.speed(f)
+    assert np.array_equal(s < 0, o.solid == 1) and (s[o.solid == 1] == -1).all()
+    fl = o.solid == 0
+    assert np.abs(s[fl] - w[fl]).max() <= 1e-6 * max(1.0, float(w[fl].max())) + 1e-9     # hypotf: device vs libm
+    assert w[fl].max() > 1e-3
+    e.close()
+
+
+def test_full_size_properties(eng):
+    """8192 x 4096 (33.5 M cells): total mass is conserved by collide + stream + bounce-back (to fp32 summation),
+    and the run is deterministic"""
+    nx, ny = 8192, 4096
+    e = eng.Lbm2D(nx, ny, obstacle_radius=400.0)
+    e.init()
+    f0, solid = e.download()
+    m0 = f0.sum(dtype=np.float64)
+    e.step(20)
+    f1, _ = e.download()
+    assert np.isfinite(f1).all()
+    assert abs(f1.sum(dtype=np.float64) - m0) <= 1e-6 * m0
+    e.init()
+    e.step(20)
+    f2, _ = e.download()
+    assert np.array_equal(f1, f2)
+    e.close()

@@ -123,3 +123,38 @@ def test_sph_extras_oracle_closed_forms(oracle_built):
     # rasterize: counts sum to N, y flipped (the dam sits at the bottom of the picture)
     g = oracle_built.OracleSph(N).rasterize(40, 12)
     assert g.shape == (24, 40) and g.sum() == N and g[:8].sum() == 0 and g[-6:].sum() > 0
+
+
+def test_lbm_oracle_closed_forms(oracle_built):
+    """oracle/lbm_oracle.c has no reference check-values (SURVEY §8c lists none for tau_lbm.cu): closed forms."""
+    nx, ny = 64, 32
+    # (a) no drive, no obstacle, fluid at rest: the equilibrium is a fixed point of collide + stream + bounce-back
+    o = oracle_built.OracleLbm(nx, ny, obstacle=0, drive=0.0)
+    f = o.init()
+    w = np.float32([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)
+    rest = np.broadcast_to(w[:, None, None], (9, ny, nx)).astype(np.float32).copy()
+    assert np.array_equal(o.solid[0], np.ones(nx, np.uint8)) and o.solid[1:-1].sum() == 0      # channel walls only
+    g = o.step(rest, 5)
+    assert np.abs(g - rest).max() <= 2e-7
+    # (b) mass is conserved by every step, with obstacle, shear start and drive
+    o = oracle_built.OracleLbm(nx, ny, obstacle_radius=6.0, drive=1e-4)
+    f = o.init()
+    m0 = f.sum(dtype=np.float64)
+    f = o.step(f, 25)
+    assert abs(f.sum(dtype=np.float64) - m0) <= 1e-6 * m0
+    # (c) a solid cell reflects: fout[opp q] = fin[q]
+    opp = [0, 3, 4, 1, 2, 7, 8, 5, 6]
+    rng = np.random.default_rng(5)
+    r = rng.random((9, ny, nx)).astype(np.float32)
+    out = o.step(r, 1)
+    sj, si = np.argwhere(o.solid == 1)[7]
+    assert all(out[opp[q], sj, si] == r[q, sj, si] for q in range(9))
+    # (d) the drive accelerates the channel flow in +x
+    o = oracle_built.OracleLbm(nx, ny, obstacle=0, drive=1e-4)
+    o.init()                                                  # builds the wall mask
+    f = o.step(rest, 60)
+    ux = (f[1] + f[5] + f[8] - f[3] - f[6] - f[7])[1:-1].mean()
+    assert ux > 1e-3
+    # (e) speed: -1 in solids, |u| elsewhere
+    s = o.speed(f)
+    assert (s[0] == -1).all() and s[ny // 2].mean() == pytest.approx(ux, rel=0.5)
