@@ -340,6 +340,7 @@ extern "C" int tauflow_create(tauflow_t **out, const tauflow_params *P, int kind
   TAU_HIP(hipSetDevice(device));
   tauflow *h = new (std::nothrow) tauflow();
   if (!h) return tau::fail("tauflow_create: out of host memory");
+  tau::HandleGuard<tauflow> guard{h, tauflow_destroy};
   h->p = *P; h->kind = kind; h->nf = kind == 0 ? 2 : 3; h->device = device; h->cur = 0; h->max_valid = false;
   if (kind == 0 && h->p.oneD) h->p.ny = 1; // tau_burgers.cu:654-655
   h->own_stream = (stream == nullptr);
@@ -351,7 +352,7 @@ extern "C" int tauflow_create(tauflow_t **out, const tauflow_params *P, int kind
   TAU_HIP(hipMalloc(&h->st, sizeof(fl2::DevState)));
   TAU_HIP(hipMemsetAsync(h->st, 0, sizeof(fl2::DevState), h->stream));
   h->tau = P->tau0; h->t = P->t0; h->step = 0; h->visc = nullptr;
-  *out = h;
+  *out = guard.release();
   return 0;
 }
 extern "C" void tauflow_destroy(tauflow_t *h) {
@@ -361,7 +362,7 @@ extern "C" void tauflow_destroy(tauflow_t *h) {
   for (int s = 0; s < 2; s++)
     for (int f = 0; f < h->nf; f++) hipFree(h->buf[s][f]);
   hipFree(h->st);
-  if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 extern "C" int tauflow_upload(tauflow_t *h, const float *const f[3]) {

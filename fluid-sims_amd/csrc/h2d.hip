@@ -572,6 +572,7 @@ extern "C" int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, vo
   TAU_HIP(hipSetDevice(device));
   tauh2 *h = new (std::nothrow) tauh2();
   if (!h) return tau::fail("tauh2_create: out of host memory");
+  tau::HandleGuard<tauh2> guard{h, tauh2_destroy};
   h->p = *p; h->device = device; h->cur = 0; h->maxs_valid = false;
   h->own_stream = (stream == nullptr);
   if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -584,7 +585,7 @@ extern "C" int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, vo
   TAU_HIP(hipMemsetAsync(h->st, 0, sizeof(h2d::DevState), h->stream));
   TAU_HIP(hipMemsetAsync(h->mask, 0, n, h->stream));
   h2_consts(h);
-  *out = h;
+  *out = guard.release();
   return 0;
 }
 extern "C" void tauh2_destroy(tauh2_t *h) {
@@ -595,7 +596,7 @@ extern "C" void tauh2_destroy(tauh2_t *h) {
     for (int f = 0; f < 4; f++) hipFree(h->buf[s][f]);
   hipFree(h->mask); hipFree(h->st);
   hipFree(h->rval); hipFree(h->rpix); hipFree(h->rmm);
-  if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 

@@ -945,6 +945,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   TAU_HIP(hipSetDevice(device));
   tau3d *h = new (std::nothrow) tau3d();
   if (!h) return tau::fail("tau3d_create: out of host memory");
+  tau::HandleGuard<tau3d> guard{h, tau3d_destroy};
   h->p = *p; h->z0 = z0; h->nzl = nzl; h->device = device; h->cur = 0;
   h->plane_n = (size_t)p->nx * p->ny;
   h->field_n = h->plane_n * (size_t)(nzl + 2 * h3d::HALO);
@@ -961,7 +962,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
   fill_consts(h);
   tau3d_clock c = {1e-5f, 1e-3f, 0.f, 0.f, 0.f, 0};
-  *out = h;
+  *out = guard.release();
   return tau3d_set_clock(h, &c);
 }
 
@@ -976,7 +977,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch);
   for (int k = 0; k < 2; k++)
     for (int sd = 0; sd < 2; sd++) hipFree(h->xbuf[k][sd]);
-  if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   if (h->ev_made) for (int i = 0; i < 4096; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); }
   delete h;
 }

@@ -152,6 +152,7 @@ extern "C" int taulbm_create(taulbm_t **out, const taulbm_params *P, int device,
   TAU_HIP(hipSetDevice(device));
   taulbm *h = new (std::nothrow) taulbm();
   if (!h) return tau::fail("taulbm_create: out of host memory");
+  tau::HandleGuard<taulbm> guard{h, taulbm_destroy};
   h->p = *P; h->device = device;
   h->own_stream = (stream == nullptr);
   if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -162,7 +163,7 @@ extern "C" int taulbm_create(taulbm_t **out, const taulbm_params *P, int device,
   TAU_HIP(hipMalloc(&h->speed, cells * sizeof(float)));
   TAU_HIP(hipMalloc(&h->solid, cells));
   TAU_HIP(hipMemsetAsync(h->solid, 0, cells, h->stream));
-  *out = h;
+  *out = guard.release();
   return 0;
 }
 extern "C" void taulbm_destroy(taulbm_t *h) {
@@ -170,7 +171,7 @@ extern "C" void taulbm_destroy(taulbm_t *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   hipFree(h->f[0]); hipFree(h->f[1]); hipFree(h->speed); hipFree(h->solid);
-  if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 

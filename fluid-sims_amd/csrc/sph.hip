@@ -466,6 +466,7 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipSetDevice(device));
   tausph *h = new (std::nothrow) tausph();
   if (!h) return tau::fail("tausph_create: out of host memory");
+  tau::HandleGuard<tausph> guard{h, tausph_destroy};
   h->p = *P; h->device = device;
   h->own_stream = (stream == nullptr);
   if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -511,7 +512,7 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
                                              h->key_bits, h->stream));
   TAU_HIP(hipMalloc(&h->cub_tmp, h->cub_bytes));
   h->tau = 0.f; h->t = P->t0 * expf(h->tau); h->step = 0; // :577-578
-  *out = h;
+  *out = guard.release();
   return 0;
 }
 extern "C" void tausph_destroy(tausph_t *h) {
@@ -522,7 +523,7 @@ extern "C" void tausph_destroy(tausph_t *h) {
   hipFree(A.pos); hipFree(A.vel); hipFree(A.acc); hipFree(A.s); hipFree(A.press); hipFree(A.cellOf);
   hipFree(A.keys); hipFree(A.ids); hipFree(A.keys_s); hipFree(A.ids_s); hipFree(A.cellStart);
   hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(A.recA2); hipFree(A.rainWinner); hipFree(h->raster); hipFree(h->cub_tmp);
-  if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
 

@@ -232,7 +232,7 @@ static void pair_destroy(Pair *h) {
   hipStreamSynchronize(h->stream);
   for (int s = 0; s < 2; s++)
     for (int f = 0; f < 2; f++) hipFree(h->buf[s][f]);
-  if (h->own_stream) hipStreamDestroy(h->stream);
+  if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
 }
 static int pair_upload(Pair *h, const float *a, const float *b) {
   TAU_HIP(hipSetDevice(h->device));
@@ -280,7 +280,7 @@ extern "C" int taugs_create(taugs_t **out, const taugs_params *p, int device, vo
   taugs *h = new (std::nothrow) taugs();
   if (!h) return tau::fail("taugs_create: out of host memory");
   h->p = *p;
-  if (st2::pair_create(&h->pr, p->nx, p->ny, device, stream)) { delete h; return 1; }
+  if (st2::pair_create(&h->pr, p->nx, p->ny, device, stream)) { taugs_destroy(h); return 1; }
   *out = h;
   return 0;
 }
@@ -350,7 +350,7 @@ extern "C" int taulap_create(taulap_t **out, const taulap_params *p, int kind, i
   taulap *h = new (std::nothrow) taulap();
   if (!h) return tau::fail("taulap_create: out of host memory");
   h->p = *p; h->kind = kind; h->oneD = oneD;
-  if (st2::pair_create(&h->pr, p->nx, p->ny, device, stream)) { delete h; return 1; }
+  if (st2::pair_create(&h->pr, p->nx, p->ny, device, stream)) { taulap_destroy(h); return 1; }
   *out = h;
   return 0;
 }

@@ -14,8 +14,10 @@ int fail(const char *fmt, ...);
 #define TAU_HIP(expr)                                                                     \
   do {                                                                                    \
     hipError_t e_ = (expr);                                                               \
-    if (e_ != hipSuccess)                                                                 \
+    if (e_ != hipSuccess) {                                                               \
+      (void)hipGetLastError(); /* the runtime's last-error is sticky: do not leave it for the next launch check */ \
       return ::tau::fail("%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    }                                                                                     \
   } while (0)
 
 #define TAU_LAUNCH_CHECK(name)                                                            \
@@ -23,6 +25,16 @@ int fail(const char *fmt, ...);
     hipError_t e_ = hipGetLastError();                                                    \
     if (e_ != hipSuccess) return ::tau::fail("%s launch: %s", name, hipGetErrorString(e_)); \
   } while (0)
+
+// Owns a half-built handle inside a *_create function: TAU_HIP returns early on the first failing HIP call,
+// and this hands what was already allocated to the handle's own destroy function.
+template <class H>
+struct HandleGuard {
+  H *h;
+  void (*destroy)(H *);
+  ~HandleGuard() { if (h) destroy(h); }
+  H *release() { H *t = h; h = nullptr; return t; }
+};
 
 // Linear block id -> work item, so that the 8 XCDs (block b runs on XCD b % 8) each walk a
 // contiguous range of tiles: neighbouring tiles share halo lines through the same L2.
