@@ -384,7 +384,7 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 }
 
 // ---------------------------------------------------------------- the step kernel
-__global__ __launch_bounds__(NT, 3) void k_step(const Args A) {
+__global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
   __shared__ float sP[6][PLANE];            // current plane, primitives, x/y halo 3
   __shared__ uint8_t sS[PLANE];             // solid flags of the same cells
   __shared__ float sFx[6][TY][TX + 1];      // low-x face flux of cell (y, x); column TX = far edge
