@@ -52,17 +52,41 @@ def cpu_baseline(n, state_slab, dt, z0, planes, max_seconds=25.0):
                       f"{el:.1f} s, gcc -O2 IEEE fp32, 1 thread (the reference is single-threaded)"}
 
 
-def cpu_baseline_2d(steps=100):
+def cpu_baseline_2d(steps=100, n=300):
     """What north_star names: tau_hypersonic_simd.c (fp64, AVX2 compute_dt, -O3 -mavx2 -mfma) on the host,
     300^2 as shipped, 1 thread — the restated CPU program of BASELINE config 1 (fluid-sims_amd/cpu/)."""
     from importlib import import_module
     m = import_module("fluid_sims_amd.cpu2d")
-    s = m.CpuHypersonic2D(300, 300, simd=True)
+    s = m.CpuHypersonic2D(n, n, simd=True)
     t0 = time.perf_counter()
     s.step(steps)
     el = time.perf_counter() - t0
-    return {"value": 300 * 300 * steps / el / 1e9, "unit": "Gcell-updates/s", "cores": 1, "kind": "port",
-            "sample": f"tau_hypersonic_simd restated, 2D 300x300 fp64, {steps} steps, {el:.2f} s, 1 thread"}
+    return {"value": n * n * steps / el / 1e9, "unit": "Gcell-updates/s", "cores": 1, "kind": "port",
+            "sample": f"tau_hypersonic_simd restated, 2D {n}x{n} fp64, {steps} steps, {el:.2f} s, 1 thread"}
+
+
+def input_variants(f, n, steps=6):
+    """SURVEY §8d asks for two more inputs beside the headline one: (i) the reference's own quiescent k_init
+    start after 50 controller warm-up steps, and a no-body variant that bounds the branch-free throughput."""
+    out = {}
+    for name, mode, warm, body in (("reference_ic_50_warmup", 0, 50, True), ("developed_no_body", 1, 10, False)):
+        p = f.Tau3DParams()
+        f.load().tau3d_params_default(ctypes.byref(p), n, n, n)
+        if not body:
+            p.sdf_r = -1.0
+        e = f.Tau3D(n, n, n, params=p)
+        e.init(mode)
+        if mode:
+            e.set_clock(0.02, 1e-4)
+        e.step_async(warm)
+        e.sync()
+        t0 = time.perf_counter()
+        e.step_async(steps)
+        e.sync()
+        el = time.perf_counter() - t0
+        out[name] = {"value": round(float(n) ** 3 * steps / el / 1e9, 3), "unit": "Gcell-updates/s", "steps": steps, "warmup": warm}
+        e.close()
+    return out
 
 
 def main():
@@ -72,6 +96,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n", type=int, default=512, help="grid edge (headline: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the two extra SURVEY 8d inputs (reference IC, no body)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab ring driver even on one GPU (self-neighbour halo copies): exercises the N>1 code path")
     args = ap.parse_args()
@@ -174,6 +199,11 @@ def main():
                           "grid": [n, n, n], "decomposition": f"z-slab x{world}" if world > 1 else "single domain",
                           "halo_planes": 3, "t": clk.t, "d_tau": clk.d_tau, "maxs": clk.maxs},
                "roofline": roof}
+        if world == 1 and not args.no_variants and not args.force_slab:
+            try:
+                out["other_inputs"] = input_variants(f, n)
+            except Exception as e:  # extras never take the headline down
+                out["other_inputs"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             planes = 8
             zc = n // 2 - 40 if n >= 128 else 0
@@ -182,6 +212,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n, [np.ascontiguousarray(a) for a in st], clk.dt, zc, planes)
             try:
                 out["cpu_baseline_2d_simd"] = cpu_baseline_2d()
+                out["cpu_baseline_2d_simd_256"] = cpu_baseline_2d(n=256)      # BASELINE config 1 size
             except Exception as e:  # the 2D CPU program is an extra, never fatal for the headline
                 out["cpu_baseline_2d_simd"] = {"error": str(e)}
         print(json.dumps(out), flush=True)

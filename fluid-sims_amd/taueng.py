@@ -17,7 +17,8 @@ class TauError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libtaueng.so")
+    # TAUENG_LIB lets a tuning experiment load a variant build of the same library; default: the in-tree one
+    return os.environ.get("TAUENG_LIB") or os.path.join(_HERE, "lib", "libtaueng.so")
 
 
 _lib = None

@@ -8,7 +8,7 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
-CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline"
+CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-variants"
 run() { # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
