@@ -49,8 +49,12 @@ int main(int argc, char **argv) {
   double t0 = cli_now();
   tau3d_clock c;
   for (int f = 0; f < frames; f++) {
-    TAU_CK(tau3d_step(h, steps_per_frame, &c));
-    if (f % 10 == 0 || f == frames - 1) /* the reference's HUD line, :1762-1771 */
+    /* the clock lives on the device: only the frames that print it pay for the read-back (the reference copies
+       maxs to the host every step, :1697) */
+    const int show = (f % 10 == 0 || f == frames - 1);
+    if (show) TAU_CK(tau3d_step(h, steps_per_frame, &c));
+    else TAU_CK(tau3d_step_async(h, steps_per_frame));
+    if (show) /* the reference's HUD line, :1762-1771 */
       printf("frame %d  step %d  t=%.6g  d_tau=%.4g  dt=%.4g  gain=%.3f  maxs=%.6g\n", f, c.step, c.t, c.d_tau, c.dt,
              c.gain, c.maxs);
   }

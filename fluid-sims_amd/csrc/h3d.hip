@@ -1088,12 +1088,19 @@ extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *st
   for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
   int nplanes = zl_hi - zl_lo;
-  // enough workgroups (~32k) to load-balance 256 CUs x 3 resident blocks; chunks of 8..32 planes
+  // Planes marched by one workgroup.  Large grids: enough workgroups (~32k) to load-balance 256 CUs x 3 resident
+  // groups, chunks of 8..32 planes (a chunk re-decodes 4 warm-up planes, so longer is cheaper).  Small grids are
+  // LATENCY bound instead — a 64^3 launch is 128 workgroups of 13 serial plane iterations with chunks of 8 — so
+  // below that the chunk shrinks (down to 2) until there are ~2k workgroups: 64^3 2.8 -> 6.0 Gcell/s.
   int zc = h->zchunk;
   if (zc <= 0) {
-    int want = (32768 + A.ntx * A.nty - 1) / (A.ntx * A.nty);
-    zc = nplanes / (want > 0 ? want : 1);
-    zc = zc < 8 ? 8 : (zc > 32 ? 32 : zc);
+    const long tiles = (long)A.ntx * A.nty;
+    zc = (int)((long)nplanes * tiles / 32768);
+    if (zc < 8) {
+      if (tiles >= 768) zc = 8;                        // wide planes fill the chip by themselves: keep chunks long
+      else { zc = (int)((long)nplanes * tiles / 2048); zc = zc < 2 ? 2 : (zc > 8 ? 8 : zc); }
+    }
+    zc = zc > 32 ? 32 : zc;
   }
   A.zchunk = zc < nplanes ? zc : nplanes;
   A.nzc = (nplanes + A.zchunk - 1) / A.zchunk;
