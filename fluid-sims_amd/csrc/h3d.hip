@@ -146,9 +146,14 @@ __device__ __forceinline__ Prim outflow_prim(const Args &A, Prim qR) {
   return q;
 }
 
-__device__ __forceinline__ bool sdf_solid(const Args &A, int x, int y, int zg) { // :173-189
-  float X = (x + 0.5f) * A.dx, Y = (y + 0.5f) * A.dy, Z = (zg + 0.5f) * A.dz;
-  float ddx = X - A.sdf_cx, ddy = Y - A.sdf_cy, ddz = Z - A.sdf_cz;
+// Solid classification of a cell centre, :173-189.  This is an INTEGER result (the mask must be bit-identical to
+// the oracle's), and cell centres do land exactly on the sphere (z = 37 of 50 planes: (37.5)/50 - 0.5 = r): there a
+// fused multiply-add rounds the other way than mul-then-sub and flips the cell.  Contraction is therefore switched
+// off for this function (HIP's __fmul_rn & co. are plain operators and do not prevent it).
+__device__ __forceinline__ bool sdf_solid(const Args &A, int x, int y, int zg) {
+#pragma clang fp contract(off)
+  const float X = (x + 0.5f) * A.dx, Y = (y + 0.5f) * A.dy, Z = (zg + 0.5f) * A.dz;
+  const float ddx = X - A.sdf_cx, ddy = Y - A.sdf_cy, ddz = Z - A.sdf_cz;
   return (sqrtf(ddx * ddx + ddy * ddy + ddz * ddz) - A.sdf_r) < 0.f;
 }
 

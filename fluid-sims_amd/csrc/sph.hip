@@ -392,6 +392,7 @@ __global__ __launch_bounds__(256) void k_xsph(const Args A) {
 // Rain, k_rain (:377-392).  Two drops may pick the same particle; the reference leaves the winner to the
 // hardware.  Here the HIGHEST drop index wins (what an in-order launch would give): claim, then apply.
 __device__ __forceinline__ unsigned rain_draw(unsigned seed, int k, float boxX, float boxY, float &x, float &y) {
+#pragma clang fp contract(off)   // drop positions are compared bit for bit with the host restatement
   unsigned s = seed ^ ((unsigned)k * 1664525u + 1013904223u);
   s = s * 1664525u + 1013904223u;
   const float rx = (s & 0x00FFFFFF) / 16777216.f;

@@ -19,7 +19,10 @@ def oracle_one_step(P, o, fields, dt, gain):
     return o.interior(out), m
 
 
-@pytest.mark.parametrize("shape", [(32, 32, 32), (48, 40, 24), (64, 64, 64), (40, 24, 16)])
+# the last five have cell centres exactly on the sphere (e.g. z = 37 of 50: 37.5 / 50 - 0.5 = r): an FMA-contracted
+# signed distance rounds those the other way (found by a random-shape sweep)
+@pytest.mark.parametrize("shape", [(32, 32, 32), (48, 40, 24), (64, 64, 64), (40, 24, 16), (61, 61, 50), (14, 29, 35),
+                                   (63, 45, 10), (39, 27, 62), (24, 41, 30)])
 def test_init_and_mask_bit_exact(eng, oracle_built, shape):
     nx, ny, nz = shape
     e = eng.Tau3D(nx, ny, nz)
