@@ -15,5 +15,5 @@ def test_random_shapes(eng, oracle_built, seed):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     msgs = []
-    it, bad = m.sweep(seed=seed, seconds=60.0, max_iter=60, log=msgs.append)
-    assert it == 60 and bad == 0, "\n".join(msgs)
+    it, bad = m.sweep(seed=seed, seconds=90.0, max_iter=90, log=msgs.append)
+    assert it == 90 and bad == 0, "\n".join(msgs)
