@@ -165,7 +165,8 @@ template <class F>
 __device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int tid, const Walk &wk, F &&body) {
   int w = 0;
   unsigned m = sM[0][tid];
-  int wbase = wk.jb[0];
+  const int b0 = wk.jb[0], d1 = wk.jb[1] - wk.jb[0], d2 = wk.jb[2] - wk.jb[1];
+  int wbase = b0;
   // One straight-line step per trip: a lane whose word ran dry fetches its next word (an empty word costs
   // that lane one idle trip), then every lane holding a bit evaluates it.  No inner loop: the other lanes
   // of the wave would only wait for it.
@@ -173,7 +174,9 @@ __device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int tid,
     if (m == 0u) {
       ++w;
       m = sM[w][tid];
-      wbase = (w < WPR ? wk.jb[0] : w < 2 * WPR ? wk.jb[1] : wk.jb[2]) + ((w & (WPR - 1)) << 5);
+      // (two independent selects: a chained select over jb[] is turned into a 3-entry table in scratch memory,
+      // and the load sits on the critical path of every word fetch)
+      wbase = b0 + (w >= WPR ? d1 : 0) + (w >= 2 * WPR ? d2 : 0) + ((w & (WPR - 1)) << 5);
     }
     if (m != 0u) {
       const int j = wbase + __builtin_ctz(m);
