@@ -117,6 +117,19 @@ __device__ __forceinline__ C4 neigh(const Args &A, const Tile &T, P4 center, int
   return T.cons(xn, yn);
 }
 
+// The same function without branches, for the twelve calls per cell of the predictor and the diffusion stencil.
+// Staging has already resolved the two x cases — halo columns left of x = 0 hold the inflow state, columns right of
+// x = W-1 hold cell W-1, both with the mask cleared — and clamps y like the reference's tile load; the caller forms
+// the wall ghost of its centre cell once.  What is left is one select per component (the branchy form above cost
+// ~36 exec-mask branches per cell).
+__device__ __forceinline__ C4 wall_ghost(const Args &A, P4 center) { return p2c(A, P4{center.r, -center.u, -center.v, center.p}); }
+__device__ __forceinline__ C4 neigh_sel(const Args &A, const Tile &T, const C4 &wg, int xn, int yn) {
+  yn = max(0, min(yn, A.H - 1));
+  const C4 c = T.cons(xn, yn);
+  const bool use_wall = T.masked(xn, yn);
+  return C4{use_wall ? wg.r : c.r, use_wall ? wg.mx : c.mx, use_wall ? wg.my : c.my, use_wall ? wg.E : c.E};
+}
+
 __device__ __forceinline__ void enforce_positive(P4 &qm, const P4 &qc, P4 &qp) { // :373-398
   for (int it = 0; it < 8; it++) {
     bool bad = (qm.r <= EPS_RHO) || (qp.r <= EPS_RHO) || (qm.p <= EPS_P) || (qp.p <= EPS_P);
@@ -138,11 +151,11 @@ __device__ __forceinline__ P4 half_step(const Args &A, P4 q, C4 dF, float h) { /
 }
 
 // MUSCL-Hancock predicted low / high face states of one cell along one axis, :911-961
-__device__ __forceinline__ void predict_axis(const Args &A, const Tile &T, P4 qc, int x, int y, int ax, float half,
+__device__ __forceinline__ void predict_axis(const Args &A, const Tile &T, P4 qc, const C4 &wg, int x, int y, int ax, float half,
                                              P4 &lo, P4 &hi) {
   const int dx = ax ? 0 : 1, dy = ax ? 1 : 0;
-  P4 qm = c2p(A, neigh(A, T, qc, x - dx, y - dy));
-  P4 qp = c2p(A, neigh(A, T, qc, x + dx, y + dy));
+  P4 qm = c2p(A, neigh_sel(A, T, wg, x - dx, y - dy));
+  P4 qp = c2p(A, neigh_sel(A, T, wg, x + dx, y + dy));
   float s_r = mc(qc.r - qm.r, 0.5f * (qp.r - qm.r), qp.r - qc.r);
   float s_u = mc(qc.u - qm.u, 0.5f * (qp.u - qm.u), qp.u - qc.u);
   float s_v = mc(qc.v - qm.v, 0.5f * (qp.v - qm.v), qp.v - qc.v);
@@ -269,11 +282,14 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
   //         the inflow column overwrite of k_apply_inflow_left happens here
   for (int t = tid; t < UH * UW; t += NT) {
     const int ly = t / UW, lx = t - ly * UW;
-    const int sx = max(0, min(bx0 - 2 + lx, A.W - 1)), sy = max(0, min(by0 - 2 + ly, A.H - 1));
+    const int gx = bx0 - 2 + lx;
+    const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(by0 - 2 + ly, A.H - 1));
     const size_t gi = (size_t)sy * A.W + sx;
-    const uint8_t m = A.mask[gi];
+    // columns outside the domain: left = the inflow state, right = a copy of cell W-1; neither is ever "wall"
+    // (neighbor_or_wall tests x before the mask, :266-290)
+    const uint8_t m = (gx < 0 || gx >= A.W) ? (uint8_t)0 : A.mask[gi];
     C4 c{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
-    if (sx == 0 && !m) c = A.in_c;
+    if ((sx == 0 && !A.mask[gi]) || gx < 0) c = A.in_c;
     sU[0][t] = c.r; sU[1][t] = c.mx; sU[2][t] = c.my; sU[3][t] = c.E;
     sM[t] = m;
   }
@@ -288,10 +304,11 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
     if (cx < 0 || cx >= A.W || cy < 0 || cy >= A.H) continue;
     if (T.masked(cx, cy)) continue;
     const P4 qc = c2p(A, T.cons(cx, cy));
+    const C4 wg = wall_ghost(A, qc);
     P4 lo, hi;
-    predict_axis(A, T, qc, cx, cy, 0, half, lo, hi);
+    predict_axis(A, T, qc, wg, cx, cy, 0, half, lo, hi);
     Q.put(0, cx, cy, lo); Q.put(1, cx, cy, hi);
-    predict_axis(A, T, qc, cx, cy, 1, half, lo, hi);
+    predict_axis(A, T, qc, wg, cx, cy, 1, half, lo, hi);
     Q.put(2, cx, cy, lo); Q.put(3, cx, cy, hi);
   }
   __syncthreads();
@@ -329,9 +346,9 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
       Un.my -= dt * (sFx[2][ty][tx + 1] - sFx[2][ty][tx]); Un.E -= dt * (sFx[3][ty][tx + 1] - sFx[3][ty][tx]);
       Un.r -= dt * (sFy[0][ty + 1][tx] - sFy[0][ty][tx]); Un.mx -= dt * (sFy[1][ty + 1][tx] - sFy[1][ty][tx]);
       Un.my -= dt * (sFy[2][ty + 1][tx] - sFy[2][ty][tx]); Un.E -= dt * (sFy[3][ty + 1][tx] - sFy[3][ty][tx]);
-      const P4 cp = c2p(A, Uc);
-      const C4 xm2 = neigh(A, T, cp, x - 2, y), xm1 = neigh(A, T, cp, x - 1, y), xp1 = neigh(A, T, cp, x + 1, y), xp2 = neigh(A, T, cp, x + 2, y);
-      const C4 ym2 = neigh(A, T, cp, x, y - 2), ym1 = neigh(A, T, cp, x, y - 1), yp1 = neigh(A, T, cp, x, y + 1), yp2 = neigh(A, T, cp, x, y + 2);
+      const C4 wg = wall_ghost(A, c2p(A, Uc));
+      const C4 xm2 = neigh_sel(A, T, wg, x - 2, y), xm1 = neigh_sel(A, T, wg, x - 1, y), xp1 = neigh_sel(A, T, wg, x + 1, y), xp2 = neigh_sel(A, T, wg, x + 2, y);
+      const C4 ym2 = neigh_sel(A, T, wg, x, y - 2), ym1 = neigh_sel(A, T, wg, x, y - 1), yp1 = neigh_sel(A, T, wg, x, y + 1), yp2 = neigh_sel(A, T, wg, x, y + 2);
       const float i12 = 1.0f / 12.0f;
 #define D2(f) (((-xm2.f + 16.0f * xm1.f - 30.0f * Uc.f + 16.0f * xp1.f - xp2.f) * i12) + \
                ((-ym2.f + 16.0f * ym1.f - 30.0f * Uc.f + 16.0f * yp1.f - yp2.f) * i12))
