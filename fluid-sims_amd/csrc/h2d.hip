@@ -234,13 +234,13 @@ __device__ __forceinline__ C4 face(const Args &A, const Tile &T, const PredTile 
   const bool hasR = (xb < A.W) && (yb < A.H) && !T.masked(xb, yb);
   P4 L, R;
   if (hasL && hasR) {
-    L = Q.get(ax ? 3 : 1, xa, ya);
-    R = Q.get(ax ? 2 : 0, xb, yb);
+    L = Q.get(1, xa, ya);
+    R = Q.get(0, xb, yb);
   } else if (hasR) {
     L = c2p(A, neigh(A, T, c2p(A, T.cons(xb, yb)), xa, ya));
-    R = Q.get(ax ? 2 : 0, xb, yb);
+    R = Q.get(0, xb, yb);
   } else if (hasL) {
-    L = Q.get(ax ? 3 : 1, xa, ya);
+    L = Q.get(1, xa, ya);
     R = c2p(A, neigh(A, T, c2p(A, T.cons(xa, ya)), xb, yb));
   } else {
     return C4{0.f, 0.f, 0.f, 0.f};
@@ -258,9 +258,8 @@ __device__ __forceinline__ float cell_speed(const Args &A, C4 c) { // k_max_wave
 __global__ __launch_bounds__(NT) void k_step(const Args A) {
   __shared__ float sU[4][UH * UW];
   __shared__ uint8_t sM[UH * UW];
-  __shared__ float sQ[16 * PH * PW];
-  __shared__ float sFx[4][TY][TX + 1];
-  __shared__ float sFy[4][TY + 1][TX];
+  __shared__ float sQ[8 * PH * PW];     // predicted low / high face states of ONE axis at a time
+  __shared__ float sF[4][TY + 1][TX + 1];   // face fluxes of the axis in flight (x: [ty][tx], tx <= TX; y: [ty][tx], ty <= TY)
   __shared__ float sRed[NT / 64];
 
   const int tid = threadIdx.x, tx = tid & (TX - 1), ty = tid >> 5, lane = tid & 63, wave = tid >> 6;
@@ -297,43 +296,55 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
   const Tile T{sU[0], sU[1], sU[2], sU[3], sM, bx0 - 2, by0 - 2};
   PredTile Q{sQ, bx0 - 1, by0 - 1};
 
-  // ---- B: predicted face states for the tile + 1-cell ring
-  for (int t = tid; t < PH * PW; t += NT) {
-    const int py = t / PW, px = t - py * PW;
-    const int cx = bx0 - 1 + px, cy = by0 - 1 + py;
-    if (cx < 0 || cx >= A.W || cy < 0 || cy >= A.H) continue;
-    if (T.masked(cx, cy)) continue;
-    const P4 qc = c2p(A, T.cons(cx, cy));
-    const C4 wg = wall_ghost(A, qc);
-    P4 lo, hi;
-    predict_axis(A, T, qc, wg, cx, cy, 0, half, lo, hi);
-    Q.put(0, cx, cy, lo); Q.put(1, cx, cy, hi);
-    predict_axis(A, T, qc, wg, cx, cy, 1, half, lo, hi);
-    Q.put(2, cx, cy, lo); Q.put(3, cx, cy, hi);
-  }
-  __syncthreads();
-
-  // ---- C: face fluxes, each once
+  // ---- B/C, one axis at a time: predicted face states of tile + ring along the axis (8 floats per cell in LDS
+  //      instead of 16 -> 27 KB per workgroup, 5 workgroups per CU instead of 4), then that axis' face fluxes
   const bool row_ok = y < A.H, col_ok = x < A.W;
-  if (row_ok && x <= A.W) { // low-x face of (x,y): fx = x
-    C4 F = face(A, T, Q, x - 1, y, x, y, 0);
-    sFx[0][ty][tx] = F.r; sFx[1][ty][tx] = F.mx; sFx[2][ty][tx] = F.my; sFx[3][ty][tx] = F.E;
-  }
-  if (col_ok && y <= A.H) { // low-y face of (x,y): fy = y
-    C4 F = face(A, T, Q, x, y - 1, x, y, 1);
-    sFy[0][ty][tx] = F.r; sFy[1][ty][tx] = F.mx; sFy[2][ty][tx] = F.my; sFy[3][ty][tx] = F.E;
-  }
-  if (wave == NT / 64 - 1 && lane < TY + TX) { // far edges: 8 x-faces at column TX, 32 y-faces at row TY
-    const bool isx = lane < TY;
-    const int ey = isx ? lane : TY, ex = isx ? TX : lane - TY;
-    const int gx = bx0 + ex, gy = by0 + ey;
-    if (isx ? (gy < A.H && gx <= A.W) : (gx < A.W && gy <= A.H)) {
-      C4 F = isx ? face(A, T, Q, gx - 1, gy, gx, gy, 0) : face(A, T, Q, gx, gy - 1, gx, gy, 1);
-      if (isx) { sFx[0][ey][TX] = F.r; sFx[1][ey][TX] = F.mx; sFx[2][ey][TX] = F.my; sFx[3][ey][TX] = F.E; }
-      else { sFy[0][TY][ex] = F.r; sFy[1][TY][ex] = F.mx; sFy[2][TY][ex] = F.my; sFy[3][TY][ex] = F.E; }
+  C4 dFx{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ax = 0; ax < 2; ax++) {
+    for (int t = tid; t < PH * PW; t += NT) {
+      const int py = t / PW, px = t - py * PW;
+      const int cx = bx0 - 1 + px, cy = by0 - 1 + py;
+      if (cx < 0 || cx >= A.W || cy < 0 || cy >= A.H) continue;
+      if (T.masked(cx, cy)) continue;
+      const P4 qc = c2p(A, T.cons(cx, cy));
+      const C4 wg = wall_ghost(A, qc);
+      P4 lo, hi;
+      predict_axis(A, T, qc, wg, cx, cy, ax, half, lo, hi);
+      Q.put(0, cx, cy, lo); Q.put(1, cx, cy, hi);
+    }
+    __syncthreads();
+    if (ax == 0) {
+      if (row_ok && x <= A.W) { // low-x face of (x,y): fx = x
+        C4 F = face(A, T, Q, x - 1, y, x, y, 0);
+        sF[0][ty][tx] = F.r; sF[1][ty][tx] = F.mx; sF[2][ty][tx] = F.my; sF[3][ty][tx] = F.E;
+      }
+      if (wave == NT / 64 - 1 && lane < TY) { // far edge: 8 x-faces at column TX
+        const int gx = bx0 + TX, gy = by0 + lane;
+        if (gy < A.H && gx <= A.W) {
+          C4 F = face(A, T, Q, gx - 1, gy, gx, gy, 0);
+          sF[0][lane][TX] = F.r; sF[1][lane][TX] = F.mx; sF[2][lane][TX] = F.my; sF[3][lane][TX] = F.E;
+        }
+      }
+    } else {
+      if (col_ok && y <= A.H) { // low-y face of (x,y): fy = y
+        C4 F = face(A, T, Q, x, y - 1, x, y, 1);
+        sF[0][ty][tx] = F.r; sF[1][ty][tx] = F.mx; sF[2][ty][tx] = F.my; sF[3][ty][tx] = F.E;
+      }
+      if (wave == NT / 64 - 1 && lane < TX) { // far edge: 32 y-faces at row TY
+        const int gx = bx0 + lane, gy = by0 + TY;
+        if (gx < A.W && gy <= A.H) {
+          C4 F = face(A, T, Q, gx, gy - 1, gx, gy, 1);
+          sF[0][TY][lane] = F.r; sF[1][TY][lane] = F.mx; sF[2][TY][lane] = F.my; sF[3][TY][lane] = F.E;
+        }
+      }
+    }
+    __syncthreads();
+    if (ax == 0) { // the x flux difference goes to registers: the y faces reuse the same LDS (next barrier is in between)
+      dFx = C4{sF[0][ty][tx + 1] - sF[0][ty][tx], sF[1][ty][tx + 1] - sF[1][ty][tx], sF[2][ty][tx + 1] - sF[2][ty][tx],
+               sF[3][ty][tx + 1] - sF[3][ty][tx]};
     }
   }
-  __syncthreads();
 
   // ---- D: update + separable 4th-order diffusion + repairs, :1096-1175
   float smax = 0.f;
@@ -342,10 +353,9 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
     const C4 Uc = T.cons(x, y);
     C4 Un = Uc;
     if (!T.masked(x, y)) {
-      Un.r -= dt * (sFx[0][ty][tx + 1] - sFx[0][ty][tx]); Un.mx -= dt * (sFx[1][ty][tx + 1] - sFx[1][ty][tx]);
-      Un.my -= dt * (sFx[2][ty][tx + 1] - sFx[2][ty][tx]); Un.E -= dt * (sFx[3][ty][tx + 1] - sFx[3][ty][tx]);
-      Un.r -= dt * (sFy[0][ty + 1][tx] - sFy[0][ty][tx]); Un.mx -= dt * (sFy[1][ty + 1][tx] - sFy[1][ty][tx]);
-      Un.my -= dt * (sFy[2][ty + 1][tx] - sFy[2][ty][tx]); Un.E -= dt * (sFy[3][ty + 1][tx] - sFy[3][ty][tx]);
+      Un.r -= dt * dFx.r; Un.mx -= dt * dFx.mx; Un.my -= dt * dFx.my; Un.E -= dt * dFx.E;
+      Un.r -= dt * (sF[0][ty + 1][tx] - sF[0][ty][tx]); Un.mx -= dt * (sF[1][ty + 1][tx] - sF[1][ty][tx]);
+      Un.my -= dt * (sF[2][ty + 1][tx] - sF[2][ty][tx]); Un.E -= dt * (sF[3][ty + 1][tx] - sF[3][ty][tx]);
       const C4 wg = wall_ghost(A, c2p(A, Uc));
       const C4 xm2 = neigh_sel(A, T, wg, x - 2, y), xm1 = neigh_sel(A, T, wg, x - 1, y), xp1 = neigh_sel(A, T, wg, x + 1, y), xp2 = neigh_sel(A, T, wg, x + 2, y);
       const C4 ym2 = neigh_sel(A, T, wg, x, y - 2), ym1 = neigh_sel(A, T, wg, x, y - 1), yp1 = neigh_sel(A, T, wg, x, y + 1), yp2 = neigh_sel(A, T, wg, x, y + 2);
