@@ -144,7 +144,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
       sU[1][t] = A.muscl ? bb : A.u0 * fsinh(bb);
     }
     else {
-      const float hh = expf(A.in[0][gi]);
+      const float hh = __builtin_amdgcn_exp2f(A.in[0][gi] * 1.44269504088896341f);   // v_exp_f32: 1 ulp, the tolerance is 1e-5
       sU[0][t] = hh; sU[1][t] = A.in[1][gi]; sU[2][t] = A.in[2][gi]; sU[NS - 1][t] = __builtin_amdgcn_sqrtf(A.g * hh);
     }
   }
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
       red = fabsf(u) * A.invdx + fabsf(v) * ((A.ny > 1) ? A.invdy : 0.0f); // wavespeed_block_max, :337-361
     } else {
       const float own_h = sN[2][r];
-      A.out[0][gi] = logf(own_h);
+      A.out[0][gi] = __builtin_amdgcn_logf(own_h) * 0.69314718055994531f;          // v_log_f32
       A.out[1][gi] = u;
       A.out[NF - 1][gi] = v;
       const float c = __builtin_amdgcn_sqrtf(A.g * own_h);
