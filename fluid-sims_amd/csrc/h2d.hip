@@ -255,7 +255,9 @@ __device__ __forceinline__ float cell_speed(const Args &A, C4 c) { // k_max_wave
   return isfinite(v) ? v : 1e-12f;
 }
 
-__global__ __launch_bounds__(NT) void k_step(const Args A) {
+// (NT, 7): 22.5 KB of LDS allow 7 workgroups per CU; the kernel needs 73 VGPRs, one more than 7 waves/SIMD
+// allow — asking for 7 costs a single spilled register and buys the seventh wave (0.485 -> 0.474 ms)
+__global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
   __shared__ float sU[4][UH * UW];
   __shared__ uint8_t sM[UH * UW];
   __shared__ float sQ[8 * PH * PW];     // predicted low / high face states of ONE axis at a time
