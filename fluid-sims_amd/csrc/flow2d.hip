@@ -25,8 +25,13 @@
 namespace fl2 {
 
 constexpr int TX = 32, TY = 8, NT = TX * TY;
-constexpr int HB = 3;                               // tile halo (MUSCL: faces of the ring need +-2 more)
-constexpr int UW = TX + 2 * HB, UH = TY + 2 * HB;   // 38 x 14
+// tile halo: the ring needs its own faces (+1), MUSCL Burgers faces reach two cells further (+2); shallow water
+// and plain Burgers have no reconstruction, so halo 2 is enough there (432 staged cells instead of 532, and the
+// shallow-water LDS fits 8 workgroups per CU instead of 7).  MUSCL is a template parameter for that reason.
+template <int KIND, bool MUSCL> struct TileDims {
+  static constexpr int HB = (KIND == 0 && MUSCL) ? 3 : 2;
+  static constexpr int UW = TX + 2 * HB, UH = TY + 2 * HB;
+};
 constexpr int RW = TX + 2, RH = TY + 2;             // updated values: tile + ring 1
 enum { K_BURGERS = 0, K_SW = 1 };
 
@@ -68,18 +73,19 @@ __device__ __forceinline__ int wrap1(int i, int n) { i = i < 0 ? i + n : i; retu
 
 // Rusanov flux of the Burgers system through one face along `ax`, from the four phi values
 // (m1, c | p1, p2) of each component around it; flux_x_kernel / flux_y_kernel, :364-455
+template <bool MUSCL>
 __device__ __forceinline__ void burgers_face(const Args &A, float um1, float uc, float up1, float up2, float vm1, float vc,
                                              float vp1, float vp2, int ax, float &Fu, float &Fv) {
   float pUL = uc, pUR = up1, pVL = vc, pVR = vp1;
-  if (A.muscl) {
+  if (MUSCL) {
     pUL = uc + 0.5f * minmodf(uc - um1, up1 - uc);
     pUR = up1 - 0.5f * minmodf(up2 - up1, up1 - uc);
     pVL = vc + 0.5f * minmodf(vc - vm1, vp1 - vc);
     pVR = vp1 - 0.5f * minmodf(vp2 - vp1, vp1 - vc);
   }
   // without MUSCL the face states are the cell values, which the staging loop has already decoded
-  const float uL = A.muscl ? A.u0 * fsinh(pUL) : pUL, vL = A.muscl ? A.u0 * fsinh(pVL) : pVL;
-  const float uR = A.muscl ? A.u0 * fsinh(pUR) : pUR, vR = A.muscl ? A.u0 * fsinh(pVR) : pVR;
+  const float uL = MUSCL ? A.u0 * fsinh(pUL) : pUL, vL = MUSCL ? A.u0 * fsinh(pVL) : pVL;
+  const float uR = MUSCL ? A.u0 * fsinh(pUR) : pUR, vR = MUSCL ? A.u0 * fsinh(pVR) : pVR;
   if (ax == 0) {
     const float a = fmaxf(fabsf(uL), fabsf(uR));
     Fu = 0.5f * (0.5f * uL * uL + 0.5f * uR * uR) - 0.5f * a * (uR - uL);
@@ -110,9 +116,10 @@ __device__ __forceinline__ void sw_face(float g, float hL, float unL, float utL,
   Ft = left ? FLt : right ? FRt : Ht;
 }
 
-template <int KIND>
+template <int KIND, bool MUSCL>
 __global__ __launch_bounds__(NT) void k_step(const Args A) {
   constexpr int NF = (KIND == K_BURGERS) ? 2 : 3;
+  constexpr int HB = TileDims<KIND, MUSCL>::HB, UW = TileDims<KIND, MUSCL>::UW, UH = TileDims<KIND, MUSCL>::UH;
   constexpr int NS = (KIND == K_BURGERS) ? 2 : 4;
   __shared__ float sU[NS][UH * UW];       // Burgers: phi_u, phi_v ; SW: h, u, v, sqrt(g h)
   __shared__ float sN[3][RH * RW];        // updated u, v (and h for shallow water) on tile + ring
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
     const size_t gi = (size_t)(A.ny >= TY + HB ? wrap1(gy, A.ny) : wrapi(gy, A.ny)) * A.nx + (A.nx >= TX + HB ? wrap1(gx, A.nx) : wrapi(gx, A.nx));
     if (KIND == K_BURGERS) { // MUSCL limits the encoded phi, so phi is staged raw; otherwise decode once here
       const float a = A.in[0][gi], bb = A.in[1][gi];
-      sU[0][t] = A.muscl ? a : A.u0 * fsinh(a);
-      sU[1][t] = A.muscl ? bb : A.u0 * fsinh(bb);
+      sU[0][t] = MUSCL ? a : A.u0 * fsinh(a);
+      sU[1][t] = MUSCL ? bb : A.u0 * fsinh(bb);
     }
     else {
       const float hh = __builtin_amdgcn_exp2f(A.in[0][gi] * 1.44269504088896341f);   // v_exp_f32: 1 ulp, the tolerance is 1e-5
@@ -156,7 +163,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
   // (Plain Burgers keeps the cell-owns-its-faces form below: its faces are a dozen flops on already decoded
   // values, cheaper than a trip through LDS and a barrier — 92 vs 87 Gcell/s.)
   constexpr int NFX = RH * (RW + 1), NFY = (RH + 1) * RW;
-  const bool own_faces = (KIND == K_BURGERS) && !A.muscl;
+  const bool own_faces = (KIND == K_BURGERS) && !MUSCL;
   for (int f = tid; f < (own_faces ? 0 : NFX + NFY); f += NT) {
     const bool isx = f < NFX;
     const int g = isx ? f : f - NFX;
@@ -168,7 +175,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
       const float *pu = sU[0], *pv = sU[1];
       float Fu = 0.f, Fv = 0.f;
       if (isx || !A.oneD)
-        burgers_face(A, pu[c - 2 * st], pu[c - st], pu[c], pu[c + st], pv[c - 2 * st], pv[c - st], pv[c], pv[c + st], isx ? 0 : 1,
+        burgers_face<MUSCL>(A, pu[c - 2 * st], pu[c - st], pu[c], pu[c + st], pv[c - 2 * st], pv[c - st], pv[c], pv[c + st], isx ? 0 : 1,
                      Fu, Fv);
       (isx ? sFx[0] : sFy[0])[g] = Fu;
       (isx ? sFx[1] : sFy[1])[g] = Fv;
@@ -192,14 +199,14 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
     if (KIND == K_BURGERS) {
       const float *pu = sU[0], *pv = sU[1];
       const float invdy = A.oneD ? 0.0f : A.invdy;
-      const float uc0 = A.muscl ? A.u0 * fsinh(pu[c]) : pu[c], vc0 = A.muscl ? A.u0 * fsinh(pv[c]) : pv[c];
+      const float uc0 = MUSCL ? A.u0 * fsinh(pu[c]) : pu[c], vc0 = MUSCL ? A.u0 * fsinh(pv[c]) : pv[c];
       float Fu_lo, Fv_lo, Fu_hi, Fv_hi, Gu_lo = 0.f, Gv_lo = 0.f, Gu_hi = 0.f, Gv_hi = 0.f;
       if (own_faces) {
-        burgers_face(A, pu[c - 2], pu[c - 1], pu[c], pu[c + 1], pv[c - 2], pv[c - 1], pv[c], pv[c + 1], 0, Fu_lo, Fv_lo);
-        burgers_face(A, pu[c - 1], pu[c], pu[c + 1], pu[c + 2], pv[c - 1], pv[c], pv[c + 1], pv[c + 2], 0, Fu_hi, Fv_hi);
+        burgers_face<MUSCL>(A, pu[c - 2], pu[c - 1], pu[c], pu[c + 1], pv[c - 2], pv[c - 1], pv[c], pv[c + 1], 0, Fu_lo, Fv_lo);
+        burgers_face<MUSCL>(A, pu[c - 1], pu[c], pu[c + 1], pu[c + 2], pv[c - 1], pv[c], pv[c + 1], pv[c + 2], 0, Fu_hi, Fv_hi);
         if (!A.oneD) {
-          burgers_face(A, pu[c - 2 * UW], pu[c - UW], pu[c], pu[c + UW], pv[c - 2 * UW], pv[c - UW], pv[c], pv[c + UW], 1, Gu_lo, Gv_lo);
-          burgers_face(A, pu[c - UW], pu[c], pu[c + UW], pu[c + 2 * UW], pv[c - UW], pv[c], pv[c + UW], pv[c + 2 * UW], 1, Gu_hi, Gv_hi);
+          burgers_face<MUSCL>(A, pu[c - 2 * UW], pu[c - UW], pu[c], pu[c + UW], pv[c - 2 * UW], pv[c - UW], pv[c], pv[c + UW], 1, Gu_lo, Gv_lo);
+          burgers_face<MUSCL>(A, pu[c - UW], pu[c], pu[c + UW], pu[c + 2 * UW], pv[c - UW], pv[c], pv[c + UW], pv[c + 2 * UW], 1, Gu_hi, Gv_hi);
         }
       } else {
         Fu_lo = sFx[0][fxi]; Fu_hi = sFx[0][fxi + 1]; Fv_lo = sFx[1][fxi]; Fv_hi = sFx[1][fxi + 1];
@@ -467,8 +474,9 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
   hipLaunchKernelGGL(fl2::k_prepare, dim3(1), dim3(1), 0, h->stream, h->st, h->cur, A.dt_try, A.CFL * A.cfl_len, dt_explicit);
   TAU_LAUNCH_CHECK("fl2::k_prepare");
   const unsigned nb = (unsigned)(A.ntx * A.nty);
-  if (h->kind == 0) hipLaunchKernelGGL(fl2::k_step<fl2::K_BURGERS>, dim3(nb), dim3(fl2::NT), 0, h->stream, A);
-  else hipLaunchKernelGGL(fl2::k_step<fl2::K_SW>, dim3(nb), dim3(fl2::NT), 0, h->stream, A);
+  if (h->kind == 0 && A.muscl) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, true>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
+  else if (h->kind == 0) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
+  else hipLaunchKernelGGL((fl2::k_step<fl2::K_SW, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   TAU_LAUNCH_CHECK("fl2::k_step");
   h->cur ^= 1;
   const int K = (h->kind == 0) ? (P.visc_substeps > 0 ? P.visc_substeps : 1) : 1;
