@@ -1105,7 +1105,11 @@ extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *st
     const long tiles = (long)A.ntx * A.nty;
     zc = (int)((long)nplanes * tiles / 32768);
     if (zc < 8) {
-      if (tiles >= 768) zc = 8;                        // wide planes fill the chip by themselves: keep chunks long
+      if (tiles >= 768) {                              // wide planes fill the chip by themselves (a Z-slab of a big grid):
+        const long nzc = (nplanes * tiles + 16384) / 32768;   // as few chunks as keep ~32k workgroups' worth of work
+        zc = (int)((nplanes + (nzc > 0 ? nzc : 1) - 1) / (nzc > 0 ? nzc : 1));
+        zc = zc < 8 ? 8 : zc;
+      }
       else { zc = (int)((long)nplanes * tiles / 2048); zc = zc < 2 ? 2 : (zc > 8 ? 8 : zc); }
     }
     zc = zc > 32 ? 32 : zc;
