@@ -71,6 +71,7 @@ struct Args {
   int nx, ny, nz;            // global
   int nzl, z0;               // local planes, global index of local plane 0
   int zl_lo, zl_hi;          // local plane range to update
+  int zl_lo2, zl_hi2, nzc1;  // optional second range in the same launch (chunks >= nzc1 belong to it); nzc1 = nzc if unused
   int zchunk;                // planes marched by one workgroup
   int ntx, nty, nzc;         // tiles in x, y; chunks in z
   float dx, dy, dz, inv_dx, inv_dy, inv_dz;
@@ -407,8 +408,9 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
   const int by = (int)(b % (unsigned)A.nty);
   const int bz = (int)(b / (unsigned)A.nty);
   const int bx0 = bx * TX, by0 = by * TY;
-  const int zc_lo = A.zl_lo + bz * A.zchunk;
-  const int zc_hi = min(zc_lo + A.zchunk, A.zl_hi);
+  const bool second = bz >= A.nzc1;                    // wave-uniform: two disjoint plane ranges can share a launch
+  const int zc_lo = second ? A.zl_lo2 + (bz - A.nzc1) * A.zchunk : A.zl_lo + bz * A.zchunk;
+  const int zc_hi = min(zc_lo + A.zchunk, second ? A.zl_hi2 : A.zl_hi);
 
   const int x = bx0 + tx, y = by0 + ty;
   const bool in_xy = (x < A.nx) && (y < A.ny);
@@ -1090,12 +1092,15 @@ extern "C" int tau3d_fill_halo_periodic_async(tau3d_t *h) {
   return 0;
 }
 
-extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *stream) {
+// steps planes [zl_lo, zl_hi) and, if zl_lo2 < zl_hi2, also [zl_lo2, zl_hi2) in the SAME launch
+static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2, void *stream) {
   if (zl_lo < 0 || zl_hi > h->nzl || zl_lo >= zl_hi) return tau::fail("tau3d_step_range: bad plane range [%d,%d)", zl_lo, zl_hi);
+  const bool two = zl_lo2 < zl_hi2;
+  if (two && (zl_lo2 < zl_hi || zl_hi2 > h->nzl)) return tau::fail("tau3d_step_edges: bad second range [%d,%d)", zl_lo2, zl_hi2);
   h3d::Args A = h->base;
   for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
-  int nplanes = zl_hi - zl_lo;
+  int nplanes = zl_hi - zl_lo;           // chunking is chosen for the first range; a second range has the same length
   // Planes marched by one workgroup.  Large grids: enough workgroups (~32k) to load-balance 256 CUs x 3 resident
   // groups, chunks of 8..32 planes (a chunk re-decodes 4 warm-up planes, so longer is cheaper).  Small grids are
   // LATENCY bound instead — a 64^3 launch is 128 workgroups of 13 serial plane iterations with chunks of 8 — so
@@ -1115,7 +1120,9 @@ extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *st
     zc = zc > 32 ? 32 : zc;
   }
   A.zchunk = zc < nplanes ? zc : nplanes;
-  A.nzc = (nplanes + A.zchunk - 1) / A.zchunk;
+  A.nzc1 = (nplanes + A.zchunk - 1) / A.zchunk;
+  A.zl_lo2 = zl_lo2; A.zl_hi2 = zl_hi2;
+  A.nzc = A.nzc1 + (two ? (zl_hi2 - zl_lo2 + A.zchunk - 1) / A.zchunk : 0);
   unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const bool tm = h->timing && h->n_ev < 4096;
@@ -1125,9 +1132,17 @@ extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *st
   if (tm) {
     TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
     h->n_ev++;
-    h->ev_cells += (double)nplanes * (double)h->plane_n;
+    h->ev_cells += (double)(nplanes + (two ? zl_hi2 - zl_lo2 : 0)) * (double)h->plane_n;
   }
   return 0;
+}
+extern "C" int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *stream) {
+  return step_ranges(h, zl_lo, zl_hi, 0, 0, stream);
+}
+extern "C" int tau3d_step_edges_async(tau3d_t *h, int depth, void *stream) {
+  if (depth < h3d::HALO) return tau::fail("tau3d_step_edges: depth %d is less than the %d halo planes", depth, h3d::HALO);
+  if (2 * depth >= h->nzl) return step_ranges(h, 0, h->nzl, 0, 0, stream);
+  return step_ranges(h, 0, depth, h->nzl - depth, h->nzl, stream);
 }
 
 extern "C" int tau3d_clock_begin_async(tau3d_t *h) {

@@ -85,6 +85,9 @@ class EngineSlabBackend:
     def step_range(self, lo, hi):
         self.h.step_range_async(lo, hi)
 
+    def step_edges(self, depth):
+        self.h.step_edges_async(depth)
+
     def clock_end(self):
         self.h.clock_end_async()
 
@@ -147,8 +150,11 @@ class SlabRing:
             # a 64-plane slab costs 13 + 13 + 58 iterations instead of 8 + 8 + 98 — the same ~76 % duty as the
             # single-GPU launch — and the interior that hides the exchange is still ~0.6 ms at 512^2 x 48.
             E = self.edge
-            b.step_range(0, E)
-            b.step_range(nzl - E, nzl)
+            if hasattr(b, "step_edges"):
+                b.step_edges(E)                        # both edges in one launch (engine backend)
+            else:
+                b.step_range(0, E)
+                b.step_range(nzl - E, nzl)
             b.pack(1)                                  # next state's boundary planes
             self._pending = self._post_exchange()      # async; lands at the start of the next step
             if nzl > 2 * E:

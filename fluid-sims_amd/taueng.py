@@ -132,6 +132,7 @@ def load():
         "tau3d_step_explicit": ([vp, f32, f32, C.POINTER(f32)], i32),
         "tau3d_clock_begin_async": ([vp], i32),
         "tau3d_step_range_async": ([vp, i32, i32, vp], i32),
+        "tau3d_step_edges_async": ([vp, i32, vp], i32),
         "tau3d_clock_end_async": ([vp], i32),
         "tau3d_fill_halo_periodic_async": ([vp], i32),
         "tau3d_halo_send_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
@@ -341,6 +342,9 @@ class Tau3D:
 
     def step_range_async(self, lo, hi, stream=None):
         _ck(self._L.tau3d_step_range_async(self._h, lo, hi, stream))
+
+    def step_edges_async(self, depth, stream=None):
+        _ck(self._L.tau3d_step_edges_async(self._h, depth, stream))
 
     def clock_end_async(self):
         _ck(self._L.tau3d_clock_end_async(self._h))

@@ -85,14 +85,17 @@ int tau3d_step_explicit(tau3d_t *h, float dt, float inflow_gain, float *maxs);
 
 /* ---- multi-GPU pieces (no reference counterpart: SURVEY §8e).  One step on rank r is
  *   tau3d_clock_begin_async            t*=exp(d_tau), dt, gain; zero the max word
- *   tau3d_step_range_async(edges)      planes [0,3) and [nzl-3,nzl) — need the halos
+ *   tau3d_step_edges_async(E)          planes [0,E) and [nzl-E,nzl), E >= 3, one launch — need the halos
  *   <caller: exchange tau3d_halo_send_ptr -> neighbour's tau3d_halo_recv_ptr>
- *   tau3d_step_range_async(interior)   planes [3,nzl-3)
+ *   tau3d_step_range_async(interior)   planes [E,nzl-E)
  *   <caller: all-reduce(max) the word at tau3d_max_ptr>
  *   tau3d_clock_end_async              d_tau controller, swap
  * The caller (bench.py / the driver) orders these on streams it owns. */
 int tau3d_clock_begin_async(tau3d_t *h);
 int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *stream);
+/* both Z-slab edges, planes [0, depth) and [nzl-depth, nzl), in ONE launch (twice the workgroups of an edge launch:
+ * the 768 resident slots of the chip fill better); the whole slab if 2*depth >= nzl.  depth >= 3. */
+int tau3d_step_edges_async(tau3d_t *h, int depth, void *stream);
 int tau3d_clock_end_async(tau3d_t *h);
 /* fill own halos from own interior (periodic single domain) */
 int tau3d_fill_halo_periodic_async(tau3d_t *h);

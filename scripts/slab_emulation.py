@@ -15,7 +15,7 @@ for world in (8, 4, 2):
     def step(k):
         for _ in range(k):
             be.clock_begin(); be.unpack(0)
-            be.step_range(0, E); be.step_range(nzl - E, nzl); be.pack(1)
+            be.step_edges(E); be.pack(1)
             be.step_range(E, nzl - E)
             be.clock_end()
     step(5); be.sync()
