@@ -166,6 +166,93 @@ __global__ __launch_bounds__(64 * WAVES) void k_march(const Args A) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Several steps per pass (temporal fusion) for the HBM-bound kinds (Gray-Scott, the shallow-water viscosity pass).
+// One step is HBM bound at 16 B per cell update; the arithmetic leaves half the VALU idle.  Here a wave carries
+// several time levels down its strip — for two levels: it loads row r of level t, forms
+// row r-1 of level t+1 from the three t-rows it holds, then row r-2 of level t+2 from the three (t+1)-rows it holds,
+// and only level t+2 is written — 8.6 B per cell update instead of 16 (reads x1.16 for the halos, one write per
+// two updates).  Every level-(t+1) value is produced by the same cell<> arithmetic as a stand-alone step, so the
+// result is bit-identical to two single steps.
+//   x: a wave loads 64 lanes x 4 cells = 256 columns but owns only the inner 248 (lanes 1..62): the outer lanes
+//      are the 2-cell halo of the two steps (their level-t+1 edge cells are garbage that never reaches an owned
+//      cell), so there is no cross-wave exchange and every load / store is an aligned float4;
+//   y: a chunk of R output rows reads R + 4 rows and forms R + 2 intermediate rows (R = 32: +12 % / +6 %).
+constexpr int GS2_COLS = 248;   // owned columns per wave
+struct Lvl { float4 a, b; };
+
+template <int KIND>
+__device__ __forceinline__ void row_step(const Args &A, const Lvl &up, const Lvl &cu, const Lvl &dn, Lvl &o) {
+  // neighbours across lanes; the wave's outermost cells get their own value (never consumed by an owned cell)
+  float al = __shfl_up(cu.a.w, 1, 64), ar = __shfl_down(cu.a.x, 1, 64);
+  float bl = __shfl_up(cu.b.w, 1, 64), br = __shfl_down(cu.b.x, 1, 64);
+  cell<KIND>(A, cu.a.x, al, cu.a.y, up.a.x, dn.a.x, cu.b.x, bl, cu.b.y, up.b.x, dn.b.x, o.a.x, o.b.x);
+  cell<KIND>(A, cu.a.y, cu.a.x, cu.a.z, up.a.y, dn.a.y, cu.b.y, cu.b.x, cu.b.z, up.b.y, dn.b.y, o.a.y, o.b.y);
+  cell<KIND>(A, cu.a.z, cu.a.y, cu.a.w, up.a.z, dn.a.z, cu.b.z, cu.b.y, cu.b.w, up.b.z, dn.b.z, o.a.z, o.b.z);
+  cell<KIND>(A, cu.a.w, cu.a.z, ar, up.a.w, dn.a.w, cu.b.w, cu.b.z, br, up.b.w, dn.b.w, o.a.w, o.b.w);
+}
+
+// K time levels per pass.  Stage s holds three consecutive rows of level t+s; every trip of the march loads one
+// row of level t and lets each stage produce one row of the next level from the three rows of the stage below.
+// The march starts K rows early with zeroed stages: whatever the upper stages compute before real data reaches
+// them is overwritten 2 trips later and never stored.
+template <int KIND, int K>
+__global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A) {
+  static_assert(KIND == K_GS || KIND == K_SW, "the Burgers pass re-encodes between levels and is VALU bound already");
+  static_assert(K >= 2 && K <= 4, "a 4-cell halo lane covers at most 4 levels");
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * WAVES + (threadIdx.x >> 6);
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)A.nstrips);
+  const int chunk = (int)(wid / (unsigned)A.nstrips);
+  const int xc = strip * GS2_COLS - 4 + 4 * lane;                 // first of this lane's four columns (may lie outside)
+  int xw = xc;                                                     // periodic wrap; nx % 4 == 0 keeps float4 alignment
+  if (xw < 0) xw += A.nx;
+  if (xw >= A.nx) xw -= A.nx;
+  if (xw >= A.nx) xw -= A.nx;                                      // (a wave reaches up to 252 columns past a small nx)
+  const bool owner = lane >= 1 && lane <= 62 && xc < A.nx && xc < (strip + 1) * GS2_COLS;
+  const int j0 = chunk * A.rows, j1 = min(j0 + A.rows, A.ny);
+
+  auto load = [&](int j, Lvl &r) {
+    int jw = j;
+    if (jw < 0) jw += A.ny;
+    if (jw >= A.ny) jw -= A.ny;
+    const size_t base = (size_t)jw * A.nx + xw;
+    r.a = *reinterpret_cast<const float4 *>(A.a + base);
+    r.b = *reinterpret_cast<const float4 *>(A.b + base);
+  };
+
+  const Lvl zero{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  Lvl st[K][3];            // st[s][0..2] = rows (r-2-s, r-1-s, r-s) of level t+s, r = newest level-t row
+#pragma unroll
+  for (int s = 0; s < K; s++) st[s][0] = st[s][1] = st[s][2] = zero;
+  Lvl nxt;
+  load(j0 - K, st[0][1]);
+  load(j0 - K + 1, st[0][2]);
+  load(j0 - K + 2, nxt);
+  // trip r: newest level-t row is r; stage s then holds level t+s rows up to r-s; the output row is r-K
+  for (int r = j0 - K + 2; r < j1 + K; r++) {
+    st[0][0] = st[0][1]; st[0][1] = st[0][2]; st[0][2] = nxt;
+    if (r + 1 < j1 + K) load(r + 1, nxt);                          // prefetch
+    Lvl out;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      Lvl o;
+      row_step<KIND>(A, st[s][0], st[s][1], st[s][2], o);          // level t+s+1, row r-1-s
+      if (s + 1 < K) { st[s + 1][0] = st[s + 1][1]; st[s + 1][1] = st[s + 1][2]; st[s + 1][2] = o; }
+      else out = o;
+    }
+    const int j = r - K;                                           // row of level t+K just produced
+    if (owner && j >= j0) {
+      const size_t off = (size_t)j * A.nx + xc;
+      typedef float v4f __attribute__((ext_vector_type(4)));
+      __builtin_nontemporal_store(v4f{out.a.x, out.a.y, out.a.z, out.a.w}, reinterpret_cast<v4f *>(A.oa + off));
+      __builtin_nontemporal_store(v4f{out.b.x, out.b.y, out.b.z, out.b.w}, reinterpret_cast<v4f *>(A.ob + off));
+    }
+  }
+}
+
 // any nx (not a multiple of 4): one thread per cell, wraps on index compare (no %)
 template <int KIND>
 __global__ __launch_bounds__(256) void k_simple(const Args A) {
@@ -251,6 +338,41 @@ static int pair_download(Pair *h, float *a, float *b) {
   return 0;
 }
 
+// n steps of an HBM-bound kind: passes of up to `kmax` fused time levels, the remainder as single steps.
+// TAU_ST2_FUSE=0 disables, TAU_ST2_LEVELS=2..4 (default 3), TAU_ST2_FROWS = output rows per wave (default 32).
+template <int KIND>
+static int run_steps(Pair *pr, Args A, int nsteps) {
+  static const bool fuse_env = !(getenv("TAU_ST2_FUSE") && atoi(getenv("TAU_ST2_FUSE")) == 0);
+  static const int frows = getenv("TAU_ST2_FROWS") ? atoi(getenv("TAU_ST2_FROWS")) : 32;
+  static const int kmax = getenv("TAU_ST2_LEVELS") ? atoi(getenv("TAU_ST2_LEVELS")) : 3;
+  const bool fuse = fuse_env && kmax >= 2 && kmax <= 4 && (A.nx & 3) == 0 && A.nx >= 256 && A.ny >= 8;
+  int s = 0;
+  while (s < nsteps) {
+    A.a = pr->buf[pr->cur][0]; A.b = pr->buf[pr->cur][1];
+    A.oa = pr->buf[pr->cur ^ 1][0]; A.ob = pr->buf[pr->cur ^ 1][1];
+    const int left = nsteps - s;
+    const int K = !fuse ? 1 : (left >= kmax ? kmax : (left >= 2 ? left : 1));
+    if (K >= 2) {
+      Args B = A;
+      B.rows = frows > 0 ? frows : 32;
+      B.nstrips = (B.nx + GS2_COLS - 1) / GS2_COLS;
+      B.nchunks = (B.ny + B.rows - 1) / B.rows;
+      const unsigned nwork = (unsigned)(B.nstrips * B.nchunks), nb = (nwork + WAVES - 1) / WAVES;
+      if (K == 2) hipLaunchKernelGGL((k_fused<KIND, 2>), dim3(nb), dim3(64 * WAVES), 0, pr->stream, B);
+      else if (K == 3) hipLaunchKernelGGL((k_fused<KIND, 3>), dim3(nb), dim3(64 * WAVES), 0, pr->stream, B);
+      else hipLaunchKernelGGL((k_fused<KIND, 4>), dim3(nb), dim3(64 * WAVES), 0, pr->stream, B);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess) return tau::fail("st2::k_fused launch: %s", hipGetErrorString(e));
+      s += K;
+    } else {
+      if (launch<KIND>(A, pr->stream)) return 1;
+      s += 1;
+    }
+    pr->cur ^= 1; // one pointer swap per pass: a fused pass leaves level t+K in the other buffer
+  }
+  return 0;
+}
+
 } // namespace st2
 
 int tau::st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,
@@ -317,13 +439,7 @@ extern "C" int taugs_step_async(taugs_t *h, int nsteps) {
   st2::Args A{};
   A.nx = h->p.nx; A.ny = h->p.ny;
   A.dx2 = h->p.dx * h->p.dx; A.dt = h->p.dt; A.Du = h->p.Du; A.Dv = h->p.Dv; A.feed = h->p.feed; A.kill = h->p.kill;
-  for (int s = 0; s < nsteps; s++) {
-    A.a = h->pr.buf[h->pr.cur][0]; A.b = h->pr.buf[h->pr.cur][1];
-    A.oa = h->pr.buf[h->pr.cur ^ 1][0]; A.ob = h->pr.buf[h->pr.cur ^ 1][1];
-    if (st2::launch<st2::K_GS>(A, h->pr.stream)) return 1;
-    h->pr.cur ^= 1; // std::swap, :327-328
-  }
-  return 0;
+  return st2::run_steps<st2::K_GS>(&h->pr, A, nsteps);   // std::swap per pass, :327-328
 }
 extern "C" int taugs_sync(taugs_t *h) {
   TAU_HIP(hipSetDevice(h->pr.device));
@@ -370,11 +486,11 @@ extern "C" int taulap_step_async(taulap_t *h, int npasses) {
   A.invdy2 = (h->kind == 0 && h->oneD) ? 0.0f : 1.0f / (h->p.dy * h->p.dy);
   A.nudt = h->p.nu * h->p.dt;
   A.u0 = h->p.u0; A.inv_u0 = 1.0f / h->p.u0;
+  if (h->kind != 0) return st2::run_steps<st2::K_SW>(&h->pr, A, npasses);
   for (int s = 0; s < npasses; s++) {
     A.a = h->pr.buf[h->pr.cur][0]; A.b = h->pr.buf[h->pr.cur][1];
     A.oa = h->pr.buf[h->pr.cur ^ 1][0]; A.ob = h->pr.buf[h->pr.cur ^ 1][1];
-    int rc = (h->kind == 0) ? st2::launch<st2::K_BURGERS>(A, h->pr.stream) : st2::launch<st2::K_SW>(A, h->pr.stream);
-    if (rc) return 1;
+    if (st2::launch<st2::K_BURGERS>(A, h->pr.stream)) return 1;
     h->pr.cur ^= 1;
   }
   return 0;
