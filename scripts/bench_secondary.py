@@ -46,8 +46,8 @@ def main():
     g = f.GrayScott(n, n)
     g.init_pattern(1337)
     r, ms = timed(g.step_async, g.sync, n * n, int(400 * k), 20)
-    fused = {"levels_per_pass": 3, "hbm_bytes_per_update_moved": 5.9,
-             "note": "3 time levels per pass (temporal fusion): 16 B is the single-step algorithmic figure, the pass moves ~5.9 B per update"}
+    fused = {"levels_per_pass": 4, "hbm_bytes_per_update_moved": 4.6,
+             "note": "4 time levels per pass (temporal fusion): 16 B is the single-step algorithmic figure, the pass moves ~4.6 B per update"}
     line(f"tau_gray_scott {n}^2", "cell-updates", r, ms, 16, "valu (hbm for a single step)", fused)
     g.close()
     rng = np.random.default_rng(1)

@@ -41,9 +41,10 @@ def test_gray_scott_reference_checkvalue(eng):
     g.close()
 
 
-def test_gray_scott_nondefault_params(eng, oracle_built):
+@pytest.mark.parametrize("dx", [0.7, 0.5, 2.0, 1.0])   # dx^2 a power of two -> exact-reciprocal path, else IEEE divide
+def test_gray_scott_nondefault_params(eng, oracle_built, dx):
     o = oracle_built.Oracle2D()
-    kw = dict(dx=0.7, dt=0.25, Du=0.16, Dv=0.08, feed=0.0367, kill=0.0649)
+    kw = dict(dx=dx, dt=0.25 * dx * dx, Du=0.16, Dv=0.08, feed=0.0367, kill=0.0649)
     p = o.gs_params(512, 200, **kw)
     u0, v0 = o.gs_init(512, 200, 42)
     g = eng.GrayScott(512, 200, **kw)
