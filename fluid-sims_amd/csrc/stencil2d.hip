@@ -215,15 +215,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A) {
   const int xc = strip * GS2_COLS - 4 + 4 * lane;                 // first of this lane's four columns (may lie outside)
   int xw = xc;                                                     // periodic wrap; nx % 4 == 0 keeps float4 alignment
   if (xw < 0) xw += A.nx;
-  if (xw >= A.nx) xw -= A.nx;
-  if (xw >= A.nx) xw -= A.nx;                                      // (a wave reaches up to 252 columns past a small nx)
+  while (xw < 0) xw += A.nx;                                       // small grids: a wave reaches 252 columns past nx,
+  while (xw >= A.nx) xw -= A.nx;                                   // lanes beyond it are duplicates that own nothing
   const bool owner = lane >= 1 && lane <= 62 && xc < A.nx && xc < (strip + 1) * GS2_COLS;
   const int j0 = chunk * A.rows, j1 = min(j0 + A.rows, A.ny);
 
   auto load = [&](int j, Lvl &r) {
     int jw = j;
-    if (jw < 0) jw += A.ny;
-    if (jw >= A.ny) jw -= A.ny;
+    while (jw < 0) jw += A.ny;                                     // (one trip on any grid taller than K rows)
+    while (jw >= A.ny) jw -= A.ny;
     const size_t base = (size_t)jw * A.nx + xw;
     r.a = *reinterpret_cast<const float4 *>(A.a + base);
     r.b = *reinterpret_cast<const float4 *>(A.b + base);
@@ -351,7 +351,7 @@ static int run_steps(Pair *pr, Args A, int nsteps) {
   static const bool fuse_env = !(getenv("TAU_ST2_FUSE") && atoi(getenv("TAU_ST2_FUSE")) == 0);
   static const int frows = getenv("TAU_ST2_FROWS") ? atoi(getenv("TAU_ST2_FROWS")) : 32;
   static const int kmax = getenv("TAU_ST2_LEVELS") ? atoi(getenv("TAU_ST2_LEVELS")) : 4;
-  const bool fuse = fuse_env && kmax >= 2 && kmax <= 4 && (A.nx & 3) == 0 && A.nx >= 256 && A.ny >= 8;
+  const bool fuse = fuse_env && kmax >= 2 && kmax <= 4 && (A.nx & 3) == 0 && A.nx >= 8 && A.ny >= 2;
   int s = 0;
   while (s < nsteps) {
     A.a = pr->buf[pr->cur][0]; A.b = pr->buf[pr->cur][1];
@@ -360,8 +360,14 @@ static int run_steps(Pair *pr, Args A, int nsteps) {
     const int K = !fuse ? 1 : (left >= kmax ? kmax : (left >= 2 ? left : 1));
     if (K >= 2) {
       Args B = A;
-      B.rows = frows > 0 ? frows : 32;
       B.nstrips = (B.nx + GS2_COLS - 1) / GS2_COLS;
+      // 32 output rows per wave on big grids (the 2K halo rows are re-read and re-computed); small grids are latency
+      // bound and want many short waves instead: at least ~2 k waves, down to 4 rows each
+      B.rows = frows > 0 ? frows : 32;
+      if (frows <= 0 || !getenv("TAU_ST2_FROWS")) {
+        long r = (long)B.ny * B.nstrips / 2048;
+        B.rows = r >= 32 ? 32 : (r < 4 ? 4 : (int)r);
+      }
       B.nchunks = (B.ny + B.rows - 1) / B.rows;
       const unsigned nwork = (unsigned)(B.nstrips * B.nchunks), nb = (nwork + WAVES - 1) / WAVES;
       if (K == 2) hipLaunchKernelGGL((k_fused<KIND, 2>), dim3(nb), dim3(64 * WAVES), 0, pr->stream, B);

@@ -13,7 +13,9 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_che
                                          (130, 70, 7), (67, 33, 5), (4, 2, 3), (2048, 2048, 3),
                                          # the fused two-steps-per-pass kernel (nx >= 256, nx % 4 == 0): one owned strip is 248
                                          # columns, chunks are 32 rows; exact strip multiples, a one-lane last strip, minimal ny
-                                         (256, 8, 2), (496, 40, 4), (744, 9, 6), (252 + 248, 33, 5), (8192, 40, 2)])
+                                         (256, 8, 2), (496, 40, 4), (744, 9, 6), (252 + 248, 33, 5), (8192, 40, 2),
+                                         # small grids: the wave wraps around the row several times, rows wrap several times
+                                         (8, 2, 9), (12, 3, 8), (128, 128, 12), (64, 5, 7), (200, 2, 4)])
 def test_gray_scott_bit_exact(eng, oracle_built, nx, ny, steps):
     o = oracle_built.Oracle2D()
     p = o.gs_params(nx, ny)
