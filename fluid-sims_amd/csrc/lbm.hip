@@ -21,6 +21,7 @@
 #include "../../include/taueng.h"
 #include "tau_common.h"
 #include <cmath>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct Args {
   float *fout;
   const uint8_t *solid;
   int nx, ny, nbx;          // nbx = workgroups per row
+  int nstrips, nchunks, rows; // fused kernel: strips of 64 - 2K owned columns, chunks of `rows` output rows
   size_t cells;
   float omega, drive;
 };
@@ -80,6 +82,135 @@ __global__ __launch_bounds__(256) void k_collide_stream(const Args A) {
     const bool blocked = (EY[q] != 0 && (nj < 0 || nj >= A.ny)) || (q != 0 && A.solid[(nj < 0 || nj >= A.ny) ? p : np]);
     if (blocked) A.fout[OPP[q] * A.cells + p] = post;
     else A.fout[q * A.cells + np] = post;
+  }
+}
+
+// -------------------------------------------------------------------------------------------------
+// K steps per pass (temporal fusion, as st2::k_fused for the stencils): 72 B per update is the single-step floor and
+// leaves 60 % of the VALU idle.  The push scheme is restated as a PULL so that a level can be assembled row by row
+// from the post-collision rows of the level below:
+//     out_q(n) = post_q(n - e_q)        if n - e_q is inside the y range and neither it nor n is solid
+//              = post_opp(q)(n)         otherwise          (post = f for a solid cell: it reflects in place)
+// which is the same single-writer assignment the push makes (a blocked push IS the second line).  A wave holds one
+// column per lane, 64 - 2K of them owned, the outer K lanes on each side being the halo of the K steps; per time
+// level it keeps the post-collision populations of three consecutive rows (+ their mask) in registers.  Each trip
+// loads one row of level t, collides it once, and every stage assembles one row of the next level, collides it and
+// hands it up; only level t+K is written.  Collision and assembly use the very expressions of the single-step kernel
+// (no FMA contraction), so the result is bit-identical to K single steps.
+struct LRow { float p[9]; int m; };   // post-collision populations of one row (this lane's column); m: 0 fluid, 1 solid, 2 no such row
+
+__device__ __forceinline__ void lbm_collide(const Args &A, LRow &r) {   // in: populations, out: post-collision
+  if (r.m != 0) return;
+  float *p = r.p;
+  // Moments and equilibria of :113-128, in the reference's association order but without the operations a strict
+  // IEEE compiler may not drop and that cannot change a bit of a FINITE state: products with the 0 / +-1 lattice components,
+  // additions of the resulting signed zeros, and — since e_opp = -e_q — the second evaluation of cu^2/2 for the
+  // opposite direction ((0.5 * -cu) * -cu is the same number).  The pass is VALU bound, so this is ~25 % of it.
+  float rho = 0.0f + p[0];
+  rho += p[1]; rho += p[2]; rho += p[3]; rho += p[4]; rho += p[5]; rho += p[6]; rho += p[7]; rho += p[8];
+  float ux = p[1];                      // (0 + 0*p0) + p1
+  ux -= p[3]; ux += p[5]; ux -= p[6]; ux -= p[7]; ux += p[8];
+  float uy = p[2];
+  uy -= p[4]; uy += p[5]; uy += p[6]; uy -= p[7]; uy -= p[8];
+  rho = fmaxf(rho, 1.0e-6f);
+  ux = ux / rho + A.drive;
+  uy /= rho;
+  const float u2 = ux * ux + uy * uy, t = 1.5f * u2;
+  const float w0 = (4.0f / 9.0f) * rho, w1 = (1.0f / 9.0f) * rho, w2 = (1.0f / 36.0f) * rho;
+  auto relax = [&](int q, float feq) { p[q] = p[q] - A.omega * (p[q] - feq); };
+  relax(0, w0 * (1.0f - t));                                            // cu = 0: (1 + 0 + 0) - 1.5 u2
+  auto pair = [&](int qa, int qb, float w, float e) {                    // directions +e and -e
+    const float cu = 3.0f * e, h = 0.5f * cu * cu;
+    relax(qa, w * (1.0f + cu + h - t));
+    relax(qb, w * (1.0f - cu + h - t));
+  };
+  pair(1, 3, w1, ux);
+  pair(2, 4, w1, uy);
+  pair(5, 7, w2, ux + uy);
+  pair(8, 6, w2, ux - uy);              // e_8 = (1, -1): 1*ux + (-1)*uy ; e_6 = (-1, 1) is its negative
+}
+
+// populations of the middle row at the next level, from the post-collision rows above (j-1), at (j) and below (j+1)
+__device__ __forceinline__ void lbm_assemble(const LRow &up, const LRow &cu, const LRow &dn, LRow &o) {
+  constexpr int EX[9] = {0, 1, 0, -1, 0, 1, -1, -1, 1};
+  constexpr int EY[9] = {0, 0, 1, 0, -1, 1, 1, -1, -1};
+  constexpr int OPP[9] = {0, 3, 4, 1, 2, 7, 8, 5, 6};
+  const int mm = up.m | (cu.m << 2) | (dn.m << 4);           // the three masks of this column in one word
+  const int ml = __shfl_up(mm, 1, 64), mr = __shfl_down(mm, 1, 64);
+  o.m = cu.m;
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const LRow &src = (EY[q] > 0) ? up : (EY[q] < 0 ? dn : cu);             // row of c = n - e_q
+    const int sh = (EY[q] > 0) ? 0 : (EY[q] < 0 ? 4 : 2);
+    float v = src.p[q];
+    int mc = mm;
+    if (EX[q] > 0) { v = __shfl_up(v, 1, 64); mc = ml; }                     // c is the column to the left
+    if (EX[q] < 0) { v = __shfl_down(v, 1, 64); mc = mr; }
+    const bool from_c = (((mc >> sh) & 3) == 0) && (cu.m == 0);              // c exists and is fluid, n is fluid
+    o.p[q] = from_c ? v : cu.p[OPP[q]];
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(64 * 4) void k_fused(const Args A) {
+  static_assert(K >= 2 && K <= 4, "");
+  constexpr int STRIDE = 64 - 2 * K;                                         // owned columns per wave
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)A.nstrips);
+  const int chunk = (int)(wid / (unsigned)A.nstrips);
+  const int xc = strip * STRIDE - K + lane;
+  int xw = xc;
+  while (xw < 0) xw += A.nx;
+  while (xw >= A.nx) xw -= A.nx;
+  const bool owner = lane >= K && lane < 64 - K && xc < A.nx && xc < (strip + 1) * STRIDE;
+  const int j0 = chunk * A.rows, j1 = min(j0 + A.rows, A.ny);
+
+  LRow st[K][3];
+#pragma unroll
+  for (int s = 0; s < K; s++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      st[s][k].m = 2;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) st[s][k].p[q] = 0.f;
+    }
+  // trip r: level-t row r enters; stage s then holds post-collision rows (r-2-s, r-1-s, r-s) of level t+s; the row of
+  // level t+K produced by the trip is r-K.  The first 2K trips only fill the pipeline (nothing is stored before j0).
+  for (int r = j0 - K; r < j1 + K; r++) {
+    st[0][0] = st[0][1]; st[0][1] = st[0][2];
+    {
+      LRow &n = st[0][2];
+      if (r >= 0 && r < A.ny) {
+        const size_t p = (size_t)r * A.nx + xw;
+        n.m = A.solid[p];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) n.p[q] = __builtin_nontemporal_load(&A.fin[q * A.cells + p]);
+      } else {
+        n.m = 2;
+      }
+      lbm_collide(A, n);
+    }
+    LRow out;
+#pragma unroll
+    for (int s = 0; s < K; s++) {
+      LRow o;
+      lbm_assemble(st[s][0], st[s][1], st[s][2], o);                         // level t+s+1, row r-1-s
+      if (s + 1 < K) {
+        lbm_collide(A, o);
+        st[s + 1][0] = st[s + 1][1]; st[s + 1][1] = st[s + 1][2]; st[s + 1][2] = o;
+      } else {
+        out = o;
+      }
+    }
+    const int j = r - K;
+    if (owner && j >= j0) {
+      const size_t p = (size_t)j * A.nx + xc;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) A.fout[q * A.cells + p] = out.p[q];
+    }
   }
 }
 
@@ -222,12 +353,34 @@ extern "C" int taulbm_step_async(taulbm_t *h, int nsteps) { // loop body :262-26
   lbm::Args A;
   A.nx = h->p.nx; A.ny = h->p.ny; A.nbx = (A.nx + 255) / 256; A.cells = (size_t)A.nx * A.ny;
   A.omega = 1.0f / h->p.tau; A.drive = h->p.drive; A.solid = h->solid;
-  for (int s = 0; s < nsteps; s++) {
+  // passes of K fused time levels.  Measured: 4 levels pay from ~8 M cells (8192^2: 77 -> 167 G updates/s), 3 levels
+  // from ~2 M (2048^2: 82 -> 127); below that a pass is a long serial march of few waves and the single-step push
+  // kernel (one dispatch per step) is faster.  TAU_LBM_LEVELS = 1..4 overrides.
+  static const int kenv = getenv("TAU_LBM_LEVELS") ? atoi(getenv("TAU_LBM_LEVELS")) : 0;
+  const int kmax = kenv > 0 ? kenv : (A.cells >= ((size_t)1 << 23) ? 4 : (A.cells >= ((size_t)1 << 21) ? 3 : 1));
+  static const int frows = getenv("TAU_LBM_FROWS") ? atoi(getenv("TAU_LBM_FROWS")) : 0;
+  int s = 0;
+  while (s < nsteps) {
     A.fin = h->f[h->cur]; A.fout = h->f[h->cur ^ 1];
-    hipLaunchKernelGGL(lbm::k_collide_stream, dim3((unsigned)(A.nbx * A.ny)), dim3(256), 0, h->stream, A);
-    TAU_LAUNCH_CHECK("lbm::k_collide_stream");
-    h->cur ^= 1;   // std::swap(d_f0, d_f1), :264
-    h->step++;
+    const int left = nsteps - s;
+    const int K = (kmax < 2 || kmax > 4) ? 1 : (left >= kmax ? kmax : (left >= 2 ? left : 1));
+    if (K >= 2) {
+      A.nstrips = (A.nx + (64 - 2 * K) - 1) / (64 - 2 * K);
+      long r = frows > 0 ? frows : (long)A.ny * A.nstrips / 4096;
+      A.rows = frows > 0 ? frows : (r >= 32 ? 32 : (r < 4 ? 4 : (int)r));
+      A.nchunks = (A.ny + A.rows - 1) / A.rows;
+      const unsigned nwork = (unsigned)(A.nstrips * A.nchunks), nb = (nwork + 3) / 4;
+      if (K == 2) hipLaunchKernelGGL(lbm::k_fused<2>, dim3(nb), dim3(256), 0, h->stream, A);
+      else if (K == 3) hipLaunchKernelGGL(lbm::k_fused<3>, dim3(nb), dim3(256), 0, h->stream, A);
+      else hipLaunchKernelGGL(lbm::k_fused<4>, dim3(nb), dim3(256), 0, h->stream, A);
+      TAU_LAUNCH_CHECK("lbm::k_fused");
+    } else {
+      hipLaunchKernelGGL(lbm::k_collide_stream, dim3((unsigned)(A.nbx * A.ny)), dim3(256), 0, h->stream, A);
+      TAU_LAUNCH_CHECK("lbm::k_collide_stream");
+    }
+    h->cur ^= 1;   // std::swap(d_f0, d_f1), :264 — once per pass
+    h->step += K;
+    s += K;
   }
   return 0;
 }

@@ -46,6 +46,26 @@ def test_random_state_and_mask_bit_exact(eng, oracle_built):
     e.close()
 
 
+@pytest.mark.parametrize("nx,ny,steps", [(2048, 1024, 7), (4096, 2048, 9), (2304, 1000, 5), (1500, 1500, 4)])
+def test_fused_passes_bit_exact(eng, oracle_built, nx, ny, steps):
+    """grids large enough for the K = 3 / K = 4 fused passes (>= 2 M / >= 8 M cells), odd step counts (a shorter last pass),
+    widths that are no multiple of the 58 / 56 owned columns of a wave, random populations and a random 10 % solid mask"""
+    rng = np.random.default_rng(nx + ny)
+    w = np.float32([4 / 9] + [1 / 9] * 4 + [1 / 36] * 4)[:, None, None]
+    f = (w * (1.0 + 0.2 * rng.random((9, ny, nx)))).astype(np.float32)      # near equilibrium: stays finite
+    solid = (rng.random((ny, nx)) < 0.1).astype(np.uint8)
+    solid[0] = 1; solid[-1] = 1
+    o = oracle_built.OracleLbm(nx, ny, drive=2e-3)
+    o.solid[:] = solid
+    e = eng.Lbm2D(nx, ny, drive=2e-3)
+    e.upload(f, solid)
+    want = o.step(f, steps)
+    e.step(steps)
+    got, _ = e.download()
+    assert np.isfinite(want).all() and np.array_equal(got, want)
+    e.close()
+
+
 def test_speed_field(eng, oracle_built):
     o = oracle_built.OracleLbm(256, 128)
     e = eng.Lbm2D(256, 128)
