@@ -21,6 +21,7 @@
 #include "../../include/taueng.h"
 #include "tau_common.h"
 #include <cmath>
+#include <type_traits>
 #include <cstdlib>
 #include <new>
 #include <vector>
@@ -179,10 +180,13 @@ __global__ __launch_bounds__(64 * 4) void k_fused(const Args A) {
     }
   // trip r: level-t row r enters; stage s then holds post-collision rows (r-2-s, r-1-s, r-s) of level t+s; the row of
   // level t+K produced by the trip is r-K.  The first 2K trips only fill the pipeline (nothing is stored before j0).
-  for (int r = j0 - K; r < j1 + K; r++) {
-    st[0][0] = st[0][1]; st[0][1] = st[0][2];
+  // The three rows of a stage live in a ROTATING window (newest in slot PH, oldest in PH+1, middle in PH+2, mod 3; the
+  // loop is unrolled over the three phases), so no row is ever copied: shifting cost ~36 register moves per update.
+  auto trip = [&](auto ph, int r) {
+    constexpr int PH = decltype(ph)::value;
+    constexpr int NEW = PH % 3, OLD = (PH + 1) % 3, MID = (PH + 2) % 3;
     {
-      LRow &n = st[0][2];
+      LRow &n = st[0][NEW];
       if (r >= 0 && r < A.ny) {
         const size_t p = (size_t)r * A.nx + xw;
         n.m = A.solid[p];
@@ -193,24 +197,29 @@ __global__ __launch_bounds__(64 * 4) void k_fused(const Args A) {
       }
       lbm_collide(A, n);
     }
-    LRow out;
 #pragma unroll
     for (int s = 0; s < K; s++) {
-      LRow o;
-      lbm_assemble(st[s][0], st[s][1], st[s][2], o);                         // level t+s+1, row r-1-s
       if (s + 1 < K) {
+        LRow &o = st[s + 1][NEW];                                              // overwrites that stage's oldest row
+        lbm_assemble(st[s][OLD], st[s][MID], st[s][NEW], o);                   // level t+s+1, row r-1-s
         lbm_collide(A, o);
-        st[s + 1][0] = st[s + 1][1]; st[s + 1][1] = st[s + 1][2]; st[s + 1][2] = o;
       } else {
-        out = o;
+        LRow out;
+        lbm_assemble(st[s][OLD], st[s][MID], st[s][NEW], out);
+        const int j = r - K;
+        if (owner && j >= j0) {
+          const size_t p = (size_t)j * A.nx + xc;
+#pragma unroll
+          for (int q = 0; q < 9; ++q) A.fout[q * A.cells + p] = out.p[q];
+        }
       }
     }
-    const int j = r - K;
-    if (owner && j >= j0) {
-      const size_t p = (size_t)j * A.nx + xc;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) A.fout[q * A.cells + p] = out.p[q];
-    }
+  };
+  const int r0 = j0 - K, r1 = j1 + K;
+  for (int r = r0; r < r1; r += 3) {
+    trip(std::integral_constant<int, 0>{}, r);
+    if (r + 1 < r1) trip(std::integral_constant<int, 1>{}, r + 1);
+    if (r + 2 < r1) trip(std::integral_constant<int, 2>{}, r + 2);
   }
 }
 
