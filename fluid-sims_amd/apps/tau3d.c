@@ -3,7 +3,7 @@
  * Stands where the reference's `tau3d` target does (Makefile:81-82, tau_hypersonic_3d_cuda.cu main
  * :1530-1797): same parameters (:1531-1557), same step loop (:1678-1713: log-time clock, k_step,
  * d_tau controller, swap, two steps per frame) — through libtaueng's C-ABI instead of the CUDA
- * launches.  The raylib volume viewer is out of scope; the reference takes no flags, the ones
+ * launches.  The raylib volume viewer is replaced by --ppm (below); the reference takes no flags, the ones
  * below are additive and default to the reference's behaviour (64^3, quiescent start).
  *   --n N | --nx/--ny/--nz   grid (64)         --frames F   frames of 2 steps (60)
  *   --start 0|1              0 = reference k_init, 1 = developed-flow start

@@ -171,7 +171,7 @@ int tauh2_sync(tauh2_t *h);
  * 2D WCSPH — replaces the per-sub-step launches of tau_sph.cu:676-701 (clear heads, build
  * cells, density/pressure, forces, integrate) and the host dt / log-time loop :665-721.
  * State in the reference layout and particle order: pos, vel, acc (float2 AoS), s = ln rho, press.
- * Rain (:377-392, racy) and XSPH (:274-322, off by default) are not on the hot path.
+ * XSPH (:274-322) and rain (:377-392) run inside the sub-step when tausph_params.useXSPH / .rain are set.
  * ===================================================================== */
 typedef struct tausph tausph_t;
 void tausph_params_default(tausph_params *p, int N);                        /* :49-85 */
