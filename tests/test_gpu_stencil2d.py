@@ -137,3 +137,28 @@ def test_burgers_viscosity_parity(eng, oracle_built, nx, ny, oneD):
     ugb, uwb = np.sinh(gb.astype(np.float64)), np.sinh(wb.astype(np.float64))
     assert (np.abs(ugb - uwb) <= 1e-5 * np.abs(uwb) + 1e-9).all()
     h.close()
+
+
+@pytest.mark.parametrize("nx,ny,passes", [(1024, 64, 8), (256, 40, 9), (2048, 2048, 4)])
+def test_burgers_viscosity_fused_passes(eng, oracle_built, nx, ny, passes):
+    """taulap_step(n) runs the Burgers pass in fused groups of up to four levels that keep u = u0*sinh(phi) decoded in
+    between (the reference re-encodes after every pass): a deviation at the rounding of asinh(sinh(.)), checked here
+    over several groups against the pass-by-pass oracle at the usual 1e-5."""
+    o = oracle_built.Oracle2D()
+    rng = np.random.default_rng(nx + 3 * ny)
+    u0 = 1.5
+    a = (rng.standard_normal((ny, nx)) * 1.5).astype(np.float32)
+    b = (rng.standard_normal((ny, nx)) * 0.02).astype(np.float32)
+    p = oracle_built.LapParams(nx, ny, 1.0, 1.0, 0.1, 0.2, u0)
+    h = eng.Laplacian2D(nx, ny, "burgers", nu=p.nu, dt=p.dt, u0=u0)
+    h.upload(a, b)
+    h.step(passes)
+    ga, gb = h.download()
+    wa, wb = o.lap_step("burgers", p, a, b, passes)
+    for g, w in ((ga, wa), (gb, wb)):
+        ug, uw = u0 * np.sinh(g.astype(np.float64)), u0 * np.sinh(w.astype(np.float64))
+        assert np.abs(ug - uw).max() <= 1e-5 * max(np.abs(uw).max(), 1e-30)
+        assert np.abs(g - w).max() <= 1e-5
+    ugb, uwb = np.sinh(gb.astype(np.float64)), np.sinh(wb.astype(np.float64))
+    assert (np.abs(ugb - uwb) <= 1e-5 * np.abs(uwb) + 1e-9).all()
+    h.close()
