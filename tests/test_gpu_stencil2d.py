@@ -159,6 +159,7 @@ def test_burgers_viscosity_fused_passes(eng, oracle_built, nx, ny, passes):
         ug, uw = u0 * np.sinh(g.astype(np.float64)), u0 * np.sinh(w.astype(np.float64))
         assert np.abs(ug - uw).max() <= 1e-5 * max(np.abs(uw).max(), 1e-30)
         assert np.abs(g - w).max() <= 1e-5
+    # the small field (|b| ~ 0.02, series branch of sinh/asinh) is accurate against ITS OWN scale, not only against a's
     ugb, uwb = np.sinh(gb.astype(np.float64)), np.sinh(wb.astype(np.float64))
-    assert (np.abs(ugb - uwb) <= 1e-5 * np.abs(uwb) + 1e-9).all()
+    assert np.abs(ugb - uwb).max() <= 1e-5 * np.abs(uwb).max()
     h.close()
