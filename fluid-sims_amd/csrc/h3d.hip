@@ -700,8 +700,31 @@ __global__ void k_init(Args A, float *const st0, float *const st1, float *const 
 }
 
 // periodic halo of a single domain: planes [nzl, nzl+3) -> low halo, planes [3, 6) -> high halo
-struct HaloArgs { float *f[6]; size_t plane_n; int nzl; };
+__device__ __forceinline__ void clock_begin(DevClock *c) { // log-time clock, :1680-1683 — before the step
+  c->t *= expf(c->d_tau);
+  c->dt = c->t * c->d_tau;
+  float ramp = c->t / 0.02f;
+  c->gain = fminf(fmaxf(ramp, 0.f), 1.f);
+  c->maxs_bits = 0u;
+}
+__device__ __forceinline__ void clock_end(DevClock *c) { // d_tau controller, :1697-1704 — after the step (and the max all-reduce)
+  float maxs = __uint_as_float(c->maxs_bits);
+  float dt_cfl = c->cfl / fmaxf(maxs, 1e-9f);
+  if (c->dt > 1.10f * dt_cfl) c->d_tau *= 0.80f;
+  else if (c->dt < 0.85f * dt_cfl) c->d_tau *= 1.10f;
+  c->d_tau = fminf(fmaxf(c->d_tau, 1e-7f), 5e-2f);
+  c->maxs_last = maxs;
+  c->step += 1;
+}
+// The single-domain step loop folds the two 1-thread clock kernels into the halo copy that precedes every k_step
+// (controller of the step before, then the clock of this one): two dependent dispatches per step instead of four,
+// which is what a 64^3 run is made of (clk == nullptr: plain halo copy).
+struct HaloArgs { float *f[6]; size_t plane_n; int nzl; DevClock *clk; int do_end; };
 __global__ void k_halo_periodic(HaloArgs H) {
+  if (H.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (H.do_end) clock_end(H.clk);
+    clock_begin(H.clk);
+  }
   const size_t n4 = (size_t)HALO * H.plane_n; // floats per halo block
   const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
   float *base = H.f[f];
@@ -731,24 +754,8 @@ __global__ void k_halo_pack(PackArgs P, int dir) {
   }
 }
 
-// log-time clock, :1680-1683 — runs before the step
-__global__ void k_clock_begin(DevClock *c) {
-  c->t *= expf(c->d_tau);
-  c->dt = c->t * c->d_tau;
-  float ramp = c->t / 0.02f;
-  c->gain = fminf(fmaxf(ramp, 0.f), 1.f);
-  c->maxs_bits = 0u;
-}
-// d_tau controller, :1697-1704 — runs after the step (and after the max all-reduce)
-__global__ void k_clock_end(DevClock *c) {
-  float maxs = __uint_as_float(c->maxs_bits);
-  float dt_cfl = c->cfl / fmaxf(maxs, 1e-9f);
-  if (c->dt > 1.10f * dt_cfl) c->d_tau *= 0.80f;
-  else if (c->dt < 0.85f * dt_cfl) c->d_tau *= 1.10f;
-  c->d_tau = fminf(fmaxf(c->d_tau, 1e-7f), 5e-2f);
-  c->maxs_last = maxs;
-  c->step += 1;
-}
+__global__ void k_clock_begin(DevClock *c) { clock_begin(c); }
+__global__ void k_clock_end(DevClock *c) { clock_end(c); }
 __global__ void k_clock_set_explicit(DevClock *c, float dt, float gain) {
   c->dt = dt; c->gain = gain; c->maxs_bits = 0u;
 }
@@ -889,6 +896,7 @@ struct tau3d {
   uint8_t *solid;
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
+  bool end_pending;         // the controller update of the last tau3d_step_async step has not run yet
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
   float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
@@ -902,6 +910,8 @@ struct tau3d {
   hipEvent_t ev0[4096], ev1[4096];
   bool ev_made;
 };
+
+static int flush_clock(tau3d *h);
 
 static float host_evib_eq(const tau3d_params &P, float T) { // tau_hypersonic_3d_cuda.cu:206-211
   float a = P.theta_v / fmaxf(T, 1e-6f);
@@ -993,6 +1003,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
 }
 
 extern "C" int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in) {
+  h->end_pending = false;   // whatever was pending is overwritten
   h3d::DevClock c;
   c.t = in->t; c.d_tau = in->d_tau; c.dt = in->dt; c.gain = in->gain; c.maxs_last = in->maxs;
   c.step = in->step; c.maxs_bits = 0u; c.cfl = h->p.cfl;
@@ -1002,6 +1013,7 @@ extern "C" int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in) {
 }
 
 extern "C" int tau3d_get_clock(tau3d_t *h, tau3d_clock *out) {
+  if (flush_clock(h)) return 1;
   h3d::DevClock c;
   TAU_HIP(hipMemcpyAsync(&c, h->clk, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   TAU_HIP(hipStreamSynchronize(h->stream));
@@ -1083,14 +1095,24 @@ extern "C" int tau3d_state_ptrs(tau3d_t *h, float *dptr[6], uint8_t **solid) {
   return 0;
 }
 
-extern "C" int tau3d_fill_halo_periodic_async(tau3d_t *h) {
+static int flush_clock(tau3d_t *h) { // the deferred k_clock_end of tau3d_step_async
+  if (!h->end_pending) return 0;
+  hipLaunchKernelGGL(h3d::k_clock_end, dim3(1), dim3(1), 0, h->stream, h->clk);
+  TAU_LAUNCH_CHECK("k_clock_end");
+  h->end_pending = false;
+  return 0;
+}
+static int fill_halo(tau3d_t *h, bool with_clock) {
   h3d::HaloArgs H;
+  H.clk = with_clock ? h->clk : nullptr; H.do_end = h->end_pending ? 1 : 0;
   for (int f = 0; f < 6; f++) H.f[f] = h->buf[h->cur][f];
   H.plane_n = h->plane_n; H.nzl = h->nzl;
   hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, 12), dim3(256), 0, h->stream, H);
   TAU_LAUNCH_CHECK("k_halo_periodic");
+  if (with_clock) h->end_pending = false;
   return 0;
 }
+extern "C" int tau3d_fill_halo_periodic_async(tau3d_t *h) { return fill_halo(h, false); }
 
 // steps planes [zl_lo, zl_hi) and, if zl_lo2 < zl_hi2, also [zl_lo2, zl_hi2) in the SAME launch
 static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2, void *stream) {
@@ -1146,6 +1168,7 @@ extern "C" int tau3d_step_edges_async(tau3d_t *h, int depth, void *stream) {
 }
 
 extern "C" int tau3d_clock_begin_async(tau3d_t *h) {
+  if (flush_clock(h)) return 1;
   hipLaunchKernelGGL(h3d::k_clock_begin, dim3(1), dim3(1), 0, h->stream, h->clk);
   TAU_LAUNCH_CHECK("k_clock_begin");
   return 0;
@@ -1161,10 +1184,10 @@ extern "C" int tau3d_step_async(tau3d_t *h, int nsteps) {
   if (h->nzl != h->p.nz) return tau::fail("tau3d_step: single-domain call on a slab handle (use the *_async pieces)");
   TAU_HIP(hipSetDevice(h->device));
   for (int s = 0; s < nsteps; s++) {
-    if (tau3d_clock_begin_async(h)) return 1;
-    if (tau3d_fill_halo_periodic_async(h)) return 1;
+    if (fill_halo(h, true)) return 1;                        // + controller of the previous step + clock of this one
     if (tau3d_step_range_async(h, 0, h->nzl, nullptr)) return 1;
-    if (tau3d_clock_end_async(h)) return 1;
+    h->cur ^= 1;                                             // std::swap x6, :1706-1711
+    h->end_pending = true;                                   // its controller update rides on the next halo copy
   }
   return 0;
 }
@@ -1178,6 +1201,7 @@ extern "C" int tau3d_step(tau3d_t *h, int nsteps, tau3d_clock *out) {
 extern "C" int tau3d_step_explicit(tau3d_t *h, float dt, float inflow_gain, float *maxs) {
   if (h->nzl != h->p.nz) return tau::fail("tau3d_step_explicit: single-domain call on a slab handle");
   TAU_HIP(hipSetDevice(h->device));
+  if (flush_clock(h)) return 1;
   hipLaunchKernelGGL(h3d::k_clock_set_explicit, dim3(1), dim3(1), 0, h->stream, h->clk, dt, inflow_gain);
   TAU_LAUNCH_CHECK("k_clock_set_explicit");
   if (tau3d_fill_halo_periodic_async(h)) return 1;
