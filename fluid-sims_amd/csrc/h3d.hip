@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <type_traits>
 
 namespace h3d {
 
@@ -58,8 +59,12 @@ struct Cons { float c[6]; };   // r, mx, my, mz, Et, Ev
 struct DevClock {
   float t, d_tau, dt, gain, maxs_last;
   int step;
-  unsigned maxs_bits;   // max wavespeed of the step in flight, as float bits (>0 floats order as uints)
   float cfl;
+  // ---- tau3d_set_clock writes the words above only
+  unsigned maxs_bits;   // max wavespeed of the step in flight, as float bits (>0 floats order as uints)
+  unsigned fmax_bits;   // largest |primitive| written by the step in flight (same encoding).  The word after
+                        // maxs_bits: tau3d_max_ptr hands out both and a slab ring all-reduces them together
+  float fmax_in;        // largest |primitive| in the state the next k_step reads (committed by clock_begin)
 };
 
 // kernel arguments (by value -> SGPRs)
@@ -78,6 +83,7 @@ struct Args {
   float u_ref, inv_u_ref, R, gamma, gm1, inv_gm1, Twall, theta_v, Rtheta, inv_tau_vib;
   float sdf_cx, sdf_cy, sdf_cz, sdf_r;
   float in_r, in_u, in_v, in_w, in_p, in_ev;   // inflow_prim(), :611-622 (ev from host expf)
+  float in_fmax;                               // largest |component| of it
   int sponge_n, sponge_out_n;
   float sponge_strength, sponge_out_strength;
 };
@@ -172,51 +178,84 @@ __device__ __forceinline__ int wrapi(int i, int n) { i %= n; return (i < 0) ? i 
 // slopes and the three candidate values are short combinations of the D_i, and the result is
 //   v_c + sum_k a_k q_k / (6 sum_k a_k)   with a_k = c_k / (eps + b_k)^2
 // (identical to the reference's w0*p0 + w1*p1 + w2*p2 because the weights sum to one).
+// Weights.  The reference's a_k = c_k / t_k^2 costs three quarter-rate reciprocals per state.  The FAST form puts the
+// three weights over their common denominator, a_k = c_k (t_i t_j)^2 with {i, j} the other two stencils: three
+// multiplies instead.  That needs t^4 (and t^4 times a first difference) inside fp32:
+//  * t is carried scaled by WLAM = 2^-10 (folded into the constants: exact).  The all-smooth stencil then sits at
+//    t = 1e-9, t^4 = 9e-37: still normal, and its products with the slopes underflow gradually (fp32 denormals are
+//    on in this code object, float_denorm_mode_32 = 3) — worst-case absolute error of a state 2e-9;
+//  * with every primitive of every cell at most W_FLIM in magnitude: |D| <= 2F, t <= 33.4 WLAM F^2 = 1.2e8, and
+//    the numerator <= 8 F t^4 = 9e37 < FLT_MAX.
+// The step kernel therefore tracks the largest |primitive| it WRITES (one more word next to the max wavespeed,
+// all-reduced with it across slabs) — that is exactly the largest value the next step reads — and the next launch
+// takes the FAST body only when that and the inflow state are within W_FLIM; otherwise the reciprocal form.  The
+// choice is one scalar branch at the top of the kernel, identical for every workgroup and every slab of a step.
+// Mach-100 flow (stagnation pressure 1.3e4) runs FAST.
+constexpr float WLAM = 0x1p-10f;
+constexpr float W_FLIM = 6.0e4f;
 __device__ __forceinline__ float inv_sq(float t) { return rcp(t * t); }
 // t_k = eps + 13/12 d^2 + 1/4 e^2
-__device__ __forceinline__ float smooth_t(float sd, float e) { return (0.25f * e) * e + sd; }
-__device__ __forceinline__ float sd_term(float d) { return ((13.f / 12.f) * d) * d + WENO_EPS; }
+template <bool FAST> __device__ __forceinline__ float smooth_t(float sd, float e) {
+  return ((FAST ? 0.25f * WLAM : 0.25f) * e) * e + sd;
+}
+template <bool FAST> __device__ __forceinline__ float sd_term(float d) {
+  return ((FAST ? (13.f / 12.f) * WLAM : (13.f / 12.f)) * d) * d + (FAST ? WENO_EPS * WLAM : WENO_EPS);
+}
+template <bool FAST>
+__device__ __forceinline__ void weno_weights(float t0, float t1, float t2, float &a0, float &a1, float &a2) {
+  if (FAST) {
+    const float u0 = t1 * t2, u1 = t0 * t2, u2 = t0 * t1;
+    a0 = (0.1f * u0) * u0; a1 = (0.6f * u1) * u1; a2 = (0.3f * u2) * u2;
+  } else {
+    a0 = 0.1f * inv_sq(t0); a1 = 0.6f * inv_sq(t1); a2 = 0.3f * inv_sq(t2);
+  }
+}
 
+template <bool FAST>
 __device__ __forceinline__ void weno_face(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
                                           float &R) {
   const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
-  const float sA = sd_term(D1 - D0), sB = sd_term(D2 - D1), sC = sd_term(D3 - D2), sD = sd_term(D4 - D3);
+  const float sA = sd_term<FAST>(D1 - D0), sB = sd_term<FAST>(D2 - D1), sC = sd_term<FAST>(D3 - D2),
+              sD = sd_term<FAST>(D4 - D3);
+  float sumL, sumR;
   // left state (centre cell v2): stencils {0,1,2} {1,2,3} {2,3,4}
   {
-    float i0 = inv_sq(smooth_t(sA, 3.f * D1 - D0));
-    float i1 = inv_sq(smooth_t(sB, D1 + D2));
-    float i2 = inv_sq(smooth_t(sC, 3.f * D2 - D3));
-    float a0 = 0.1f * i0, a1 = 0.6f * i1, a2 = 0.3f * i2;
+    float a0, a1, a2;
+    weno_weights<FAST>(smooth_t<FAST>(sA, 3.f * D1 - D0), smooth_t<FAST>(sB, D1 + D2),
+                       smooth_t<FAST>(sC, 3.f * D2 - D3), a0, a1, a2);
     float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
-    L = v2 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+    sumL = a0 + a1 + a2;
+    L = v2 + num * (rcp(sumL) * (1.f / 6.f));
   }
   // right state (centre cell v3): the mirror image, stencils {5,4,3} {4,3,2} {3,2,1}
   {
-    float i0 = inv_sq(smooth_t(sD, 3.f * D3 - D4));
-    float i1 = inv_sq(smooth_t(sC, D3 + D2));
-    float i2 = inv_sq(smooth_t(sB, 3.f * D2 - D1));
-    float a0 = 0.1f * i0, a1 = 0.6f * i1, a2 = 0.3f * i2;
+    float a0, a1, a2;
+    weno_weights<FAST>(smooth_t<FAST>(sD, 3.f * D3 - D4), smooth_t<FAST>(sC, D3 + D2),
+                       smooth_t<FAST>(sB, 3.f * D2 - D1), a0, a1, a2);
     float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
-    R = v3 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+    sumR = a0 + a1 + a2;
+    R = v3 + num * (rcp(sumR) * (1.f / 6.f));
   }
 }
 
 // cell-centred: m2,m1,c,p1,p2 around a cell -> Lhi = left state at its high face, Rlo = right state at its low face
+template <bool FAST>
 __device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
   const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
-  const float i0 = inv_sq(smooth_t(sd_term(D1 - D0), 3.f * D1 - D0));
-  const float i1 = inv_sq(smooth_t(sd_term(D2 - D1), D1 + D2));
-  const float i2 = inv_sq(smooth_t(sd_term(D3 - D2), 3.f * D2 - D3));
-  const float a1 = 0.6f * i1;
+  float w0, w1, w2; // 0.1 i0, 0.6 i1, 0.3 i2 with i_k = 1 / t_k^2 up to a common factor
+  weno_weights<FAST>(smooth_t<FAST>(sd_term<FAST>(D1 - D0), 3.f * D1 - D0), smooth_t<FAST>(sd_term<FAST>(D2 - D1), D1 + D2),
+                     smooth_t<FAST>(sd_term<FAST>(D3 - D2), 3.f * D2 - D3), w0, w1, w2);
+  float sumL, sumR;
   {
-    float a0 = 0.1f * i0, a2 = 0.3f * i2;
-    float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
-    Lhi = c0 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+    float num = w0 * (5.f * D1 - 2.f * D0) + w1 * (2.f * D2 + D1) + w2 * (4.f * D2 - D3);
+    sumL = w0 + w1 + w2;
+    Lhi = c0 + num * (rcp(sumL) * (1.f / 6.f));
   }
-  {
-    float a0 = 0.1f * i2, a2 = 0.3f * i0;
-    float num = a0 * (2.f * D3 - 5.f * D2) - a1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
-    Rlo = c0 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  { // mirrored roles: a0 = 0.1 i2, a1 = 0.6 i1, a2 = 0.3 i0
+    float a0 = (1.f / 3.f) * w2, a2 = 3.f * w0;
+    float num = a0 * (2.f * D3 - 5.f * D2) - w1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
+    sumR = a0 + w1 + a2;
+    Rlo = c0 + num * (rcp(sumR) * (1.f / 6.f));
   }
 }
 
@@ -359,10 +398,11 @@ __device__ __forceinline__ void solid_override_xy(Prim &L, Prim &R, const float 
 }
 
 // face between line cells v[2] | v[3]; six cells from LDS
+template <bool FAST>
 __device__ __forceinline__ Cons face_flux6(const Args &A, const float (&v)[6][6], unsigned s, int axis) {
   Prim L, R;
 #pragma unroll
-  for (int m = 0; m < 6; m++) weno_face(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+  for (int m = 0; m < 6; m++) weno_face<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
   solid_override(L, R, v[2], v[3], s, axis);
   prim_floor(L);
   prim_floor(R);
@@ -390,12 +430,15 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 }
 
 // ---------------------------------------------------------------- the step kernel
-__global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
-  __shared__ float sP[6][PLANE];            // current plane, primitives, x/y halo 3
-  __shared__ uint8_t sS[PLANE];             // solid flags of the same cells
-  __shared__ float sFx[6][TY][TX + 1];      // low-x face flux of cell (y, x); column TX = far edge
-  __shared__ float sFy[6][TY + 1][TX];      // low-y face flux of cell (y, x); row TY = far edge
-  __shared__ float sRed[NT / 64];
+struct StepLds {
+  float sP[6][PLANE];            // current plane, primitives, x/y halo 3
+  uint8_t sS[PLANE];             // solid flags of the same cells
+  float sFx[6][TY][TX + 1];      // low-x face flux of cell (y, x); column TX = far edge
+  float sFy[6][TY + 1][TX];      // low-y face flux of cell (y, x); row TY = far edge
+  float sRed[2][NT / 64];
+};
+template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, StepLds &S) {
+  auto &sP = S.sP; auto &sS = S.sS; auto &sFx = S.sFx; auto &sFy = S.sFy; auto &sRed = S.sRed;
 
   const int tid = threadIdx.x;
   const int tx = tid & (TX - 1), ty = tid >> 5;
@@ -444,8 +487,8 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
 #pragma unroll
     for (int m = 0; m < 6; m++) {
       float Rdummy;
-      weno_cell(T[m], W[0][m], W[1][m], W[2][m], W[3][m], L.q[m], Rdummy);      // cell zc_lo-1 -> L at zc_lo-1/2
-      weno_cell(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lz[m], R.q[m]);     // cell zc_lo -> R there, L above
+      weno_cell<FAST>(T[m], W[0][m], W[1][m], W[2][m], W[3][m], L.q[m], Rdummy);      // cell zc_lo-1 -> L at zc_lo-1/2
+      weno_cell<FAST>(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lz[m], R.q[m]);     // cell zc_lo -> R there, L above
     }
     solid_override(L, R, W[1], W[2], ws, 2);
     prim_floor(L);
@@ -460,7 +503,7 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
       for (int m = 0; m < 6; m++) W[k][m] = W[k + 1][m];
   }
 
-  float smax = 0.f;
+  float smax = 0.f, fmx = 0.f;
 
   for (int z = zc_lo; z < zc_hi; z++) {
     // ---- bring plane z+3 into the window: W[0..4] = z-1 .. z+3
@@ -515,7 +558,7 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
         for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3)];
         s |= (unsigned)sS[lc + (k - 3)] << k;
       }
-      Cons F = face_flux6(A, v, s, 0);
+      Cons F = face_flux6<FAST>(A, v, s, 0);
 #pragma unroll
       for (int m = 0; m < 6; m++) sFx[m][ty][tx] = F.c[m];
     }
@@ -528,12 +571,12 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
         for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3) * PXS];
         s |= (unsigned)sS[lc + (k - 3) * PXS] << k;
       }
-      Cons F = face_flux6(A, v, s, 1);
+      Cons F = face_flux6<FAST>(A, v, s, 1);
 #pragma unroll
       for (int m = 0; m < 6; m++) sFy[m][ty][tx] = F.c[m];
     }
     // far-edge faces of the tile: 8 x-faces at column TX, 32 y-faces at row TY — one extra
-    // round of the last wave, axis is lane-varying
+    // round of one wave, axis is lane-varying
     if (wave == (z & (NT / 64 - 1)) && lane < TY + TX) { // the wave that takes the extra round rotates with z: SIMD balance
       const bool isx = lane < TY;
       const int ey = isx ? lane : TY;
@@ -550,7 +593,7 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
       }
       Prim L, R;
 #pragma unroll
-      for (int m = 0; m < 6; m++) weno_face(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+      for (int m = 0; m < 6; m++) weno_face<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
       solid_override_xy(L, R, v[2], v[3], s, isx);
       prim_floor(L);
       prim_floor(R);
@@ -569,10 +612,9 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
       Prim L, R;
       float Lnext[6];
 #pragma unroll
-      for (int m = 0; m < 6; m++) {
-        L.q[m] = Lz[m];
-        weno_cell(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lnext[m], R.q[m]);
-      }
+      for (int m = 0; m < 6; m++) L.q[m] = Lz[m];
+#pragma unroll
+      for (int m = 0; m < 6; m++) weno_cell<FAST>(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lnext[m], R.q[m]);
       solid_override(L, R, W[1], W[2], ws, 2);
       prim_floor(L);
       prim_floor(R);
@@ -647,6 +689,7 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
         float a = soundspeed(A, p1, r1); // :1345-1351
         float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
         if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
+        fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
 
         A.out[0][gi] = flog(fmaxf(r1, RHO_P_FLOOR)); // :1353-1358
         A.out[1][gi] = fasinh(u1 * A.inv_u_ref);
@@ -665,15 +708,25 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
       for (int m = 0; m < 6; m++) W[k][m] = W[k + 1][m];
   }
 
-  // ---- max wavespeed: wave64 butterfly, then one atomic per workgroup
+  // ---- max wavespeed and max |primitive|: wave64 butterflies, then one atomic each per workgroup
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-  if (lane == 0) sRed[wave] = smax;
-  __syncthreads();
-  if (tid == 0) {
-    float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-    tau::atomic_max_float_bits(&A.clk->maxs_bits, m);
+  for (int o = 32; o > 0; o >>= 1) {
+    smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    fmx = fmaxf(fmx, __shfl_xor(fmx, o, 64));
   }
+  if (lane == 0) { sRed[0][wave] = smax; sRed[1][wave] = fmx; }
+  __syncthreads();
+  if (tid < 2) {
+    float m = fmaxf(fmaxf(sRed[tid][0], sRed[tid][1]), fmaxf(sRed[tid][2], sRed[tid][3]));
+    tau::atomic_max_float_bits(tid ? &A.clk->fmax_bits : &A.clk->maxs_bits, m);
+  }
+}
+
+__global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
+  __shared__ StepLds S;
+  // one scalar decision for the whole launch (see WLAM above); NaN in fmax_in takes the reciprocal form
+  if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) step_body<true>(A, S);
+  else step_body<false>(A, S);
 }
 
 // ---------------------------------------------------------------- small kernels
@@ -700,12 +753,18 @@ __global__ void k_init(Args A, float *const st0, float *const st1, float *const 
 }
 
 // periodic halo of a single domain: planes [nzl, nzl+3) -> low halo, planes [3, 6) -> high halo
+// what the step about to run reads is what the last one wrote (or what init / upload measured, k_field_max)
+__device__ __forceinline__ void field_max_commit(DevClock *c) {
+  c->fmax_in = __uint_as_float(c->fmax_bits);
+  c->fmax_bits = 0u;
+}
 __device__ __forceinline__ void clock_begin(DevClock *c) { // log-time clock, :1680-1683 — before the step
   c->t *= expf(c->d_tau);
   c->dt = c->t * c->d_tau;
   float ramp = c->t / 0.02f;
   c->gain = fminf(fmaxf(ramp, 0.f), 1.f);
   c->maxs_bits = 0u;
+  field_max_commit(c);
 }
 __device__ __forceinline__ void clock_end(DevClock *c) { // d_tau controller, :1697-1704 — after the step (and the max all-reduce)
   float maxs = __uint_as_float(c->maxs_bits);
@@ -758,6 +817,26 @@ __global__ void k_clock_begin(DevClock *c) { clock_begin(c); }
 __global__ void k_clock_end(DevClock *c) { clock_end(c); }
 __global__ void k_clock_set_explicit(DevClock *c, float dt, float gain) {
   c->dt = dt; c->gain = gain; c->maxs_bits = 0u;
+  field_max_commit(c);
+}
+// largest |primitive| of planes [zh_lo, zh_hi) of the halo layout, folded into fmax_bits (after init / upload)
+__global__ __launch_bounds__(256) void k_field_max(Args A, int zh_lo, int zh_hi) {
+  __shared__ float red[4];
+  const size_t n0 = (size_t)A.nx * A.ny * zh_lo, n1 = (size_t)A.nx * A.ny * zh_hi;
+  float m = 0.f;
+  for (size_t i = n0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (size_t)gridDim.x * blockDim.x) {
+    const Prim q = decode(A, i);
+    float c = fmaxf(fmaxf(fmaxf(fabsf(q.q[0]), fabsf(q.q[1])), fabsf(q.q[2])),
+                    fmaxf(fmaxf(fabsf(q.q[3]), fabsf(q.q[4])), fabsf(q.q[5])));
+    if (!(c <= 3.0e38f)) c = __builtin_inff();   // NaN / inf cells: no claim about the range
+    m = fmaxf(m, c);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    tau::atomic_max_float_bits(&A.clk->fmax_bits, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 
@@ -951,6 +1030,9 @@ static void fill_consts(tau3d *h) {
   A.in_r = fmaxf(P.inflow_r, 1e-30f); A.in_p = fmaxf(P.inflow_p, 1e-30f);
   A.in_u = P.inflow_u; A.in_v = P.inflow_v; A.in_w = P.inflow_w;
   A.in_ev = host_evib_eq(P, A.in_p / (A.in_r * P.R));
+  A.in_fmax = fmaxf(fmaxf(fmaxf(fabsf(A.in_r), fabsf(A.in_u)), fmaxf(fabsf(A.in_v), fabsf(A.in_w))), fmaxf(fabsf(A.in_p), fabsf(A.in_ev)));
+  if (!(A.in_fmax <= 3.0e38f)) A.in_fmax = INFINITY;
+  if (const char *e = getenv("TAU3D_WENO_RCP")) { if (atoi(e) != 0) A.in_fmax = INFINITY; }   // force the reciprocal form
   A.sponge_n = P.sponge_n > 0 ? P.sponge_n : 0; A.sponge_out_n = P.sponge_out_n > 0 ? P.sponge_out_n : 0;
   A.sponge_strength = P.sponge_strength; A.sponge_out_strength = P.sponge_out_strength;
   A.solid = h->solid; A.clk = h->clk;
@@ -981,6 +1063,14 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
   fill_consts(h);
+  { // nothing is known about the state yet: the first k_step takes the reciprocal form unless init / upload measured it
+    h3d::DevClock c0;
+    memset(&c0, 0, sizeof(c0));
+    c0.fmax_bits = 0x7F800000u;
+    c0.fmax_in = INFINITY;
+    TAU_HIP(hipMemcpyAsync(h->clk, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream));
+    TAU_HIP(hipStreamSynchronize(h->stream));
+  }
   tau3d_clock c = {1e-5f, 1e-3f, 0.f, 0.f, 0.f, 0};
   *out = guard.release();
   return tau3d_set_clock(h, &c);
@@ -1007,7 +1097,7 @@ extern "C" int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in) {
   h3d::DevClock c;
   c.t = in->t; c.d_tau = in->d_tau; c.dt = in->dt; c.gain = in->gain; c.maxs_last = in->maxs;
   c.step = in->step; c.maxs_bits = 0u; c.cfl = h->p.cfl;
-  TAU_HIP(hipMemcpyAsync(h->clk, &c, sizeof(c), hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipMemcpyAsync(h->clk, &c, offsetof(h3d::DevClock, fmax_bits), hipMemcpyHostToDevice, h->stream));
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1018,6 +1108,17 @@ extern "C" int tau3d_get_clock(tau3d_t *h, tau3d_clock *out) {
   TAU_HIP(hipMemcpyAsync(&c, h->clk, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   TAU_HIP(hipStreamSynchronize(h->stream));
   out->t = c.t; out->d_tau = c.d_tau; out->dt = c.dt; out->gain = c.gain; out->maxs = c.maxs_last; out->step = c.step;
+  return 0;
+}
+
+// The state was written from outside the step kernel: fold its largest |primitive| into fmax_bits (`fresh`: the
+// whole local state was replaced, forget what was there).  The next clock_begin commits it.
+static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
+  if (fresh) TAU_HIP(hipMemsetAsync(&h->clk->fmax_bits, 0, sizeof(unsigned), h->stream));
+  h3d::Args a = h->base;
+  for (int f = 0; f < 6; f++) a.in[f] = h->buf[h->cur][f];
+  hipLaunchKernelGGL(h3d::k_field_max, dim3(1024), dim3(256), 0, h->stream, a, zl_lo + h3d::HALO, zl_hi + h3d::HALO);
+  TAU_LAUNCH_CHECK("k_field_max");
   return 0;
 }
 
@@ -1042,6 +1143,7 @@ extern "C" int tau3d_init(tau3d_t *h, int mode) {
   hipLaunchKernelGGL(h3d::k_init, dim3(2048), dim3(256), 0, h->stream, h->base, b[0], b[1], b[2], b[3], b[4], b[5],
                      (const uint8_t *)h->solid, iv);
   TAU_LAUNCH_CHECK("k_init");
+  if (measure_field(h, -h3d::HALO, h->nzl + h3d::HALO, true)) return 1;
   tau3d_clock c = {1e-5f, 1e-3f, 0.f, 0.f, 0.f, 0};
   return tau3d_set_clock(h, &c);
 }
@@ -1052,6 +1154,8 @@ extern "C" int tau3d_upload_state(tau3d_t *h, const float *const host[6]) {
   for (int f = 0; f < 6; f++)
     TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f] + h3d::HALO * h->plane_n, host[f], n * sizeof(float),
                            hipMemcpyHostToDevice, h->stream));
+  // halo planes keep what they held (a periodic fill or an exchange refreshes them from measured planes)
+  if (measure_field(h, 0, h->nzl, false)) return 1;
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1080,6 +1184,7 @@ static int planes_copy(tau3d_t *h, int zl_lo, int zl_hi, const float *const up[6
     if (up) TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f] + off, up[f], n, hipMemcpyHostToDevice, h->stream));
     else TAU_HIP(hipMemcpyAsync(down[f], h->buf[h->cur][f] + off, n, hipMemcpyDeviceToHost, h->stream));
   }
+  if (up && measure_field(h, zl_lo, zl_hi, false)) return 1;
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -1241,6 +1346,22 @@ extern "C" int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, siz
   if ((kind | 1) != 1 || (side | 1) != 1 || !p) return tau::fail("tau3d_halo_buf_ptr: bad argument");
   *p = h->xbuf[kind][side];
   if (nfloats) *nfloats = 6 * (size_t)h3d::HALO * h->plane_n;
+  return 0;
+}
+extern "C" int tau3d_state_written(tau3d_t *h) {
+  TAU_HIP(hipSetDevice(h->device));
+  return measure_field(h, -h3d::HALO, h->nzl + h3d::HALO, false);
+}
+extern "C" int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast_form) {
+  TAU_HIP(hipSetDevice(h->device));
+  h3d::DevClock c;
+  TAU_HIP(hipMemcpyAsync(&c, h->clk, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  float w;
+  memcpy(&w, &c.fmax_bits, 4);
+  if (read_max) *read_max = c.fmax_in;
+  if (written_max) *written_max = w;
+  if (fast_form) *fast_form = fmaxf(c.fmax_in, h->base.in_fmax) <= h3d::W_FLIM ? 1 : 0;
   return 0;
 }
 extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {

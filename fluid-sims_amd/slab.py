@@ -10,7 +10,7 @@ The reference is single-GPU (no NCCL/MPI anywhere); this layer is ne
     step edge planes [0,3) , [nzl-3,nzl) need the halos; produce next state's boundary planes
     pack those planes, isend/irecv       2 sends + 2 recvs of one packed buffer each (comm stream, async)
     step interior planes [3, nzl-3)      overlaps the exchange
-    all_reduce(MAX) of the max-wavespeed word (4 bytes)
+    all_reduce(MAX) of the max-wavespeed and max-|primitive| words (8 bytes)
     clock_end                            d_tau controller (device) + swap
 
 Only 3 planes x 6 fields cross each link per step (18.9 MB at 512^2 planes); each direction of a
@@ -65,7 +65,7 @@ class EngineSlabBackend:
             for side in (0, 1):
                 p, n = self.h.halo_buf(kind, side)
                 self._buf[(kind, side)] = torch.as_tensor(_DevMem(p, (n,)), device=self.dev)
-        self._max = torch.as_tensor(_DevMem(self.h.max_ptr(), (1,)), device=self.dev)
+        self._max = torch.as_tensor(_DevMem(self.h.max_ptr(), (2,)), device=self.dev)   # max wavespeed, max |primitive|
 
     def buf(self, kind, side):
         return self._buf[(kind, side)]
@@ -139,6 +139,8 @@ class SlabRing:
         self.b.pack(0)
         self._pending = self._post_exchange()
         self._land(0)
+        if self.world > 1:                             # the field range init / upload measured, over all slabs
+            dist.all_reduce(self.b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
 
     def step(self, n=1):
         b, nzl = self.b, self.b.nzl

@@ -141,6 +141,8 @@ def load():
         "tau3d_unpack_halos_async": ([vp, i32], i32),
         "tau3d_halo_buf_ptr": ([vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)], i32),
         "tau3d_max_ptr": ([vp, C.POINTER(vp)], i32),
+        "tau3d_state_written": ([vp], i32),
+        "tau3d_field_range": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)], i32),
         "tau3d_sync": ([vp], i32),
         "tau3d_vis": ([vp, i32, vp], i32),
         "tau3d_vis_async": ([vp, i32, vp], i32),
@@ -370,9 +372,19 @@ class Tau3D:
         return p.value, n.value
 
     def max_ptr(self):
+        """device address of two floats: max wavespeed, max |primitive| (all-reduced together by a slab ring)"""
         p = C.c_void_p()
         _ck(self._L.tau3d_max_ptr(self._h, C.byref(p)))
         return p.value
+
+    def state_written(self):
+        _ck(self._L.tau3d_state_written(self._h))
+
+    def field_range(self):
+        """(read_max, written_max, fast_form) — see tau3d_field_range"""
+        a, b, f = C.c_float(), C.c_float(), C.c_int()
+        _ck(self._L.tau3d_field_range(self._h, C.byref(a), C.byref(b), C.byref(f)))
+        return a.value, b.value, bool(f.value)
 
     def sync(self):
         _ck(self._L.tau3d_sync(self._h))

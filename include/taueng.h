@@ -88,7 +88,7 @@ int tau3d_step_explicit(tau3d_t *h, float dt, float inflow_gain, float *maxs);
  *   tau3d_step_edges_async(E)          planes [0,E) and [nzl-E,nzl), E >= 3, one launch — need the halos
  *   <caller: exchange tau3d_halo_send_ptr -> neighbour's tau3d_halo_recv_ptr>
  *   tau3d_step_range_async(interior)   planes [E,nzl-E)
- *   <caller: all-reduce(max) the word at tau3d_max_ptr>
+ *   <caller: all-reduce(max) the TWO words at tau3d_max_ptr, as floats>
  *   tau3d_clock_end_async              d_tau controller, swap
  * The caller (bench.py / the driver) orders these on streams it owns. */
 int tau3d_clock_begin_async(tau3d_t *h);
@@ -109,7 +109,18 @@ int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p);
 int tau3d_pack_halos_async(tau3d_t *h, int which);
 int tau3d_unpack_halos_async(tau3d_t *h, int which);
 int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, size_t *nfloats);
+/* Two consecutive device words, both non-negative floats: [0] the max wavespeed of the step in flight (the
+ * controller input of :1697-1704), [1] the largest |primitive| that step wrote — or, after init / upload, the
+ * largest in the state (the step kernel picks its WENO weight form from it).  A ring all-reduces
+ * (max) both after the step's launches, and once after init / upload before the first step. */
 int tau3d_max_ptr(tau3d_t *h, float **p);
+/* Diagnostics (synchronises): *read_max = the largest |primitive| the last launched step was told its input holds,
+ * *written_max = the largest it (or init / upload since) wrote, *fast_form = 1 if that launch took the
+ * common-denominator WENO weights, 0 if the reciprocal form (input range above 6e4).  Any pointer may be NULL. */
+int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast_form);
+/* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state through them says so
+ * here before the next step (tau3d_init / tau3d_upload_* do it themselves). */
+int tau3d_state_written(tau3d_t *h);
 int tau3d_sync(tau3d_t *h);
 
 /* Visualisation fields — replaces k_vis (tau_hypersonic_3d_cuda.cu:800-905, launched :1715-1716),

@@ -40,7 +40,7 @@ def _worker(rank, world, port, shape, steps, outdir):
         def __init__(self, *a):
             super().__init__(*a)
             self._host = {k: torch.empty(v.shape, dtype=v.dtype) for k, v in self._buf.items()}
-            self._hmax = torch.zeros(1, dtype=torch.float32)
+            self._hmax = torch.zeros(self._max.shape, dtype=torch.float32)
 
         def buf(self, kind, side):
             return self._host[(kind, side)]

@@ -153,3 +153,126 @@ def test_full_size_slab_vs_oracle(eng, oracle_built):
     r = assert_parity(got, want, mask=fluid, what="512^3 slab")
     print("512^3 slab parity", {k: f"{v:.2e}" for k, v in r.items()})
     e.close()
+
+
+# ---- WENO weight form: the step kernel takes the common-denominator weights when the state it reads
+# ---- is within 6e4 in magnitude, the reciprocal form otherwise — both against the same oracle
+def _explicit_vs_oracle(eng, oracle_built, shape, fields, dt, gain=1.0, **par):
+    import ctypes
+    nx, ny, nz = shape
+    P = eng.Tau3DParams()
+    eng.load().tau3d_params_default(ctypes.byref(P), nx, ny, nz)
+    o = oracle_built.Oracle3D(nx, ny, nz)
+    for k, v in par.items():
+        setattr(P, k, v)
+        setattr(o.p, k, v)
+    o = oracle_built.Oracle3D(nx, ny, nz, params=o.p)          # rebuilds the mask with the changed parameters
+    e = eng.Tau3D(nx, ny, nz, params=P)
+    e.init(1)
+    e.upload(fields)
+    want, m_want = oracle_one_step(oracle_built, o, fields, dt, gain)
+    m_got = e.step_explicit(dt, gain)
+    got = e.download()
+    rng = e.field_range()
+    e.close()
+    return got, want, o.interior([o.solid])[0] == 0, rng, (m_got, m_want)
+
+
+def _developed(eng, shape, warm):
+    e = eng.Tau3D(*shape)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(warm)
+    st = e.download()
+    c = e.clock()
+    rng = e.field_range()
+    e.close()
+    return st, float(c.dt), rng
+
+
+def _forced_reciprocal(fn):
+    """run fn() with the engine told to use the reciprocal weights whatever the range (read at tau3d_create)"""
+    os.environ["TAU3D_WENO_RCP"] = "1"
+    try:
+        return fn()
+    finally:
+        del os.environ["TAU3D_WENO_RCP"]
+
+
+CONS = ("rho", "mx", "my", "mz", "E")
+
+
+def test_weight_form_follows_the_field_range(eng, oracle_built):
+    shape = (48, 40, 24)
+    st, dt, rng = _developed(eng, shape, 25)
+    assert rng[2] and 99.9 <= rng[0] < 6e4 and 99.9 <= rng[1] < 6e4          # Mach-100 run: fast form, |u| = 100 seen
+    got, want, fluid, rng, m = _explicit_vs_oracle(eng, oracle_built, shape, st, dt)
+    assert rng[2]
+    assert_parity(got, want, mask=fluid, what="fast form")
+    got2, _, _, rng2, _ = _forced_reciprocal(lambda: _explicit_vs_oracle(eng, oracle_built, shape, st, dt))
+    assert not rng2[2]
+    assert_parity(got2, want, mask=fluid, what="reciprocal form, forced")
+    # same flow, pressure and vibrational energy lifted by 1e5 (no vibrational relaxation: exp(theta/T) - 1 at that
+    # temperature is all cancellation): out of the fast window -> reciprocal form.  A Mach-0.3 flow now, so the
+    # velocities are compared through the momenta (relative to rho (|u| + a)), not through asinh(u / u_ref).
+    # (A lift of 1e7 puts e_vib jumps at 2e9, where the reference's own (eps + beta)^2 leaves fp32.)
+    big = [a.copy() for a in st]
+    big[4] += np.float32(np.log(1e5))
+    big[5] += np.float32(np.log(1e5))
+    got, want, fluid, rng, m = _explicit_vs_oracle(eng, oracle_built, shape, big, dt * 1e-3, tau_vib=1e30)
+    assert not rng[2] and rng[0] > 6e4
+    rep = report(got, want, mask=fluid)
+    assert all(rep[k] < 1e-5 for k in CONS) and rep["xi"] < 1e-5 and rep["lam"] < 1e-5, rep
+    assert m[0] == pytest.approx(m[1], rel=1e-5)
+
+
+def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built):
+    """cell-to-cell jumps of the largest admitted size in u, v, w, p and e_vib at once, in every direction: t^4 is at
+    the top of fp32 — finite, within tolerance of the oracle, and next to the reciprocal form"""
+    shape = (32, 24, 16)
+    nx, ny, nz = shape
+    rng = np.random.default_rng(5)
+    F = 5.5e4
+    sgn = lambda: rng.choice([-1.0, 1.0], size=(nz, ny, nx))
+    mag = lambda lo: np.where(rng.random((nz, ny, nx)) < 0.5, lo, F)
+    r, p, ev = 1.0 + rng.random((nz, ny, nx)), mag(1.0), mag(1e-3)
+    u, v, w = (sgn() * mag(1.0) for _ in range(3))
+    fields = [np.log(r), np.arcsinh(u / 10.0), np.arcsinh(v / 10.0), np.arcsinh(w / 10.0), np.log(p), np.log(ev)]
+    fields = [a.astype(np.float32) for a in fields]
+    run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 1e-8, tau_vib=1e30)
+    got, want, fluid, fr, m = run()
+    assert fr[2] and 5e4 < fr[0] <= 6e4, fr
+    assert all(np.isfinite(g).all() for g in got) and all(np.isfinite(w_).all() for w_ in want)
+    rep = report(got, want, mask=fluid)
+    got2, _, _, fr2, _ = _forced_reciprocal(run)
+    assert not fr2[2]
+    rep2 = report(got2, want, mask=fluid)
+    print("edge", {k: (f"{rep[k]:.1e}", f"{rep2[k]:.1e}") for k in CONS})
+    # input this wild (every face a 1e5 jump) is ill-conditioned for any fp32 evaluation: the bar is the error the
+    # reciprocal form has against the same oracle
+    worst, worst2 = max(rep[k] for k in CONS), max(rep2[k] for k in CONS)
+    assert worst < 1e-4 and worst < 2 * worst2, (rep, rep2)
+
+
+def test_fast_weights_keep_small_smooth_corrections(eng, oracle_built):
+    """the other end of the window: every stencil at the eps floor (t = 1e-6), slopes of 1e-7 — the products
+    a_k q_k run through fp32 denormals and must still carry the high-order correction: the error against the oracle
+    stays at the rounding level the reciprocal form has"""
+    shape = (40, 32, 24)
+    nx, ny, nz = shape
+    z, y, x = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    wave = np.sin(2 * np.pi * (x / nx + 2 * y / ny + z / nz))
+    amp = 1e-6
+    r = 0.02 * (1 + amp * wave); p = 0.02 * (1 + amp * np.roll(wave, 3, 2)); ev = 1e-3 * (1 + amp * np.roll(wave, 5, 1))
+    u = 100.0 * (1 + amp * np.roll(wave, 7, 0)); v = 1e-4 * wave; w = -1e-4 * np.roll(wave, 2, 2)
+    fields = [np.log(r), np.arcsinh(u / 10.0), np.arcsinh(v / 10.0), np.arcsinh(w / 10.0), np.log(p), np.log(ev)]
+    fields = [a.astype(np.float32) for a in fields]
+    run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 2e-6, sdf_r=0.0)
+    got, want, fluid, fr, m = run()
+    assert fr[2]
+    got2, _, _, fr2, _ = _forced_reciprocal(run)
+    assert not fr2[2]
+    rep, rep2 = report(got, want, mask=fluid), report(got2, want, mask=fluid)
+    print("smooth", {k: (f"{rep[k]:.1e}", f"{rep2[k]:.1e}") for k in rep})
+    for k in ("xi", "phix", "phiy", "phiz", "rho", "mx", "my", "mz", "E"):
+        assert rep[k] < 2e-6 and rep[k] <= 1.5 * rep2[k] + 1e-7, (k, rep[k], rep2[k])
