@@ -3,11 +3,11 @@
 #
 #   make            engine library + every driver
 #   make cpu        tau_hypersonic tau_hypersonic_simd            (CPU programs, as in the reference)
-#   make cuda       tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph tau_burgers tau_sw tau_lbm   (HIP engine behind them;
-#                   tau_lbm has no target in the reference Makefile — its build line is in the header of tau_lbm.cu)
+#   make cuda       tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph tau_burgers tau_sw tau_lbm th3cs   (HIP engine behind
+#                   them; tau_lbm and th3cs have no target in the reference Makefile — their build lines are in the file headers)
 #   make test       the reference's regression round trip (needs an MI355X)
 #   make <target>   a single program by its reference name
-# Not provided: jsc jsc3d sim tau_mhd number_fluid2d/3d th3cs (out of the hot-path scope).
+# Not provided: jsc jsc3d sim tau_mhd number_fluid2d/3d (out of the hot-path scope).
 CC      ?= gcc
 ROCM    ?= /opt/rocm
 ENG      = fluid-sims_amd
@@ -16,7 +16,7 @@ CFLAGS  ?= -O2 -Wall -std=gnu99
 LINK     = -L$(ENG)/lib -ltaueng -L$(ROCM)/lib -lamdhip64 -lstdc++ -lm -Wl,-rpath,$(abspath $(ENG)/lib) -Wl,-rpath,$(ROCM)/lib
 
 CPU_BINS  := tau_hypersonic tau_hypersonic_simd
-CUDA_BINS := tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph tau_burgers tau_sw tau_lbm
+CUDA_BINS := tau3d tgs tau_2d_hypersonic_cuda tau_hypersonic_cuda_tests tau_sph tau_burgers tau_sw tau_lbm th3cs
 
 .PHONY: all cpu cuda test clean engine $(CPU_BINS) $(CUDA_BINS)
 all: cpu cuda
@@ -49,7 +49,7 @@ $(BIN)/tau_sw: $(ENG)/apps/tau_flow.c $(ENG)/apps/tau_cli.h include/taueng.h eng
 	$(CC) $(CFLAGS) -DTAU_SW $< -o $@ $(LINK)
 
 $(CUDA_BINS): %: $(BIN)/%
-$(BIN)/%: $(ENG)/apps/%.c $(ENG)/apps/tau_cli.h include/taueng.h engine
+$(BIN)/%: $(ENG)/apps/%.c $(ENG)/apps/tau_cli.h $(ENG)/apps/tau_4splat.h include/taueng.h engine
 	@mkdir -p $(BIN)
 	$(CC) $(CFLAGS) $< -o $@ $(LINK)
 

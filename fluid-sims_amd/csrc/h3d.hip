@@ -943,6 +943,32 @@ __global__ __launch_bounds__(256) void k_slice_rgba(const float *__restrict__ s,
   }
 }
 
+// th3cs.cu:1199-1222 — the export path of the headless program: a whole visualisation volume to 8-bit palette
+// indices, (int)(pow((v - min) / max(max - min, 1e-12), gamma) * 255) clamped to 0..255.  The reference does the
+// min / max and the map on the host over a downloaded float volume; here the volume never leaves the device and one
+// byte per voxel comes back.
+__global__ __launch_bounds__(256) void k_volume_minmax(const float *__restrict__ s, size_t n, unsigned *mm) {
+  float mn = 1e30f, mx = -1e30f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float v = s[i];
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+  if ((threadIdx.x & 63) == 0) { atomicMin(&mm[0], fkey(mn)); atomicMax(&mm[1], fkey(mx)); }
+}
+__global__ __launch_bounds__(256) void k_palette_index(const float *__restrict__ s, size_t n, float gamma,
+                                                       const unsigned *mm, uint8_t *__restrict__ dst) {
+  const float mn = funkey(mm[0]), mx = funkey(mm[1]);
+  const float range = fmaxf(mx - mn, 1e-12f);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float norm = powf((s[i] - mn) / range, gamma);
+    int p = (int)(norm * 255.0f);
+    p = p < 0 ? 0 : (p > 255 ? 255 : p);
+    dst[i] = (uint8_t)p;
+  }
+}
+
 // k_outflow_reflection_metric, :1389-1408: max |p - p_inflow| over the last nprobe columns
 __global__ __launch_bounds__(256) void k_outflow_reflection(const Args A, int x0, unsigned *out_bits) {
   const int ncol = A.nx - x0;
@@ -979,6 +1005,7 @@ struct tau3d {
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
   float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
+  uint8_t *pidx = nullptr;   // palette indices of the last tau3d_palette_indices
   float *vis;               // nx*ny*nzl scalar field of the last tau3d_vis (lazy)
   uint32_t *rgba;           // one slice of pixels (lazy)
   unsigned *scratch;        // 4 words: slice min/max keys, reflection metric bits
@@ -1084,7 +1111,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
     for (int f = 0; f < 6; f++) hipFree(h->buf[s][f]);
   hipFree(h->solid);
   hipFree(h->clk);
-  hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch);
+  hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
   for (int k = 0; k < 2; k++)
     for (int sd = 0; sd < 2; sd++) hipFree(h->xbuf[k][sd]);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
@@ -1440,6 +1467,28 @@ extern "C" int tau3d_slice_rgba(tau3d_t *h, int zslice, int log_scale, float a_g
   unsigned keys[2];
   TAU_HIP(hipMemcpyAsync(keys, h->scratch, sizeof(keys), hipMemcpyDeviceToHost, h->stream));
   if (host_rgba) TAU_HIP(hipMemcpyAsync(host_rgba, h->rgba, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  auto unkey = [](unsigned k) { unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
+  if (mn) *mn = unkey(keys[0]);
+  if (mx) *mx = unkey(keys[1]);
+  return 0;
+}
+extern "C" int tau3d_palette_indices(tau3d_t *h, float gamma, uint8_t *host_idx, float *mn, float *mx) {
+  TAU_HIP(hipSetDevice(h->device));
+  if (!h->vis) return tau::fail("tau3d_palette_indices: no visualisation field yet (call tau3d_vis first)");
+  const size_t n = h->plane_n * (size_t)h->nzl;
+  if (!h->pidx) TAU_HIP(hipMalloc(&h->pidx, n));
+  const unsigned init[2] = {0xffffffffu, 0u};
+  TAU_HIP(hipMemcpyAsync(h->scratch, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+  const unsigned nb = (unsigned)(n / 256 < 1 ? 1 : (n / 256 > 4096 ? 4096 : n / 256));
+  hipLaunchKernelGGL(h3d::k_volume_minmax, dim3(nb), dim3(256), 0, h->stream, (const float *)h->vis, n, h->scratch);
+  TAU_LAUNCH_CHECK("k_volume_minmax");
+  hipLaunchKernelGGL(h3d::k_palette_index, dim3(nb), dim3(256), 0, h->stream, (const float *)h->vis, n, gamma,
+                     (const unsigned *)h->scratch, h->pidx);
+  TAU_LAUNCH_CHECK("k_palette_index");
+  unsigned keys[2];
+  TAU_HIP(hipMemcpyAsync(keys, h->scratch, sizeof(keys), hipMemcpyDeviceToHost, h->stream));
+  if (host_idx) TAU_HIP(hipMemcpyAsync(host_idx, h->pidx, n, hipMemcpyDeviceToHost, h->stream));
   TAU_HIP(hipStreamSynchronize(h->stream));
   auto unkey = [](unsigned k) { unsigned b = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k; float f; memcpy(&f, &b, 4); return f; };
   if (mn) *mn = unkey(keys[0]);

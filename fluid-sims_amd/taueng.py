@@ -142,6 +142,7 @@ def load():
         "tau3d_halo_buf_ptr": ([vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)], i32),
         "tau3d_max_ptr": ([vp, C.POINTER(vp)], i32),
         "tau3d_state_written": ([vp], i32),
+        "tau3d_palette_indices": ([vp, f32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "tau3d_field_range": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)], i32),
         "tau3d_sync": ([vp], i32),
         "tau3d_vis": ([vp, i32, vp], i32),
@@ -376,6 +377,13 @@ class Tau3D:
         p = C.c_void_p()
         _ck(self._L.tau3d_max_ptr(self._h, C.byref(p)))
         return p.value
+
+    def palette_indices(self, gamma=0.65):
+        """8-bit palette indices of the last vis() volume (th3cs.cu:1199-1222); returns (uint8 array, min, max)"""
+        out = np.empty((self.nzl, self.params.ny, self.params.nx), np.uint8)
+        mn, mx = C.c_float(), C.c_float()
+        _ck(self._L.tau3d_palette_indices(self._h, gamma, out.ctypes.data_as(C.c_void_p), C.byref(mn), C.byref(mx)))
+        return out, mn.value, mx.value
 
     def state_written(self):
         _ck(self._L.tau3d_state_written(self._h))

@@ -123,6 +123,12 @@ int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast
 int tau3d_state_written(tau3d_t *h);
 int tau3d_sync(tau3d_t *h);
 
+/* The export path of th3cs.cu (:1193-1222): the volume of the last tau3d_vis — th3cs uses mode 0, its
+ * k_schlieren_export (:641-673) is that field — mapped to 8-bit palette indices,
+ * (int)(powf((v - min) / fmaxf(max - min, 1e-12f), gamma) * 255) clamped to 0..255 (th3cs: gamma = 0.65).  The
+ * reference downloads the float volume and does min / max / map on the host; here one byte per voxel comes back
+ * (host_idx: nx*ny*nzl bytes, may be NULL to leave them on the device).  *mn, *mx: the range used. */
+int tau3d_palette_indices(tau3d_t *h, float gamma, uint8_t *host_idx, float *mn, float *mx);
 /* Visualisation fields — replaces k_vis (tau_hypersonic_3d_cuda.cu:800-905, launched :1715-1716),
  * slice_to_rgba (:1416-1442, called per slice :1735-1739) and k_outflow_reflection_metric (:1389-1408,
  * launched :1724-1731).  mode = the reference's VisMode (:784-794): 0 |grad rho|, 1 log(1+rho),

@@ -127,6 +127,16 @@ class Oracle3D:
                                 C.byref(mn), C.byref(mx))
         return px.view(np.uint8).reshape(ny, nx, 4), mn.value, mx.value
 
+    def palette_indices(self, vol, gamma=0.65):
+        """th3cs.cu:1199-1222: (uint8 indices, min, max) of a float volume"""
+        vol = np.ascontiguousarray(vol, np.float32)
+        out = np.empty(vol.shape, np.uint8)
+        mn, mx = C.c_float(), C.c_float()
+        self.L.o3_palette_indices.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.POINTER(C.c_float),
+                                              C.POINTER(C.c_float)]
+        self.L.o3_palette_indices(_vp(vol), vol.size, gamma, _vp(out), C.byref(mn), C.byref(mx))
+        return out, mn.value, mx.value
+
     def outflow_reflection(self, st, nprobe=6):
         self.L.o3_outflow_reflection.restype = C.c_float
         return self.L.o3_outflow_reflection(C.byref(self.p), self.nzl, _ptrs(st), int(nprobe))

@@ -677,6 +677,28 @@ void o3_slice_to_rgba(uint32_t *dst, const float *vol, int nx, int ny, int nz, i
   if (mx_out) *mx_out = mx;
 }
 
+/* th3cs.cu:1199-1222 — the export map of the headless program: whole-volume min / max, then per voxel
+ * pIdx = clamp((int)(powf((v - min) / max(max - min, 1e-12), gamma) * 255), 0, 255) (th3cs: gamma = 0.65).
+ * The volume is th3cs's k_schlieren_export field (:641-673), which is o3_vis mode 0 (same prim_at_xbc, same
+ * central differences of rho). */
+void o3_palette_indices(const float *vol, size_t n, float gamma, uint8_t *out, float *mn_out, float *mx_out) {
+  float min_val = 1e30f, max_val = -1e30f;
+  for (size_t i = 0; i < n; i++) {
+    min_val = fminf(min_val, vol[i]);
+    max_val = fmaxf(max_val, vol[i]);
+  }
+  float range = fmaxf(max_val - min_val, 1e-12f);
+  for (size_t i = 0; i < n; i++) {
+    float norm = (vol[i] - min_val) / range;
+    norm = powf(norm, gamma);
+    int pIdx = (int)(norm * 255.0f);
+    pIdx = pIdx < 0 ? 0 : (pIdx > 255 ? 255 : pIdx);
+    out[i] = (uint8_t)pIdx;
+  }
+  if (mn_out) *mn_out = min_val;
+  if (mx_out) *mx_out = max_val;
+}
+
 /* k_outflow_reflection_metric, :1389-1408 — max |p - p_inflow| over the last nprobe x-columns */
 float o3_outflow_reflection(const tau3d_params *P, int nzl, const float *const st[6], int nprobe) {
   const int nx = P->nx, ny = P->ny;

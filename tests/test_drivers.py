@@ -26,7 +26,7 @@ def run(*args, **kw):
 
 def test_reference_target_names_exist(built):
     for t in ("tau_hypersonic", "tau_hypersonic_simd", "tau_2d_hypersonic_cuda", "tau_hypersonic_cuda_tests", "tau3d",
-              "tgs", "tau_sph", "tau_burgers", "tau_sw"):
+              "tgs", "tau_sph", "tau_burgers", "tau_sw", "tau_lbm", "th3cs"):
         assert os.access(os.path.join(built, t), os.X_OK), t
 
 
