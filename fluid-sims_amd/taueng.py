@@ -735,6 +735,12 @@ class GrayScott:
         _ck(self._L.taugs_download(self._h, u.ctypes.data, v.ctypes.data))
         return u, v
 
+    def state_ptrs(self):
+        """device addresses of the current u, v arrays (they swap with every step)"""
+        u, v = C.c_void_p(), C.c_void_p()
+        _ck(self._L.taugs_state_ptrs(self._h, C.byref(u), C.byref(v)))
+        return u.value, v.value
+
     def step(self, n=1):
         _ck(self._L.taugs_step(self._h, n))
 
@@ -773,6 +779,12 @@ class Laplacian2D:
         a, b = np.empty(shp, np.float32), np.empty(shp, np.float32)
         _ck(self._L.taulap_download(self._h, a.ctypes.data, b.ctypes.data))
         return a, b
+
+    def state_ptrs(self):
+        """device addresses of the current two arrays (they swap with every pass)"""
+        a, b = C.c_void_p(), C.c_void_p()
+        _ck(self._L.taulap_state_ptrs(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def step(self, n=1):
         _ck(self._L.taulap_step(self._h, n))
