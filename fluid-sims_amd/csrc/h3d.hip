@@ -238,6 +238,41 @@ __device__ __forceinline__ void weno_face(float v0, float v1, float v2, float v3
   }
 }
 
+// x faces of the own cells, one lane per cell along x: the LEFT state of face i-1/2 is built on the three stencils
+// of cell i-1 — exactly the stencils lane i-1 has just weighted for ITS right state (in mirrored order).  So a lane
+// computes the un-normalised weights w_k (without the c_k) of its own cell only and takes the left ones from lane
+// i-1 with a DPP wave shift: per variable 3 v_mov_dpp instead of one second difference, three smoothness
+// indicators and their weights.  Lanes at tx = 0 receive another row's values: their face is not used (the
+// tile's low-x edge faces are done with weno_face in the edge round).
+__device__ __forceinline__ float lane_below(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+template <bool FAST>
+__device__ __forceinline__ void weno_face_xshare(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
+                                                 float &R) {
+  const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
+  const float sB = sd_term<FAST>(D2 - D1), sC = sd_term<FAST>(D3 - D2), sD = sd_term<FAST>(D4 - D3);
+  // own cell (v3): stencils {5,4,3} {4,3,2} {3,2,1}
+  const float t0 = smooth_t<FAST>(sD, 3.f * D3 - D4), t1 = smooth_t<FAST>(sC, D3 + D2), t2 = smooth_t<FAST>(sB, 3.f * D2 - D1);
+  float w0, w1, w2;
+  if (FAST) {
+    const float u0 = t1 * t2, u1 = t0 * t2, u2 = t0 * t1;
+    w0 = u0 * u0; w1 = u1 * u1; w2 = u2 * u2;
+  } else {
+    w0 = inv_sq(t0); w1 = inv_sq(t1); w2 = inv_sq(t2);
+  }
+  {
+    const float a0 = 0.1f * w0, a1 = 0.6f * w1, a2 = 0.3f * w2;
+    const float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
+    R = v3 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+  { // cell v2 = the own cell of the lane below: its stencils {0,1,2} {1,2,3} {2,3,4} are that lane's {3,2,1} {4,3,2} {5,4,3}
+    const float a0 = 0.1f * lane_below(w2), a1 = 0.6f * lane_below(w1), a2 = 0.3f * lane_below(w0);
+    const float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    L = v2 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+}
+
 // cell-centred: m2,m1,c,p1,p2 around a cell -> Lhi = left state at its high face, Rlo = right state at its low face
 template <bool FAST>
 __device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
@@ -398,11 +433,14 @@ __device__ __forceinline__ void solid_override_xy(Prim &L, Prim &R, const float 
 }
 
 // face between line cells v[2] | v[3]; six cells from LDS
-template <bool FAST>
+template <bool FAST, bool XSHARE = false>
 __device__ __forceinline__ Cons face_flux6(const Args &A, const float (&v)[6][6], unsigned s, int axis) {
   Prim L, R;
 #pragma unroll
-  for (int m = 0; m < 6; m++) weno_face<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+  for (int m = 0; m < 6; m++) {
+    if (XSHARE) weno_face_xshare<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+    else weno_face<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+  }
   solid_override(L, R, v[2], v[3], s, axis);
   prim_floor(L);
   prim_floor(R);
@@ -558,9 +596,11 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
         for (int m = 0; m < 6; m++) v[k][m] = sP[m][lc + (k - 3)];
         s |= (unsigned)sS[lc + (k - 3)] << k;
       }
-      Cons F = face_flux6<FAST>(A, v, s, 0);
+      Cons F = face_flux6<FAST, true>(A, v, s, 0);
+      if (tx != 0) {      // the left state of column 0 came from another row: that face belongs to the edge round
 #pragma unroll
-      for (int m = 0; m < 6; m++) sFx[m][ty][tx] = F.c[m];
+        for (int m = 0; m < 6; m++) sFx[m][ty][tx] = F.c[m];
+      }
     }
     {
       float v[6][6];
@@ -575,12 +615,12 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
 #pragma unroll
       for (int m = 0; m < 6; m++) sFy[m][ty][tx] = F.c[m];
     }
-    // far-edge faces of the tile: 8 x-faces at column TX, 32 y-faces at row TY — one extra
+    // edge faces of the tile: 8 x-faces at column TX, 32 y-faces at row TY, 8 x-faces at column 0 — one extra
     // round of one wave, axis is lane-varying
-    if (wave == (z & (NT / 64 - 1)) && lane < TY + TX) { // the wave that takes the extra round rotates with z: SIMD balance
-      const bool isx = lane < TY;
-      const int ey = isx ? lane : TY;
-      const int ex = isx ? TX : (lane - TY);
+    if (wave == (z & (NT / 64 - 1)) && lane < 2 * TY + TX) { // the wave that takes the extra round rotates with z: SIMD balance
+      const bool isx = lane < TY || lane >= TY + TX;
+      const int ey = lane < TY ? lane : (lane < TY + TX ? TY : lane - (TY + TX));
+      const int ex = lane < TY ? TX : (lane < TY + TX ? lane - TY : 0);
       const int st = isx ? 1 : PXS;
       const int c0 = (ey + HALO) * PXS + (ex + HALO);
       float v[6][6];
@@ -600,7 +640,7 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
       Cons F = hllc(A, L, R, isx ? 0 : 1);
       if (isx) {
 #pragma unroll
-        for (int m = 0; m < 6; m++) sFx[m][ey][TX] = F.c[m];
+        for (int m = 0; m < 6; m++) sFx[m][ey][ex] = F.c[m];
       } else {
 #pragma unroll
         for (int m = 0; m < 6; m++) sFy[m][TY][ex] = F.c[m];
