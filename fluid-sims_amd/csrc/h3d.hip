@@ -29,6 +29,7 @@
 #include "../../include/taueng.h"
 #include "tau_common.h"
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <new>
 #include <type_traits>
@@ -60,12 +61,16 @@ struct DevClock {
   float t, d_tau, dt, gain, maxs_last;
   int step;
   float cfl;
+  unsigned pad_;        // keeps the two words below on a 32-byte boundary (they are handed to RCCL as one tensor)
   // ---- tau3d_set_clock writes the words above only
   unsigned maxs_bits;   // max wavespeed of the step in flight, as float bits (>0 floats order as uints)
   unsigned fmax_bits;   // largest |primitive| written by the step in flight (same encoding).  The word after
                         // maxs_bits: tau3d_max_ptr hands out both and a slab ring all-reduces them together
   float fmax_in;        // largest |primitive| in the state the next k_step reads (committed by clock_begin)
 };
+
+static_assert(offsetof(DevClock, maxs_bits) % 32 == 0 && offsetof(DevClock, fmax_bits) == offsetof(DevClock, maxs_bits) + 4,
+              "tau3d_max_ptr hands out {maxs_bits, fmax_bits} as one aligned 2-word tensor");
 
 // kernel arguments (by value -> SGPRs)
 struct Args {
@@ -1163,7 +1168,7 @@ extern "C" int tau3d_set_clock(tau3d_t *h, const tau3d_clock *in) {
   h->end_pending = false;   // whatever was pending is overwritten
   h3d::DevClock c;
   c.t = in->t; c.d_tau = in->d_tau; c.dt = in->dt; c.gain = in->gain; c.maxs_last = in->maxs;
-  c.step = in->step; c.maxs_bits = 0u; c.cfl = h->p.cfl;
+  c.step = in->step; c.maxs_bits = 0u; c.cfl = h->p.cfl; c.pad_ = 0u;
   TAU_HIP(hipMemcpyAsync(h->clk, &c, offsetof(h3d::DevClock, fmax_bits), hipMemcpyHostToDevice, h->stream));
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
