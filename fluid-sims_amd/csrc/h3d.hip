@@ -37,8 +37,16 @@
 namespace h3d {
 
 constexpr int HALO = 3;            // WENO_HALO, tau_hypersonic_3d_cuda.cu:58
-constexpr int TX = 32, TY = 8;     // workgroup tile in (x, y)
-constexpr int NT = TX * TY;        // 256 threads = 4 waves
+// TY = 12 (six waves: the 56 edge faces would be shared by six waves instead of 48 by four) was measured: a
+// six-wave workgroup lands 2+2+1+1 on the four SIMDs and a second one no longer fits under the 3-waves-per-SIMD
+// register limit — 9.2 Gcell/s against 16.0.
+#ifndef TAU3D_TY
+#define TAU3D_TY 8
+#endif
+constexpr int TX = 32, TY = TAU3D_TY; // workgroup tile in (x, y)
+constexpr int NT = TX * TY;        // threads: TY / 2 waves
+constexpr int NW = NT / 64;
+static_assert(TY % 2 == 0 && 2 * TY + TX <= 64 && 2 * HALO * (TX + TY) <= NT, "edge round is one wave, halo decode one round");
 constexpr int PX = TX + 2 * HALO;  // 38
 constexpr int PY = TY + 2 * HALO;  // 14
 constexpr int PXS = 40;            // padded LDS row stride (floats)
@@ -622,7 +630,7 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
     }
     // edge faces of the tile: 8 x-faces at column TX, 32 y-faces at row TY, 8 x-faces at column 0 — one extra
     // round of one wave, axis is lane-varying
-    if (wave == (z & (NT / 64 - 1)) && lane < 2 * TY + TX) { // the wave that takes the extra round rotates with z: SIMD balance
+    if (wave == (int)((unsigned)z % (unsigned)NW) && lane < 2 * TY + TX) { // the wave that takes the extra round rotates with z: SIMD balance
       const bool isx = lane < TY || lane >= TY + TX;
       const int ey = lane < TY ? lane : (lane < TY + TX ? TY : lane - (TY + TX));
       const int ex = lane < TY ? TX : (lane < TY + TX ? lane - TY : 0);
@@ -762,7 +770,9 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
   if (lane == 0) { sRed[0][wave] = smax; sRed[1][wave] = fmx; }
   __syncthreads();
   if (tid < 2) {
-    float m = fmaxf(fmaxf(sRed[tid][0], sRed[tid][1]), fmaxf(sRed[tid][2], sRed[tid][3]));
+    float m = sRed[tid][0];
+#pragma unroll
+    for (int k = 1; k < NW; k++) m = fmaxf(m, sRed[tid][k]);
     tau::atomic_max_float_bits(tid ? &A.clk->fmax_bits : &A.clk->maxs_bits, m);
   }
 }
