@@ -36,16 +36,17 @@ constexpr int RW = TX + 2, RH = TY + 2;             // updated values: tile + ri
 enum { K_BURGERS = 0, K_SW = 1 };
 
 struct DevState {
-  unsigned maxbits[2];   // wavespeed metric of the state on each ping-pong side (float bits)
+  // wavespeed metric (float bits), three slots in rotation: step s reads slot s % 3 (its input state), reduces the
+  // state it writes into slot (s+1) % 3 and clears slot (s+2) % 3 for the step after — no kernel between steps
+  unsigned maxbits[3];
   float dt_last;
-  int pad;
 };
 
 struct Args {
   const float *in[3];
   float *out[3];
   DevState *st;
-  int nx, ny, ntx, nty, cur;
+  int nx, ny, ntx, nty, slot;
   float dx, dy, invdx, invdy, invdx2, invdy2, nu, u0, inv_u0, g, CFL, dt_try, dt_explicit, cfl_len;
   int muscl, oneD, do_visc, reduce;
   float visc_frac;       // dt fraction of the fused viscosity pass (1/K)
@@ -134,9 +135,13 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
   float dt; // dt_eff = min(t*dtau, CFL*len/max), tau_burgers.cu:693-694, tau_shallow_water.cu:689-690
   if (A.dt_explicit > 0.f) dt = A.dt_explicit;
   else {
-    float m = __uint_as_float(A.st->maxbits[A.cur]);
+    float m = __uint_as_float(A.st->maxbits[A.slot]);
     if (!(m >= 1e-12f)) m = 1e-12f;
     dt = fminf(A.dt_try, A.CFL * A.cfl_len / m);
+  }
+  if (blockIdx.x == 0 && tid == 0) { // the step's bookkeeping (was a 1-thread kernel of its own)
+    A.st->dt_last = dt;
+    A.st->maxbits[(A.slot + 2) % 3] = 0u;
   }
 
   for (int t = tid; t < UH * UW; t += NT) {
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
     __syncthreads();
     if (tid == 0) {
       float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-      tau::atomic_max_float_bits(&A.st->maxbits[A.cur ^ 1], m);
+      tau::atomic_max_float_bits(&A.st->maxbits[(A.slot + 1) % 3], m);
     }
   }
 }
@@ -295,17 +300,6 @@ __global__ __launch_bounds__(256) void k_metric(const Args A, int slot) {
   }
 }
 
-__global__ void k_prepare(DevState *s, int cur, float dt_try, float CFLlen, float dt_explicit) {
-  float dt = dt_explicit;
-  if (!(dt > 0.f)) {
-    float m = __uint_as_float(s->maxbits[cur]);
-    if (!(m >= 1e-12f)) m = 1e-12f;
-    dt = fminf(dt_try, CFLlen / m);
-  }
-  s->dt_last = dt;
-  s->maxbits[cur ^ 1] = 0u;
-}
-
 } // namespace fl2
 
 // =====================================================================================
@@ -320,6 +314,7 @@ struct tauflow {
   fl2::DevState *st;
   int cur;
   bool max_valid;
+  int slot;          // max slot of the current state (DevState::maxbits)
   float t, tau;
   long step;
   taulap_t *visc;   // Burgers: extra viscosity passes (K > 1) through the marching kernel
@@ -348,7 +343,7 @@ extern "C" int tauflow_create(tauflow_t **out, const tauflow_params *P, int kind
   tauflow *h = new (std::nothrow) tauflow();
   if (!h) return tau::fail("tauflow_create: out of host memory");
   tau::HandleGuard<tauflow> guard{h, tauflow_destroy};
-  h->p = *P; h->kind = kind; h->nf = kind == 0 ? 2 : 3; h->device = device; h->cur = 0; h->max_valid = false;
+  h->p = *P; h->kind = kind; h->nf = kind == 0 ? 2 : 3; h->device = device; h->cur = 0; h->slot = 0; h->max_valid = false;
   if (kind == 0 && h->p.oneD) h->p.ny = 1; // tau_burgers.cu:654-655
   h->own_stream = (stream == nullptr);
   if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
@@ -448,7 +443,7 @@ static void flow_args(tauflow *h, fl2::Args &A, float dt_explicit) {
   memset(&A, 0, sizeof(A));
   for (int f = 0; f < h->nf; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.st = h->st; A.nx = P.nx; A.ny = P.ny; A.ntx = (P.nx + fl2::TX - 1) / fl2::TX; A.nty = (P.ny + fl2::TY - 1) / fl2::TY;
-  A.cur = h->cur; A.dx = P.dx; A.dy = P.dy; A.invdx = 1.0f / P.dx; A.invdy = 1.0f / P.dy;
+  A.slot = h->slot; A.dx = P.dx; A.dy = P.dy; A.invdx = 1.0f / P.dx; A.invdy = 1.0f / P.dy;
   A.invdx2 = 1.0f / (P.dx * P.dx); A.invdy2 = 1.0f / (P.dy * P.dy);
   A.nu = P.nu; A.u0 = P.u0; A.inv_u0 = 1.0f / P.u0; A.g = P.g; A.CFL = P.CFL;
   A.dt_try = h->t * P.dtau; A.dt_explicit = dt_explicit;
@@ -465,31 +460,30 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
   flow_args(h, A, dt_explicit);
   const tauflow_params &P = h->p;
   if (!h->max_valid) {
-    TAU_HIP(hipMemsetAsync(&h->st->maxbits[h->cur], 0, sizeof(unsigned), h->stream));
-    if (h->kind == 0) hipLaunchKernelGGL(fl2::k_metric<fl2::K_BURGERS>, dim3(1024), dim3(256), 0, h->stream, A, h->cur);
-    else hipLaunchKernelGGL(fl2::k_metric<fl2::K_SW>, dim3(1024), dim3(256), 0, h->stream, A, h->cur);
+    TAU_HIP(hipMemsetAsync(h->st->maxbits, 0, sizeof(h->st->maxbits), h->stream));
+    if (h->kind == 0) hipLaunchKernelGGL(fl2::k_metric<fl2::K_BURGERS>, dim3(1024), dim3(256), 0, h->stream, A, h->slot);
+    else hipLaunchKernelGGL(fl2::k_metric<fl2::K_SW>, dim3(1024), dim3(256), 0, h->stream, A, h->slot);
     TAU_LAUNCH_CHECK("fl2::k_metric");
     h->max_valid = true;
   }
-  hipLaunchKernelGGL(fl2::k_prepare, dim3(1), dim3(1), 0, h->stream, h->st, h->cur, A.dt_try, A.CFL * A.cfl_len, dt_explicit);
-  TAU_LAUNCH_CHECK("fl2::k_prepare");
   const unsigned nb = (unsigned)(A.ntx * A.nty);
   if (h->kind == 0 && A.muscl) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, true>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   else if (h->kind == 0) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   else hipLaunchKernelGGL((fl2::k_step<fl2::K_SW, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   TAU_LAUNCH_CHECK("fl2::k_step");
   h->cur ^= 1;
+  h->slot = (h->slot + 1) % 3;
   const int K = (h->kind == 0) ? (P.visc_substeps > 0 ? P.visc_substeps : 1) : 1;
   if (K > 1) { // remaining viscosity passes (marching kernel), then the metric of the final state
     for (int k = 1; k < K; k++) {
       if (tau::st2_burgers_pass(h->buf[h->cur][0], h->buf[h->cur][1], h->buf[h->cur ^ 1][0], h->buf[h->cur ^ 1][1], P.nx,
-                                P.ny, P.dx, P.dy, P.nu, P.u0, P.oneD, h->st, 1.0f / (float)K, h->stream)) return 1;
+                                P.ny, P.dx, P.dy, P.nu, P.u0, P.oneD, &h->st->dt_last, 1.0f / (float)K, h->stream)) return 1;
       h->cur ^= 1;
     }
     fl2::Args B;
     flow_args(h, B, 0.f);
-    TAU_HIP(hipMemsetAsync(&h->st->maxbits[h->cur], 0, sizeof(unsigned), h->stream));
-    hipLaunchKernelGGL(fl2::k_metric<fl2::K_BURGERS>, dim3(1024), dim3(256), 0, h->stream, B, h->cur);
+    TAU_HIP(hipMemsetAsync(&h->st->maxbits[h->slot], 0, sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(fl2::k_metric<fl2::K_BURGERS>, dim3(1024), dim3(256), 0, h->stream, B, h->slot);
     TAU_LAUNCH_CHECK("fl2::k_metric");
   }
   return 0;
@@ -528,7 +522,7 @@ extern "C" int tauflow_get_clock(tauflow_t *h, float *t, float *tau, float *dt_l
   if (t) *t = h->t;
   if (tau) *tau = h->tau;
   if (dt_last) *dt_last = s.dt_last;
-  if (wavespeed) memcpy(wavespeed, &s.maxbits[h->cur], 4);
+  if (wavespeed) memcpy(wavespeed, &s.maxbits[h->slot], 4);
   if (step) *step = h->step;
   return 0;
 }

@@ -35,7 +35,10 @@ struct P4 { float r, u, v, p; };
 struct C4 { float r, mx, my, E; };
 
 struct DevState {
-  unsigned maxs_bits[2];  // max wavespeed of the state each ping-pong side holds (float bits)
+  // max wavespeed (float bits), three slots in rotation: step s reads slot s % 3 (its input state), reduces the
+  // state it writes into slot (s+1) % 3 and clears slot (s+2) % 3 for the step after — no kernel between steps
+  unsigned maxs_bits[3];
+  unsigned pad_;
   double t;
   float dt_last;
   int step;
@@ -47,7 +50,7 @@ struct Args {
   const uint8_t *mask;
   DevState *st;
   int W, H, ntx, nty;
-  int cur;                 // which maxs slot belongs to the input state
+  int slot;                // which maxs slot belongs to the input state
   float dt_explicit;       // > 0: use this dt instead of the CFL one
   float gamma, gm1, inv_gm1, cfl, dt_diff;
   float visc_nu, visc_rho, visc_e;
@@ -273,11 +276,17 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
   float dt;
   if (A.dt_explicit > 0.f) dt = A.dt_explicit;
   else {
-    float maxs = __uint_as_float(A.st->maxs_bits[A.cur]);
+    float maxs = __uint_as_float(A.st->maxs_bits[A.slot]);
     if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
     dt = fminf(A.cfl / maxs, A.dt_diff);
   }
   const float half = 0.5f * dt;
+  if (blockIdx.x == 0 && tid == 0) { // the step's bookkeeping (was a 1-thread kernel of its own): sim_t += dt, :1888
+    A.st->t += (double)dt;
+    A.st->dt_last = dt;
+    A.st->step += 1;
+    A.st->maxs_bits[(A.slot + 2) % 3] = 0u;
+  }
 
   // ---- A: stage the conserved state, halo 2, clamped like the reference's tile load (:877-901);
   //         the inflow column overwrite of k_apply_inflow_left happens here
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
   __syncthreads();
   if (tid == 0) {
     float m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-    tau::atomic_max_float_bits(&A.st->maxs_bits[A.cur ^ 1], m);
+    tau::atomic_max_float_bits(&A.st->maxs_bits[(A.slot + 1) % 3], m);
   }
 }
 
@@ -408,22 +417,8 @@ __global__ __launch_bounds__(256) void k_maxspeed(const Args A) {
   __syncthreads();
   if (threadIdx.x == 0) {
     m = fmaxf(fmaxf(sRed[0], sRed[1]), fmaxf(sRed[2], sRed[3]));
-    tau::atomic_max_float_bits(&A.st->maxs_bits[A.cur], m);
+    tau::atomic_max_float_bits(&A.st->maxs_bits[A.slot], m);
   }
-}
-
-// bookkeeping before a step: t += dt, zero the slot the step will reduce into
-__global__ void k_prepare(DevState *s, int cur, float cfl, float dt_diff, float dt_explicit) {
-  float dt = dt_explicit;
-  if (!(dt > 0.f)) {
-    float maxs = __uint_as_float(s->maxs_bits[cur]);
-    if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
-    dt = fminf(cfl / maxs, dt_diff);
-  }
-  s->t += (double)dt;
-  s->dt_last = dt;
-  s->step += 1;
-  s->maxs_bits[cur ^ 1] = 0u;
 }
 
 // ---- device self-test: the kernel's own helpers evaluated on the known answers of the
@@ -529,6 +524,7 @@ struct tauh2 {
   uint8_t *mask;
   h2d::DevState *st;
   int cur;
+  int slot = 0;      // max slot of the current state (DevState::maxs_bits)
   bool maxs_valid;
   h2d::Args base;
   float *rval;              // render scalar per cell (lazy)
@@ -684,18 +680,17 @@ extern "C" int tauh2_init(tauh2_t *h) { // k_init, :740-770 (geometry on the hos
 static int h2_launch_step(tauh2 *h, float dt_explicit) {
   h2d::Args A = h->base;
   for (int f = 0; f < 4; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
-  A.cur = h->cur; A.dt_explicit = dt_explicit;
+  A.slot = h->slot; A.dt_explicit = dt_explicit;
   if (!h->maxs_valid) { // first step after init / upload: one reduction pass
-    TAU_HIP(hipMemsetAsync(&h->st->maxs_bits[h->cur], 0, sizeof(unsigned), h->stream));
+    TAU_HIP(hipMemsetAsync(h->st->maxs_bits, 0, sizeof(h->st->maxs_bits), h->stream));
     hipLaunchKernelGGL(h2d::k_maxspeed, dim3(2048), dim3(256), 0, h->stream, A);
     TAU_LAUNCH_CHECK("h2d::k_maxspeed");
     h->maxs_valid = true;
   }
-  hipLaunchKernelGGL(h2d::k_prepare, dim3(1), dim3(1), 0, h->stream, h->st, h->cur, A.cfl, A.dt_diff, dt_explicit);
-  TAU_LAUNCH_CHECK("h2d::k_prepare");
   hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);
   TAU_LAUNCH_CHECK("h2d::k_step");
   h->cur ^= 1; // swap_Us, :1378-1392
+  h->slot = (h->slot + 1) % 3;
   return 0;
 }
 
@@ -717,7 +712,7 @@ extern "C" int tauh2_get_time(tauh2_t *h, double *t, double *dt_last, double *ma
   TAU_HIP(hipStreamSynchronize(h->stream));
   if (t) *t = s.t;
   if (dt_last) *dt_last = s.dt_last;
-  if (maxs) { float m; memcpy(&m, &s.maxs_bits[h->cur], 4); *maxs = m; }
+  if (maxs) { float m; memcpy(&m, &s.maxs_bits[h->slot], 4); *maxs = m; }
   if (step) *step = s.step;
   return 0;
 }

@@ -400,12 +400,12 @@ static int run_steps(Pair *pr, Args A, int nsteps) {
 } // namespace st2
 
 int tau::st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,
-                          float u0, int oneD, const void *flow_state, float frac, hipStream_t stream) {
+                          float u0, int oneD, const float *dt_dev, float frac, hipStream_t stream) {
   st2::Args A{};
   A.a = a; A.b = b; A.oa = oa; A.ob = ob; A.nx = nx; A.ny = ny;
   A.invdx2 = 1.0f / (dx * dx); A.invdy2 = oneD ? 0.0f : 1.0f / (dy * dy);
   A.nudt = nu * frac; A.u0 = u0; A.inv_u0 = 1.0f / u0;
-  A.dt_dev = reinterpret_cast<const float *>(static_cast<const char *>(flow_state) + 2 * sizeof(unsigned)); // DevState::dt_last
+  A.dt_dev = dt_dev;   // fl2::DevState::dt_last of the step in flight
   return st2::launch<st2::K_BURGERS>(A, stream);
 }
 

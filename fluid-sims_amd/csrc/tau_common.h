@@ -60,6 +60,6 @@ __device__ __forceinline__ void atomic_max_float_bits(unsigned *word, float v) {
 // one Burgers viscosity pass through the row-marching kernel (stencil2d.hip) with the time step read
 // from a device word: nu * (*dt_dev) * frac  (used by flow2d.hip for visc_substeps > 1)
 int st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,
-                     float u0, int oneD, const void *flow_state, float frac, hipStream_t stream);
+                     float u0, int oneD, const float *dt_dev, float frac, hipStream_t stream);
 
 } // namespace tau
