@@ -65,6 +65,33 @@ def cpu_baseline_2d(steps=100, n=300):
             "sample": f"tau_hypersonic_simd restated, 2D {n}x{n} fp64, {steps} steps, {el:.2f} s, 1 thread"}
 
 
+def cpu_baseline_2d_all_cores(steps=60, n=300):
+    """SURVEY §8d's optional row: the same single-threaded program as independent replicas on every host core
+    (one solver handle per thread; the C step releases the GIL), aggregate rate."""
+    import threading
+    from importlib import import_module
+    m = import_module("fluid_sims_amd.cpu2d")
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sims = [m.CpuHypersonic2D(n, n, simd=True) for _ in range(cores)]
+    gate = threading.Barrier(cores + 1)
+
+    def work(s):
+        gate.wait()
+        s.step(steps)
+
+    th = [threading.Thread(target=work, args=(s,)) for s in sims]
+    for t in th:
+        t.start()
+    gate.wait()
+    t0 = time.perf_counter()
+    for t in th:
+        t.join()
+    el = time.perf_counter() - t0
+    return {"value": cores * n * n * steps / el / 1e9, "unit": "Gcell-updates/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} independent replicas of tau_hypersonic_simd restated (one per core), 2D {n}x{n} fp64, "
+                      f"{steps} steps each, {el:.2f} s"}
+
+
 def input_variants(f, n, steps=6):
     """SURVEY §8d asks for two more inputs beside the headline one: (i) the reference's own quiescent k_init
     start after 50 controller warm-up steps, and a no-body variant that bounds the branch-free throughput."""
@@ -213,6 +240,7 @@ def main():
             try:
                 out["cpu_baseline_2d_simd"] = cpu_baseline_2d()
                 out["cpu_baseline_2d_simd_256"] = cpu_baseline_2d(n=256)      # BASELINE config 1 size
+                out["cpu_baseline_2d_simd_all_cores"] = cpu_baseline_2d_all_cores()
             except Exception as e:  # the 2D CPU program is an extra, never fatal for the headline
                 out["cpu_baseline_2d_simd"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
