@@ -72,6 +72,13 @@ def cpu_baseline_2d_all_cores(steps=60, n=300):
     from importlib import import_module
     m = import_module("fluid_sims_amd.cpu2d")
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:  # a container's CPU quota is what it can really use, whatever the affinity mask says
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(float(q) / float(per) + 0.5)))
+    except Exception:
+        pass
+    cores = min(cores, 64)   # bounds the run time when the quota cannot be read
     sims = [m.CpuHypersonic2D(n, n, simd=True) for _ in range(cores)]
     gate = threading.Barrier(cores + 1)
 
