@@ -20,5 +20,5 @@ for world in (8, 4, 2):
             be.clock_end()
     step(5); be.sync()
     t0 = time.perf_counter(); step(20); be.sync(); el = (time.perf_counter() - t0) / 20
-    print("world %d: slab %d planes, %.3f ms/step per rank (no comm)  -> %.1f Gcell/s aggregate if comm hides, ideal %.3f ms" % (world, nzl, el * 1e3, n**3 / el / 1e9, 9.06 / world))
+    print("world %d: slab %d planes, %.3f ms/step per rank (no comm)  -> %.1f Gcell/s aggregate if comm hides, ideal %.3f ms" % (world, nzl, el * 1e3, n**3 / el / 1e9, 8.40 / world))
     del be
