@@ -140,9 +140,9 @@ struct Stage {
   int base[3], len[3], delta[3];
   bool on;
 };
-__device__ __forceinline__ Stage make_stage(const Args &A, int k0) {
+__device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw) {
   Stage st;
-  const int kl = min(k0 + 255, A.N - 1);
+  const int kl = min(k0 + ppw - 1, A.N - 1);
   const int c0 = (int)A.keys_s[k0], c1 = (int)A.keys_s[kl];
   const int gy = c0 / A.Gx;
   const int cxa = max(c0 - gy * A.Gx - 1, 0), cxb = min(c1 - gy * A.Gx + 1, A.Gx - 1);
@@ -160,20 +160,26 @@ __device__ __forceinline__ Stage make_stage(const Args &A, int k0) {
   return st;
 }
 
-// iterate the set bits of this lane's NW mask words (column `tid` of sM) in ascending candidate order
-template <class F>
-__device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int tid, const Walk &wk, F &&body) {
-  int w = 0;
-  unsigned m = sM[0][tid];
+// Lanes per particle.  LPP = 1: one lane walks all NW mask words of its particle.  LPP = 4 (small N: 65 536
+// particles are one wave per SIMD otherwise, and a lone wave issues its dependent chain at a fraction of the VALU
+// rate): four consecutive lanes share a particle, lane `sub` owns word `sub` of each of the three row ranges
+// (words sub, sub + 4, sub + 8) and every fourth 32-candidate block of the overflow; the partial sums meet in a
+// quad reduction.  The masks in LDS and in nbrMask are indexed by particle either way.
+//
+// iterate the set bits of this lane's mask words (column `pl` of sM) in ascending candidate order
+template <int LPP, class F>
+__device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int pl, int sub, const Walk &wk, F &&body) {
+  int w = sub;
+  unsigned m = sM[w][pl];
   const int b0 = wk.jb[0], d1 = wk.jb[1] - wk.jb[0], d2 = wk.jb[2] - wk.jb[1];
-  int wbase = b0;
+  int wbase = b0 + ((w & (WPR - 1)) << 5);
   // One straight-line step per trip: a lane whose word ran dry fetches its next word (an empty word costs
   // that lane one idle trip), then every lane holding a bit evaluates it.  No inner loop: the other lanes
   // of the wave would only wait for it.
-  while (m != 0u || w < NW - 1) {
+  while (m != 0u || w + LPP < NW) {
     if (m == 0u) {
-      ++w;
-      m = sM[w][tid];
+      w += LPP;
+      m = sM[w][pl];
       // (two independent selects: a chained select over jb[] is turned into a 3-entry table in scratch memory,
       // and the load sits on the critical path of every word fetch)
       wbase = b0 + (w >= WPR ? d1 : 0) + (w >= 2 * WPR ? d2 : 0) + ((w & (WPR - 1)) << 5);
@@ -185,17 +191,24 @@ __device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int tid,
     }
   }
 }
-// the candidates of over-full rows that the mask does not cover
-template <class F>
-__device__ __forceinline__ void for_each_overflow(const Walk &wk, F &&body) {
+// the candidates of over-full rows that the mask does not cover (32-candidate blocks dealt round-robin to the lanes)
+template <int LPP, class F>
+__device__ __forceinline__ void for_each_overflow(const Walk &wk, int sub, F &&body) {
 #pragma unroll
   for (int r = 0; r < 3; r++)
-    for (int j = wk.jb[r] + ROWCAP; j < wk.jb[r] + wk.jn[r]; j++) body(j);
+    for (int blk = WPR + sub; blk * 32 < wk.jn[r]; blk += LPP) {
+      const int j0 = wk.jb[r] + blk * 32, j1 = wk.jb[r] + min(blk * 32 + 32, wk.jn[r]);
+      for (int j = j0; j < j1; j++) body(j);
+    }
+}
+template <int LPP> __device__ __forceinline__ float quad_sum(float v) {
+  if (LPP == 4) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); }
+  return v;
 }
 
 // density of one particle; P indexes candidate positions (LDS slots or sorted records — wk is in the same space)
-template <class PosArr>
-__device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], int tid, int k, const Walk &wk,
+template <int LPP, class PosArr>
+__device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], int pl, int sub, int k, const Walk &wk,
                                             float2 me, PosArr P) {
   const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
   const float ih = 1.0f / A.h;
@@ -204,7 +217,7 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
 #pragma unroll
   for (int r = 0; r < 3; r++) {
 #pragma unroll 1
-    for (int w = 0; w < WPR; w++) {
+    for (int w = sub; w < WPR; w += LPP) {
       const int base = wk.jb[r] + 32 * w;
       const int cnt = min(max(wk.jn[r] - 32 * w, 0), 32);
       unsigned m = 0u;                     // built MSB-last: m = 2 m + hit is one add-with-carry per candidate
@@ -216,7 +229,7 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
         m = m + m + ((r2 < twoh2) ? 1u : 0u);
       }
       m = cnt ? (__builtin_bitreverse32(m) >> (32 - cnt)) : 0u;   // candidate b -> bit b
-      sM[r * WPR + w][tid] = m;
+      sM[r * WPR + w][pl] = m;
       A.nbrMask[(size_t)(r * WPR + w) * A.N + k] = m;
     }
   }
@@ -227,37 +240,40 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
     const float r2 = dx * dx + dy * dy;
     rho += A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
   };
-  for_each_hit(sM, tid, wk, add);
-  for_each_overflow(wk, [&](int j) {
+  for_each_hit<LPP>(sM, pl, sub, wk, add);
+  for_each_overflow<LPP>(wk, sub, [&](int j) {
     const float2 o = P[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
     if (dx * dx + dy * dy < twoh2) add(j);
   });
-  return rho;
+  return quad_sum<LPP>(rho);
 }
 
+template <int LPP>
 __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pressure_cell, :178-213
+  constexpr int PPW = 256 / LPP;      // particles per workgroup
   __shared__ unsigned sM[NW][256];
   __shared__ float2 sP[CAP];
-  const int tid = threadIdx.x, k0 = blockIdx.x * 256, k = k0 + tid;
-  const Stage st = make_stage(A, k0);
+  const int tid = threadIdx.x, pl = tid / LPP, sub = tid % LPP, k0 = blockIdx.x * PPW, k = k0 + pl;
+  const Stage st = make_stage(A, k0, PPW);
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++)
       for (int i = tid; i < st.len[r]; i += 256) sP[st.base[r] + st.delta[r] + i] = A.recP[st.base[r] + i];
     __syncthreads();
   }
-  if (k >= A.N) return;
+  if (k >= A.N) return;                // whole quads leave together (k is the same for the LPP lanes)
   const float2 me = A.recP[k];
   Walk wk = make_walk(A, k);
   float rho;
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    rho = density_of(A, sM, tid, k, wk, me, (const float2 *)sP);
+    rho = density_of<LPP>(A, sM, pl, sub, k, wk, me, (const float2 *)sP);
   } else {
-    rho = density_of(A, sM, tid, k, wk, me, (const float2 *)A.recP);
+    rho = density_of<LPP>(A, sM, pl, sub, k, wk, me, (const float2 *)A.recP);
   }
+  if (sub != 0) return;
   const float si = logf(fmaxf(rho, 1e-6f));
   rho = expf(si);
   const float ratio = rho / A.rho0;
@@ -270,8 +286,8 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
 }
 
 // acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
-template <class ArrA, class ArrB>
-__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], int tid, int kk, const Walk &wk,
+template <int LPP, class ArrA, class ArrB>
+__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], int pl, int sub, int kk, const Walk &wk,
                                            float4 me, float2 meB, ArrA RA, ArrB RB) {
   const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
   const float ih = 1.0f / h;
@@ -305,21 +321,23 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], i
     ax += coef * gwx;
     ay += coef * gwy;
   };
-  for_each_hit(sM, tid, wk, add);
-  for_each_overflow(wk, [&](int j) {
+  for_each_hit<LPP>(sM, pl, sub, wk, add);
+  for_each_overflow<LPP>(wk, sub, [&](int j) {
     const float4 o = RA[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
     if (dx * dx + dy * dy < twoh2) add(j);
   });
-  return make_float2(ax, ay);
+  return make_float2(quad_sum<LPP>(ax), quad_sum<LPP>(ay));
 }
 
+template <int LPP>
 __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell :215-272 + k_integrate :324-355
+  constexpr int PPW = 256 / LPP;
   __shared__ unsigned sM[NW][256];
   __shared__ float4 sA[CAP];
   __shared__ float2 sB[CAP];
-  const int tid = threadIdx.x, k0 = blockIdx.x * 256, k = k0 + tid;
-  const Stage st = make_stage(A, k0);
+  const int tid = threadIdx.x, pl = tid / LPP, sub = tid % LPP, k0 = blockIdx.x * PPW, k = k0 + pl;
+  const Stage st = make_stage(A, k0, PPW);
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   }
   if (k >= A.N) return;
 #pragma unroll
-  for (int w = 0; w < NW; w++) sM[w][tid] = A.nbrMask[(size_t)w * A.N + k];
+  for (int w = sub; w < NW; w += LPP) sM[w][pl] = A.nbrMask[(size_t)w * A.N + k];   // only the words this lane walks
   const float4 me = A.recA[k];
   const float2 meB = A.recB[k];
   Walk wk = make_walk(A, k);
@@ -339,10 +357,11 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    a = accel_of(A, sM, tid, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+    a = accel_of<LPP>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
   } else {
-    a = accel_of(A, sM, tid, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+    a = accel_of<LPP>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
   }
+  if (sub != 0) return;
   float ax = a.x, ay = a.y;
   if (A.useGrav) { ax += A.gx; ay += A.gy; }
   const unsigned id = A.ids_s[k];
@@ -454,6 +473,7 @@ struct tausph {
   long rain_spawned;
   int *raster;
   size_t raster_n;
+  int lpp;           // lanes per particle of the density / force passes (1 or 4)
 };
 
 extern "C" void tausph_params_default(tausph_params *P, int N) { // tau_sph.cu:49-85
@@ -509,6 +529,11 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipMemsetAsync(A.acc, 0, N * sizeof(float2), h->stream));
   TAU_HIP(hipMemsetAsync(A.s, 0, N * sizeof(float), h->stream));
   TAU_HIP(hipMemsetAsync(A.press, 0, N * sizeof(float), h->stream));
+  // one lane per particle does not fill 1 024 SIMDs below ~100 k particles (lattice sub-step, 1 vs 4 lanes: 4 096:
+  // 110 vs 69 us, 65 536: 134 vs 112 us, 262 144: 226 vs 289 us; the reference's compressed default run at 65 536:
+  // 0.64-0.87 vs 0.29-0.45 ms)
+  h->lpp = (P->N < (1 << 17)) ? 4 : 1;
+  if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 4) h->lpp = v; }
   h->key_bits = 1;
   while ((1 << h->key_bits) < A.M) h->key_bits++;
   h->cub_tmp = nullptr; h->cub_bytes = 0;
@@ -604,10 +629,19 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
   TAU_LAUNCH_CHECK("sph::k_cell_start");
   hipLaunchKernelGGL(sph::k_gather, dim3(gs), dim3(256), 0, h->stream, A);
   TAU_LAUNCH_CHECK("sph::k_gather");
-  hipLaunchKernelGGL(sph::k_density, dim3(gs), dim3(256), 0, h->stream, A);
-  TAU_LAUNCH_CHECK("sph::k_density");
-  hipLaunchKernelGGL(sph::k_forces, dim3(gs), dim3(256), 0, h->stream, A);
-  TAU_LAUNCH_CHECK("sph::k_forces");
+  // four lanes per particle while there are too few particles to fill the chip with one
+  if (h->lpp == 4) {
+    const unsigned gq = (unsigned)((A.N + 63) / 64);
+    hipLaunchKernelGGL(sph::k_density<4>, dim3(gq), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_density");
+    hipLaunchKernelGGL(sph::k_forces<4>, dim3(gq), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_forces");
+  } else {
+    hipLaunchKernelGGL(sph::k_density<1>, dim3(gs), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_density");
+    hipLaunchKernelGGL(sph::k_forces<1>, dim3(gs), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_forces");
+  }
   if (A.recA2) { // :698-704
     hipLaunchKernelGGL(sph::k_xsph, dim3(gs), dim3(256), 0, h->stream, A);
     TAU_LAUNCH_CHECK("sph::k_xsph");
