@@ -235,3 +235,35 @@ def test_dense_cluster_takes_the_overflow_path(eng, oracle_built):
     print("cluster parity rho %.2e acc %.2e (tol %.1e), rho range %.3g..%.3g" % (e_rho, e_a, tol, rho_w.min(), rho_w.max()))
     assert e_rho <= tol and e_a <= tol
     e.close()
+
+
+@pytest.mark.parametrize("N,warm", [(4096, 40), (65536, 200), (200000, 3)])
+def test_one_and_four_lanes_per_particle_agree(eng, oracle_built, N, warm):
+    """the density / force passes exist with one lane per particle and with four (chosen by N): both
+    against the oracle on the same state — 65 536 particles after 200 default steps is the compressed regime
+    (hundreds of candidates per row: mask words AND overflow blocks are split over the four lanes)"""
+    base = eng.Sph2D(N)
+    base.reset_particles()
+    base.step(warm)
+    st = base.download()
+    dt = base.dt()
+    base.close()
+    o = oracle_built.OracleSph(N)
+    o.set_state(st["pos"], st["vel"])
+    o.substep(dt)
+    want = o.state()
+    got = {}
+    for lpp in (1, 4):
+        os.environ["TAU_SPH_LPP"] = str(lpp)
+        try:
+            e = eng.Sph2D(N)
+        finally:
+            del os.environ["TAU_SPH_LPP"]
+        e.upload(st["pos"], st["vel"])
+        e.substep(dt)
+        got[lpp] = e.download()
+        compare_substep(got[lpp], want, what=f"N={N} warm={warm} lanes={lpp}", gamma=1.0, c0=1.0, dt=dt)
+        e.close()
+    assert np.array_equal(got[1]["cell"], got[4]["cell"])
+    rho1, rho4 = np.exp(got[1]["s"].astype(np.float64)), np.exp(got[4]["s"].astype(np.float64))
+    assert float((np.abs(rho1 - rho4) / rho1).max()) < 1e-5
