@@ -222,7 +222,7 @@ def main():
                 "kernel": "h3d::k_step", "launches": k_launches,
                 "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(k_launches, 1),
-                "note": "kernel is FP32-VALU bound (WENO5+HLLC, ~2.4k VALU instr/cell executed, ~70 % of the VALU issue peak); the HBM fraction is "
+                "note": "kernel is FP32-VALU bound (WENO5+HLLC, ~2.4k VALU instr/cell executed, ~74 % of the measured v_fma_f32 issue peak); the HBM fraction is "
                         "reported because BASELINE.json's metric asks for it"}
         out = {"metric": "Gcell-updates/s, 3D hypersonic 512^3 fp32", "value": round(value, 4),
                "unit": "Gcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
