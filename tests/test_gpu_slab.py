@@ -76,3 +76,21 @@ def test_rccl_on_aliased_tensors(eng):
         assert be.clock().maxs == before
     finally:
         dist.destroy_process_group()
+
+
+def test_multigpu_driver_script_world1(eng, tmp_path):
+    """scripts/tau3d_multigpu.py with one process (the ring is its own neighbour): same state as bin/tau3d's loop"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "r0.bin"
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "tau3d_multigpu.py"), "--n", "32", "--frames", "3",
+                        "--steps-per-frame", "2", "--dump-rank0", str(out)], capture_output=True, text=True, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "6 steps on 32x32x32 over 1 GPU(s)" in r.stdout and "step 6" in r.stdout
+    got = np.fromfile(out, np.float32).reshape(6, 32, 32, 32)
+    e = eng.Tau3D(32)
+    e.init(0)
+    e.step(6)
+    for g, w in zip(got, e.download()):
+        assert np.array_equal(g, w)
+    e.close()
