@@ -275,6 +275,147 @@ __global__ __launch_bounds__(NT) void k_step(const Args A) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same step as a MARCH (plain Burgers and shallow water; MUSCL keeps the tile kernel above).  A wave owns 60
+// columns (64 lanes, two halo lanes a side — the viscosity stencil of the updated values reaches two cells) and walks
+// down a chunk of rows with everything in registers: per trip it takes in one input row, forms the y-face fluxes
+// between the last two input rows and the x-face fluxes of the older one (left neighbour by lane shift), updates that
+// row, applies the viscosity pass to the row before it from the three updated rows it holds, and stores it.  Every
+// face is evaluated once per wave, nothing goes through LDS, and the arithmetic per cell is the tile kernel's, operand
+// for operand — the results are bit-identical.  Redundancy: 64/60 lanes x (R + 4)/R rows instead of the tile's
+// 432 staged and 340 updated cells per 256.
+constexpr int MCOLS = 60;
+struct MRow { float a, b, c, d; };   // Burgers: u, v ; shallow water: h, u, v, sqrt(g h)
+
+template <int KIND>
+__device__ __forceinline__ MRow march_load(const Args &A, int row, int col, bool ok) {
+  MRow r{0.f, 0.f, 0.f, 0.f};
+  const size_t gi = (size_t)row * A.nx + col;
+  if (KIND == K_BURGERS) {
+    r.a = A.u0 * fsinh(A.in[0][gi]);
+    r.b = A.u0 * fsinh(A.in[1][gi]);
+  } else {
+    r.a = __builtin_amdgcn_exp2f(A.in[0][gi] * 1.44269504088896341f);
+    r.b = A.in[1][gi]; r.c = A.in[2][gi];
+    r.d = __builtin_amdgcn_sqrtf(A.g * r.a);
+  }
+  (void)ok;
+  return r;
+}
+// flux through the face between cell L (low side) and cell R along axis ax: 2 (Burgers) or 3 components
+template <int KIND>
+__device__ __forceinline__ void march_face(const Args &A, const MRow &L, const MRow &R, int ax, float &f0, float &f1, float &f2) {
+  if (KIND == K_BURGERS) {
+    f2 = 0.f;
+    burgers_face<false>(A, 0.f, L.a, R.a, 0.f, 0.f, L.b, R.b, 0.f, ax, f0, f1);
+  } else {
+    float Fh, Fn, Ft;
+    if (ax == 0) sw_face(A.g, L.a, L.b, L.c, L.d, R.a, R.b, R.c, R.d, Fh, Fn, Ft);
+    else sw_face(A.g, L.a, L.c, L.b, L.d, R.a, R.c, R.b, R.d, Fh, Fn, Ft);
+    f0 = Fh; f1 = ax == 0 ? Fn : Ft; f2 = ax == 0 ? Ft : Fn;   // stored as (h, x-momentum, y-momentum)
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstrips, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(nstrips * nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+
+  float dt; // dt_eff = min(t*dtau, CFL*len/max), tau_burgers.cu:693-694, tau_shallow_water.cu:689-690
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float m = __uint_as_float(A.st->maxbits[A.slot]);
+    if (!(m >= 1e-12f)) m = 1e-12f;
+    dt = fminf(A.dt_try, A.CFL * A.cfl_len / m);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // the step's bookkeeping
+    A.st->dt_last = dt;
+    A.st->maxbits[(A.slot + 2) % 3] = 0u;
+  }
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)nstrips), chunk = (int)(wid / (unsigned)nstrips);
+  const int xo = strip * MCOLS + lane - 2;                       // column of this lane, before the periodic wrap
+  const int col = ((xo % A.nx) + A.nx) % A.nx;
+  const bool own = lane >= 2 && lane < 2 + MCOLS && xo < A.nx;   // the lanes that store
+  const int j0 = chunk * rows, j1 = min(j0 + rows, A.ny);
+  const bool oneD = (KIND == K_BURGERS) && A.oneD;
+  const float invdy = oneD ? 0.0f : A.invdy;
+  const float invdy2 = oneD ? 0.0f : A.invdy2;
+  const float nudt = A.nu * (dt * A.visc_frac);
+
+  auto wrapy = [&](int r) { return ((r % A.ny) + A.ny) % A.ny; };
+  MRow P{0.f, 0.f, 0.f, 0.f};       // input row r-1
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;   // y-face flux below row r-1 (between r-2 and r-1)
+  float w0a = 0.f, w0b = 0.f, w1a = 0.f, w1b = 0.f, w1h = 0.f;   // updated (u, v) of rows r-3, r-2 (and h of r-2)
+  float red = 0.f;
+  MRow N = march_load<KIND>(A, wrapy(j0 - 2), col, true);
+  for (int r = j0 - 2; r <= j1 + 1; r++) {
+    MRow nxt = N;
+    if (r < j1 + 1) nxt = march_load<KIND>(A, wrapy(r + 1), col, true);   // prefetch the next input row
+    // y-face between rows r-1 (P) and r (N)
+    float G0 = 0.f, G1 = 0.f, G2 = 0.f;
+    if (!oneD) march_face<KIND>(A, P, N, 1, G0, G1, G2);
+    // x-faces of row r-1: low face of this lane from the lane below, high face = the low face of the lane above
+    MRow Pl;
+    Pl.a = __shfl_up(P.a, 1, 64); Pl.b = __shfl_up(P.b, 1, 64);
+    Pl.c = (KIND == K_SW) ? __shfl_up(P.c, 1, 64) : 0.f; Pl.d = (KIND == K_SW) ? __shfl_up(P.d, 1, 64) : 0.f;
+    float F0, F1, F2;
+    march_face<KIND>(A, Pl, P, 0, F0, F1, F2);
+    const float F0h = __shfl_down(F0, 1, 64), F1h = __shfl_down(F1, 1, 64), F2h = (KIND == K_SW) ? __shfl_down(F2, 1, 64) : 0.f;
+    // conservative update of row r-1 (update_convective :458-487 / update_kernel :474-513)
+    float un, vn, hn = 0.f;
+    if (KIND == K_BURGERS) {
+      un = P.a - dt * ((F0h - F0) * A.invdx + (G0 - g0) * invdy);
+      vn = P.b - dt * ((F1h - F1) * A.invdx + (G1 - g1) * invdy);
+    } else {
+      float h = P.a, mx = h * P.b, my = h * P.c;
+      h -= dt * ((F0h - F0) * A.invdx + (G0 - g0) * A.invdy);
+      mx -= dt * ((F1h - F1) * A.invdx + (G1 - g1) * A.invdy);
+      my -= dt * ((F2h - F2) * A.invdx + (G2 - g2) * A.invdy);
+      h = fmaxf(h, 1e-6f);
+      const float ih = __builtin_amdgcn_rcpf(h);
+      un = mx * ih; vn = my * ih; hn = h;
+    }
+    // viscosity pass on row r-2 from the updated rows r-3 (w0), r-2 (w1), r-1 (un, vn), then store it
+    const int o = r - 2;
+    {
+      float u = w1a, v = w1b;
+      if (A.do_visc) {
+        const float ul = __shfl_up(w1a, 1, 64), ur = __shfl_down(w1a, 1, 64);
+        const float vl = __shfl_up(w1b, 1, 64), vr = __shfl_down(w1b, 1, 64);
+        const float lu = (ur - 2.0f * u + ul) * A.invdx2 + (un - 2.0f * u + w0a) * invdy2;
+        const float lv = (vr - 2.0f * v + vl) * A.invdx2 + (vn - 2.0f * v + w0b) * invdy2;
+        u += nudt * lu;
+        v += nudt * lv;
+      }
+      if (own && o >= j0 && o < j1) {
+        const size_t gi = (size_t)o * A.nx + xo;
+        if (KIND == K_BURGERS) {
+          A.out[0][gi] = fasinh(u * A.inv_u0);
+          A.out[1][gi] = fasinh(v * A.inv_u0);
+          red = fmaxf(red, fabsf(u) * A.invdx + fabsf(v) * ((A.ny > 1) ? A.invdy : 0.0f));
+        } else {
+          A.out[0][gi] = __builtin_amdgcn_logf(w1h) * 0.69314718055994531f;
+          A.out[1][gi] = u;
+          A.out[2][gi] = v;
+          const float c = __builtin_amdgcn_sqrtf(A.g * w1h);
+          red = fmaxf(red, fmaxf(fabsf(u) + c, fabsf(v) + c));
+        }
+      }
+    }
+    // slide
+    w0a = w1a; w0b = w1b; w1a = un; w1b = vn; w1h = hn;
+    g0 = G0; g1 = G1; g2 = G2;
+    P = N; N = nxt;
+  }
+  if (A.reduce) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) red = fmaxf(red, __shfl_xor(red, o, 64));
+    if (lane == 0) tau::atomic_max_float_bits(&A.st->maxbits[(A.slot + 1) % 3], red);
+  }
+}
+
 // wavespeed metric of a state (first step after init / upload, and after extra Burgers viscosity passes)
 template <int KIND>
 __global__ __launch_bounds__(256) void k_metric(const Args A, int slot) {
@@ -467,7 +608,17 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
     h->max_valid = true;
   }
   const unsigned nb = (unsigned)(A.ntx * A.nty);
-  if (h->kind == 0 && A.muscl) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, true>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
+  static const int use_march = [] { const char *e = getenv("TAU_FLOW_MARCH"); return e ? atoi(e) : 1; }();
+  if (use_march && !(h->kind == 0 && A.muscl) && P.nx >= 8 && P.ny >= 4) {   // plain Burgers, shallow water: the marching kernel
+    const int nstrips = (P.nx + fl2::MCOLS - 1) / fl2::MCOLS;
+    int rows = (int)((long)P.ny * nstrips / 4096);                 // ~4k waves at least, chunks of 8..64 rows
+    rows = rows < 8 ? 8 : (rows > 64 ? 64 : rows);
+    const int nchunks = (P.ny + rows - 1) / rows;
+    const unsigned nwg = (unsigned)((nstrips * nchunks + 3) / 4);
+    if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    else hipLaunchKernelGGL(fl2::k_march<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+  }
+  else if (h->kind == 0 && A.muscl) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, true>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   else if (h->kind == 0) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   else hipLaunchKernelGGL((fl2::k_step<fl2::K_SW, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   TAU_LAUNCH_CHECK("fl2::k_step");

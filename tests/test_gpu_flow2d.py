@@ -1,4 +1,6 @@
 """GPU: fused Burgers / shallow-water steps (tauflow_*, through the C-ABI) against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -138,3 +140,33 @@ def test_full_size_translation_invariance(eng):
         for x, y in zip(a, b):
             assert np.array_equal(np.roll(x, sh, (0, 1)), y)
         e.close()
+
+
+@pytest.mark.parametrize("kind,nx,ny,kw", [("burgers", 256, 128, {}), ("burgers", 100, 61, {}), ("burgers", 512, 16, dict(oneD=1)),
+                                           ("sw", 256, 128, {}), ("sw", 97, 50, dict(nu=0.0)), ("sw", 1000, 300, dict(nu=0.05)),
+                                           ("burgers", 300, 200, dict(visc_substeps=3))])
+def test_marching_step_agrees_with_the_tile_step(eng, tmp_path, kind, nx, ny, kw):
+    """plain Burgers and shallow water take the marching kernel (one wave per 60-column strip, everything in
+    registers); TAU_FLOW_MARCH=0 keeps the LDS-tile kernel.  Same faces, same update formulas — the two differ only
+    in where the compiler contracts multiply-adds, so 25 steps apart they agree to ~1e-6 (the parity tests above run
+    the marching kernel against the oracle)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import fluid_sims_amd as f, numpy as np\n"
+            "e = f.Flow2D(%r, %d, %d, **%r); e.init(); e.step(25)\n"
+            "c = e.clock(); np.savez(sys.argv[1], *e.download(), clock=np.array([c['t'], c['dt'], c['wavespeed'], c['step']]))\n"
+            % (root, kind, nx, ny, kw))
+    outs = []
+    for march in ("1", "0"):
+        out = tmp_path / f"m{march}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], capture_output=True, text=True, env=dict(os.environ, TAU_FLOW_MARCH=march))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert a["clock"][3] == b["clock"][3] == 25 and a["clock"][0] == b["clock"][0]
+    assert abs(a["clock"][1] - b["clock"][1]) <= 1e-5 * abs(b["clock"][1])
+    for k in a.files:
+        if k.startswith("arr_"):
+            assert np.isfinite(a[k]).all()
+            scale = max(float(np.abs(b[k]).max()), 1e-30)
+            assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= 1e-4 * scale, k
