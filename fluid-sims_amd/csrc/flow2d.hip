@@ -611,8 +611,10 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
   static const int use_march = [] { const char *e = getenv("TAU_FLOW_MARCH"); return e ? atoi(e) : 1; }();
   if (use_march && !(h->kind == 0 && A.muscl) && P.nx >= 8 && P.ny >= 4) {   // plain Burgers, shallow water: the marching kernel
     const int nstrips = (P.nx + fl2::MCOLS - 1) / fl2::MCOLS;
-    int rows = (int)((long)P.ny * nstrips / 4096);                 // ~4k waves at least, chunks of 8..64 rows
-    rows = rows < 8 ? 8 : (rows > 64 ? 64 : rows);
+    int rows = (int)((long)P.ny * nstrips / 8192);                 // ~8k waves at least, chunks of 8..48 rows (8192^2: 32-48
+    rows = rows < 8 ? 8 : (rows > 48 ? 48 : rows);                 // rows 184 Gcell/s, 16: 175, 64: 179, 128: 154)
+    static const int rows_env = [] { const char *e = getenv("TAU_FLOW_ROWS"); return e ? atoi(e) : 0; }();
+    if (rows_env >= 1) rows = rows_env;
     const int nchunks = (P.ny + rows - 1) / rows;
     const unsigned nwg = (unsigned)((nstrips * nchunks + 3) / 4);
     if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
