@@ -609,7 +609,10 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
   }
   const unsigned nb = (unsigned)(A.ntx * A.nty);
   static const int use_march = [] { const char *e = getenv("TAU_FLOW_MARCH"); return e ? atoi(e) : 1; }();
-  if (use_march && !(h->kind == 0 && A.muscl) && P.nx >= 8 && P.ny >= 4) {   // plain Burgers, shallow water: the marching kernel
+  // plain Burgers, shallow water: the marching kernel from ~2 M cells on (a wave walks its strip serially, so it needs
+  // thousands of strips x chunks to fill the chip: 1024^2 24.6 vs 15.9 us per step, 1536^2 28.8 vs 29.4, 4096^2 103 vs 146);
+  // TAU_FLOW_MARCH=2 forces it at any size
+  if (use_march && !(h->kind == 0 && A.muscl) && P.nx >= 8 && P.ny >= 4 && (use_march > 1 || (long)P.nx * P.ny >= (1L << 21))) {
     const int nstrips = (P.nx + fl2::MCOLS - 1) / fl2::MCOLS;
     int rows = (int)((long)P.ny * nstrips / 8192);                 // ~8k waves at least, chunks of 8..48 rows (8192^2: 32-48
     rows = rows < 8 ? 8 : (rows > 48 ? 48 : rows);                 // rows 184 Gcell/s, 16: 175, 64: 179, 128: 154)
