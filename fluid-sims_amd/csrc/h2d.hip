@@ -400,6 +400,172 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// The same step as a MARCH (large grids).  A wave owns a 60-column strip (64 lanes, two halo lanes a side: the
+// diffusion stencil and "predicted state of the neighbour" both reach two cells) and walks down a chunk of rows
+// holding a five-row window of the input state in registers.  Per trip it takes in row a, predicts row a-1 along
+// both axes (MUSCL-Hancock, x neighbours by lane shift), forms the x-face fluxes of row a-1 and the y-face fluxes
+// between rows a-2 and a-1, and completes row a-2: flux differences, 4th-order diffusion from the window, repairs,
+// store, wavespeed.  Nothing goes through LDS memory and every face is evaluated once per wave; the tile kernel
+// above stages 432 cells and predicts 340 to write 256.  The boundary rules are the ones the tile staging resolves
+// (columns left of x = 0 hold the inflow state, columns right of W-1 a copy of cell W-1, rows are clamped, all
+// with the mask cleared / taken from the clamped cell), applied where a row is loaded.
+constexpr int MCOLS = 60;
+struct MCell { C4 c; bool m, in; };   // staged conserved state, body mask, "a cell of the domain" (for has-state tests)
+
+__device__ __forceinline__ MCell march_load(const Args &A, int gx, int row) {
+  MCell q;
+  const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(row, A.H - 1));
+  const size_t gi = (size_t)sy * A.W + sx;
+  const bool mk = A.mask[gi] != 0;
+  q.m = (gx < 0 || gx >= A.W) ? false : mk;
+  q.c = C4{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
+  if ((sx == 0 && !mk) || gx < 0) q.c = A.in_c;
+  q.in = gx >= 0 && gx < A.W && row >= 0 && row < A.H;
+  return q;
+}
+__device__ __forceinline__ MCell lane_shift(const MCell &q, int d) {   // the cell d lanes away (own value at the wave's ends)
+  MCell o;
+  if (d > 0) {   // from the lane below
+    o.c = C4{__shfl_up(q.c.r, d, 64), __shfl_up(q.c.mx, d, 64), __shfl_up(q.c.my, d, 64), __shfl_up(q.c.E, d, 64)};
+    const int f = __shfl_up((int)q.m | ((int)q.in << 1), d, 64);
+    o.m = f & 1; o.in = (f >> 1) & 1;
+  } else {
+    o.c = C4{__shfl_down(q.c.r, -d, 64), __shfl_down(q.c.mx, -d, 64), __shfl_down(q.c.my, -d, 64), __shfl_down(q.c.E, -d, 64)};
+    const int f = __shfl_down((int)q.m | ((int)q.in << 1), -d, 64);
+    o.m = f & 1; o.in = (f >> 1) & 1;
+  }
+  return o;
+}
+__device__ __forceinline__ C4 ghost_sel(const C4 &wg, const MCell &n) {   // neigh_sel on a staged cell
+  return C4{n.m ? wg.r : n.c.r, n.m ? wg.mx : n.c.mx, n.m ? wg.my : n.c.my, n.m ? wg.E : n.c.E};
+}
+// predict_axis on explicit neighbours (already ghost-selected, conserved)
+__device__ __forceinline__ void predict_from(const Args &A, P4 qc, const C4 &cm, const C4 &cp, int ax, float half, P4 &lo, P4 &hi) {
+  P4 qm = c2p(A, cm), qp = c2p(A, cp);
+  float s_r = mc(qc.r - qm.r, 0.5f * (qp.r - qm.r), qp.r - qc.r);
+  float s_u = mc(qc.u - qm.u, 0.5f * (qp.u - qm.u), qp.u - qc.u);
+  float s_v = mc(qc.v - qm.v, 0.5f * (qp.v - qm.v), qp.v - qc.v);
+  float s_p = mc(qc.p - qm.p, 0.5f * (qp.p - qm.p), qp.p - qc.p);
+  P4 L{qc.r - 0.5f * s_r, qc.u - 0.5f * s_u, qc.v - 0.5f * s_v, qc.p - 0.5f * s_p};
+  P4 R{qc.r + 0.5f * s_r, qc.u + 0.5f * s_u, qc.v + 0.5f * s_v, qc.p + 0.5f * s_p};
+  enforce_positive(L, qc, R);
+  P4 Lf{fmaxf(L.r, EPS_RHO), L.u, L.v, fmaxf(L.p, EPS_P)}, Rf{fmaxf(R.r, EPS_RHO), R.u, R.v, fmaxf(R.p, EPS_P)};
+  C4 FL = flux_p(A, Lf, p2c(A, L), ax), FR = flux_p(A, Rf, p2c(A, R), ax);
+  C4 dF{FR.r - FL.r, FR.mx - FL.mx, FR.my - FL.my, FR.E - FL.E};
+  lo = half_step(A, L, dF, half);
+  hi = half_step(A, R, dF, half);
+}
+// face() on explicit cells: a = low side (predicted high state ha), b = high side (predicted low state lb)
+__device__ __forceinline__ C4 face_from(const Args &A, const MCell &a, const P4 &ha, const MCell &b, const P4 &lb, int ax) {
+  const bool hasL = a.in && !a.m, hasR = b.in && !b.m;
+  P4 L = ha, R = lb;
+  if (!hasL) L = c2p(A, ghost_sel(wall_ghost(A, c2p(A, b.c)), a));
+  if (!hasR) R = c2p(A, ghost_sel(wall_ghost(A, c2p(A, a.c)), b));
+  C4 F = hllc(A, L, R, ax);
+  if (!hasL && !hasR) F = C4{0.f, 0.f, 0.f, 0.f};
+  return F;
+}
+
+__global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstrips, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(nstrips * nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  float dt;
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float maxs = __uint_as_float(A.st->maxs_bits[A.slot]);
+    if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
+    dt = fminf(A.cfl / maxs, A.dt_diff);
+  }
+  const float half = 0.5f * dt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // the step's bookkeeping: sim_t += dt, :1888
+    A.st->t += (double)dt;
+    A.st->dt_last = dt;
+    A.st->step += 1;
+    A.st->maxs_bits[(A.slot + 2) % 3] = 0u;
+  }
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)nstrips), chunk = (int)(wid / (unsigned)nstrips);
+  const int gx = strip * MCOLS + lane - 2;
+  const bool own = lane >= 2 && lane < 2 + MCOLS && gx < A.W;
+  const int j0 = chunk * rows, j1 = min(j0 + rows, A.H);
+
+  MCell w0, w1, w2, w3, w4;                       // input rows a-4 .. a
+  w2 = march_load(A, gx, j0 - 2);                 // (the loop's first slide makes these rows a-4, a-3 = j0-3?, see below)
+  w3 = march_load(A, gx, j0 - 2);
+  w4 = march_load(A, gx, j0 - 1);
+  w0 = w2; w1 = w2;
+  P4 yhi_prev{1.f, 0.f, 0.f, 1.f};                // predicted high-y state of row a-2
+  C4 Gy_lo{0.f, 0.f, 0.f, 0.f};                   // y-face flux below row a-2 (between a-3 and a-2)
+  C4 dFx{0.f, 0.f, 0.f, 0.f};                     // x flux difference of row a-2
+  float smax = 0.f;
+  MCell nxt = march_load(A, gx, j0);
+  for (int a = j0; a <= j1 + 1; a++) {
+    w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = nxt; // window = rows a-4 .. a
+    if (a < j1 + 1) nxt = march_load(A, gx, a + 1);
+    // ---- predict row p = a-1 (centre w3) along x and y
+    const int p = a - 1;
+    const bool has_p = w3.in && !w3.m;
+    const P4 qc = c2p(A, w3.c);
+    const C4 wg = wall_ghost(A, qc);
+    const MCell l1 = lane_shift(w3, 1), r1 = lane_shift(w3, -1);
+    P4 xlo, xhi, ylo, yhi;
+    predict_from(A, qc, ghost_sel(wg, l1), ghost_sel(wg, r1), 0, half, xlo, xhi);
+    predict_from(A, qc, ghost_sel(wg, w2), ghost_sel(wg, w4), 1, half, ylo, yhi);
+    // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
+    P4 xhi_l;
+    xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
+    const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
+    const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my,
+                   __shfl_down(Fx.E, 1, 64) - Fx.E};
+    // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
+    const C4 Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
+    // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175
+    const int j = a - 2;
+    if (j >= j0 && j < j1) {   // wave-uniform
+      const C4 Uc = w2.c;
+      C4 Un = Uc;
+      float sp = 0.f;
+      const MCell xm1 = lane_shift(w2, 1), xm2 = lane_shift(w2, 2), xp1 = lane_shift(w2, -1), xp2 = lane_shift(w2, -2);
+      if (!w2.m) {
+        Un.r -= dt * dFx.r; Un.mx -= dt * dFx.mx; Un.my -= dt * dFx.my; Un.E -= dt * dFx.E;
+        Un.r -= dt * (Gy.r - Gy_lo.r); Un.mx -= dt * (Gy.mx - Gy_lo.mx);
+        Un.my -= dt * (Gy.my - Gy_lo.my); Un.E -= dt * (Gy.E - Gy_lo.E);
+        const C4 wgc = wall_ghost(A, c2p(A, Uc));
+        const C4 cxm2 = ghost_sel(wgc, xm2), cxm1 = ghost_sel(wgc, xm1), cxp1 = ghost_sel(wgc, xp1), cxp2 = ghost_sel(wgc, xp2);
+        const C4 cym2 = ghost_sel(wgc, w0), cym1 = ghost_sel(wgc, w1), cyp1 = ghost_sel(wgc, w3), cyp2 = ghost_sel(wgc, w4);
+        const float i12 = 1.0f / 12.0f;
+#define D2(f) (((-cxm2.f + 16.0f * cxm1.f - 30.0f * Uc.f + 16.0f * cxp1.f - cxp2.f) * i12) + \
+               ((-cym2.f + 16.0f * cym1.f - 30.0f * Uc.f + 16.0f * cyp1.f - cyp2.f) * i12))
+        Un.r += (A.visc_rho * dt) * D2(r);
+        Un.mx += (A.visc_nu * dt) * D2(mx);
+        Un.my += (A.visc_nu * dt) * D2(my);
+        Un.E += (A.visc_e * dt) * D2(E);
+#undef D2
+        Un.r = fmaxf(Un.r, EPS_RHO);
+        P4 pp = c2p(A, Un);
+        if (pp.p <= EPS_P || !isfinite(pp.p) || !isfinite(pp.r) || !isfinite(pp.u) || !isfinite(pp.v)) {
+          pp.r = fmaxf(pp.r, EPS_RHO);
+          pp.p = fmaxf(pp.p, EPS_P);
+          Un = p2c(A, pp);
+        }
+        sp = cell_speed(A, (gx == 0) ? A.in_c : Un);
+      }
+      if (own) {
+        const size_t gi = (size_t)j * A.W + gx;
+        A.out[0][gi] = Un.r; A.out[1][gi] = Un.mx; A.out[2][gi] = Un.my; A.out[3][gi] = Un.E;
+        smax = fmaxf(smax, sp);
+      }
+    }
+    (void)p; (void)has_p;
+    yhi_prev = yhi; Gy_lo = Gy; dFx = dFx_p;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  if (lane == 0) tau::atomic_max_float_bits(&A.st->maxs_bits[(A.slot + 1) % 3], smax);
+}
+
 // max wavespeed of a freshly initialised / uploaded state (the reference's two reduction kernels)
 __global__ __launch_bounds__(256) void k_maxspeed(const Args A) {
   __shared__ float sRed[4];
@@ -687,7 +853,18 @@ static int h2_launch_step(tauh2 *h, float dt_explicit) {
     TAU_LAUNCH_CHECK("h2d::k_maxspeed");
     h->maxs_valid = true;
   }
-  hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);
+  static const int use_march = [] { const char *e = getenv("TAU_H2_MARCH"); return e ? atoi(e) : 1; }();
+  if (use_march && A.W >= 8 && A.H >= 4 && (use_march > 1 || (long)A.W * A.H >= (1L << 21))) {
+    const int nstrips = (A.W + h2d::MCOLS - 1) / h2d::MCOLS;
+    int rows = (int)((long)A.H * nstrips / 8192);
+    rows = rows < 8 ? 8 : (rows > 32 ? 32 : rows);                 // 4096^2: 16 rows 40.5, 32: 41.1, 48: 40.3, 96: 38.0 Gcell/s
+    static const int rows_env = [] { const char *e = getenv("TAU_H2_ROWS"); return e ? atoi(e) : 0; }();
+    if (rows_env >= 1) rows = rows_env;
+    const int nchunks = (A.H + rows - 1) / rows;
+    hipLaunchKernelGGL(h2d::k_march, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+  } else {
+    hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);
+  }
   TAU_LAUNCH_CHECK("h2d::k_step");
   h->cur ^= 1; // swap_Us, :1378-1392
   h->slot = (h->slot + 1) % 3;

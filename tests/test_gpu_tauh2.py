@@ -135,3 +135,31 @@ def test_deterministic(eng):
     for a, b in zip(outs[0][0], outs[1][0]):
         assert np.array_equal(a, b)
     assert outs[0][1] == outs[1][1]
+
+
+@pytest.mark.parametrize("W,H,steps", [(300, 200, 12), (512, 256, 20), (1000, 130, 8), (70, 50, 6)])
+def test_marching_step_agrees_with_the_tile_step(eng, tmp_path, W, H, steps):
+    """from ~2 M cells on the step runs as a march (one wave per 60-column strip, a five-row window in registers,
+    nothing through LDS); TAU_H2_MARCH=2 forces it at these sizes, TAU_H2_MARCH=0 keeps the tile kernel.  Same
+    predictor, faces, diffusion and repairs on the same operands — the two differ in where multiply-adds are
+    contracted.  Mask and time must agree exactly, the fields to rounding after a few steps (the oracle parity
+    tests above run the tile kernel here; the fuzz sweep runs the march against the oracle when forced)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import fluid_sims_amd as f, numpy as np\n"
+            "h = f.Hypersonic2D(%d, %d); h.init(); t = h.step(%d)\n"
+            "st, m = h.download(with_mask=True); np.savez(sys.argv[1], *st, mask=m, t=np.float64(t if t is not None else 0.0))\n"
+            % (root, W, H, steps))
+    outs = []
+    for march in ("2", "0"):
+        out = tmp_path / f"m{march}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], capture_output=True, text=True, env=dict(os.environ, TAU_H2_MARCH=march))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert np.array_equal(a["mask"], b["mask"])
+    assert abs(float(a["t"]) - float(b["t"])) <= 1e-6 * abs(float(b["t"])) + 1e-12
+    for k in ("arr_0", "arr_1", "arr_2", "arr_3"):
+        assert np.isfinite(a[k]).all()
+        scale = max(float(np.abs(b[k]).max()), 1e-30)
+        assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= 2e-5 * scale, k
