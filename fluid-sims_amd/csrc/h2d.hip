@@ -460,8 +460,13 @@ __device__ __forceinline__ void predict_from(const Args &A, P4 qc, const C4 &cm,
 __device__ __forceinline__ C4 face_from(const Args &A, const MCell &a, const P4 &ha, const MCell &b, const P4 &lb, int ax) {
   const bool hasL = a.in && !a.m, hasR = b.in && !b.m;
   P4 L = ha, R = lb;
-  if (!hasL) L = c2p(A, ghost_sel(wall_ghost(A, c2p(A, b.c)), a));
-  if (!hasR) R = c2p(A, ghost_sel(wall_ghost(A, c2p(A, a.c)), b));
+  // ghost states only where a side has no predicted state (body surface, domain edge): a real branch, skipped by
+  // every wave away from those (as selects the two wall ghosts and four conversions ran for every face)
+  if (__builtin_amdgcn_ballot_w64(!hasL || !hasR) != 0ull) {   // wave-uniform: some lane of the wave needs a ghost
+    const P4 gl = c2p(A, ghost_sel(wall_ghost(A, c2p(A, b.c)), a)), gr = c2p(A, ghost_sel(wall_ghost(A, c2p(A, a.c)), b));
+    if (!hasL) L = gl;
+    if (!hasR) R = gr;
+  }
   C4 F = hllc(A, L, R, ax);
   if (!hasL && !hasR) F = C4{0.f, 0.f, 0.f, 0.f};
   return F;
@@ -508,11 +513,15 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
     const int p = a - 1;
     const bool has_p = w3.in && !w3.m;
     const P4 qc = c2p(A, w3.c);
-    const C4 wg = wall_ghost(A, qc);
     const MCell l1 = lane_shift(w3, 1), r1 = lane_shift(w3, -1);
+    C4 nl = l1.c, nr = r1.c, nd = w2.c, nu = w4.c;
+    if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | w4.m) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
+      const C4 wg = wall_ghost(A, qc);
+      nl = ghost_sel(wg, l1); nr = ghost_sel(wg, r1); nd = ghost_sel(wg, w2); nu = ghost_sel(wg, w4);
+    }
     P4 xlo, xhi, ylo, yhi;
-    predict_from(A, qc, ghost_sel(wg, l1), ghost_sel(wg, r1), 0, half, xlo, xhi);
-    predict_from(A, qc, ghost_sel(wg, w2), ghost_sel(wg, w4), 1, half, ylo, yhi);
+    predict_from(A, qc, nl, nr, 0, half, xlo, xhi);
+    predict_from(A, qc, nd, nu, 1, half, ylo, yhi);
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     P4 xhi_l;
     xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
@@ -532,9 +541,12 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
         Un.r -= dt * dFx.r; Un.mx -= dt * dFx.mx; Un.my -= dt * dFx.my; Un.E -= dt * dFx.E;
         Un.r -= dt * (Gy.r - Gy_lo.r); Un.mx -= dt * (Gy.mx - Gy_lo.mx);
         Un.my -= dt * (Gy.my - Gy_lo.my); Un.E -= dt * (Gy.E - Gy_lo.E);
-        const C4 wgc = wall_ghost(A, c2p(A, Uc));
-        const C4 cxm2 = ghost_sel(wgc, xm2), cxm1 = ghost_sel(wgc, xm1), cxp1 = ghost_sel(wgc, xp1), cxp2 = ghost_sel(wgc, xp2);
-        const C4 cym2 = ghost_sel(wgc, w0), cym1 = ghost_sel(wgc, w1), cyp1 = ghost_sel(wgc, w3), cyp2 = ghost_sel(wgc, w4);
+        C4 cxm2 = xm2.c, cxm1 = xm1.c, cxp1 = xp1.c, cxp2 = xp2.c, cym2 = w0.c, cym1 = w1.c, cyp1 = w3.c, cyp2 = w4.c;
+        if (__builtin_amdgcn_ballot_w64(xm2.m | xm1.m | xp1.m | xp2.m | w0.m | w1.m | w3.m | w4.m) != 0ull) {
+          const C4 wgc = wall_ghost(A, c2p(A, Uc));
+          cxm2 = ghost_sel(wgc, xm2); cxm1 = ghost_sel(wgc, xm1); cxp1 = ghost_sel(wgc, xp1); cxp2 = ghost_sel(wgc, xp2);
+          cym2 = ghost_sel(wgc, w0); cym1 = ghost_sel(wgc, w1); cyp1 = ghost_sel(wgc, w3); cyp2 = ghost_sel(wgc, w4);
+        }
         const float i12 = 1.0f / 12.0f;
 #define D2(f) (((-cxm2.f + 16.0f * cxm1.f - 30.0f * Uc.f + 16.0f * cxp1.f - cxp2.f) * i12) + \
                ((-cym2.f + 16.0f * cym1.f - 30.0f * Uc.f + 16.0f * cyp1.f - cyp2.f) * i12))
