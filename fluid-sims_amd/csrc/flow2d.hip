@@ -416,6 +416,90 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
   }
 }
 
+// MUSCL Burgers as a march.  The limited reconstruction works on the ENCODED phi of four cells along the axis and
+// decodes the two face states (four sinh per face), so phi is carried raw: a four-row window for the y faces
+// (face a-2 | a-1 needs rows a-3 .. a), lanes l-2 .. l+1 for the x faces, three halo lanes a side (own 58 columns).
+constexpr int MCOLS_M = 58;
+__global__ __launch_bounds__(256) void k_march_muscl(const Args A, int rows, int nstrips, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(nstrips * nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  float dt;
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float m = __uint_as_float(A.st->maxbits[A.slot]);
+    if (!(m >= 1e-12f)) m = 1e-12f;
+    dt = fminf(A.dt_try, A.CFL * A.cfl_len / m);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.st->dt_last = dt;
+    A.st->maxbits[(A.slot + 2) % 3] = 0u;
+  }
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)nstrips), chunk = (int)(wid / (unsigned)nstrips);
+  const int xo = strip * MCOLS_M + lane - 3;
+  const int col = ((xo % A.nx) + A.nx) % A.nx;
+  const bool own = lane >= 3 && lane < 3 + MCOLS_M && xo < A.nx;
+  const int j0 = chunk * rows, j1 = min(j0 + rows, A.ny);
+  const bool oneD = A.oneD != 0;
+  const float invdy = oneD ? 0.0f : A.invdy, invdy2 = oneD ? 0.0f : A.invdy2;
+  const float nudt = A.nu * (dt * A.visc_frac);
+  auto wrapy = [&](int r) { return ((r % A.ny) + A.ny) % A.ny; };
+  auto load = [&](int r, float &pu, float &pv) { const size_t gi = (size_t)wrapy(r) * A.nx + col; pu = A.in[0][gi]; pv = A.in[1][gi]; };
+
+  float u3, v3, u2, v2, u1, v1, un_, vn_;          // phi of rows a-3, a-2, a-1, a
+  load(j0 - 3, u2, v2); load(j0 - 2, u1, v1); load(j0 - 1, un_, vn_);
+  u3 = u2; v3 = v2;
+  float nu_, nv_;
+  load(j0, nu_, nv_);
+  float g0 = 0.f, g1 = 0.f;                         // y-face flux below row a-2
+  float w0a = 0.f, w0b = 0.f, w1a = 0.f, w1b = 0.f; // updated (u, v) of rows a-4, a-3
+  float red = 0.f;
+  for (int a = j0; a <= j1 + 2; a++) {
+    u3 = u2; v3 = v2; u2 = u1; v2 = v1; u1 = un_; v1 = vn_; un_ = nu_; vn_ = nv_;   // window = rows a-3 .. a
+    if (a < j1 + 2) load(a + 1, nu_, nv_);
+    // y face between rows a-2 and a-1 (cells a-3, a-2 | a-1, a)
+    float G0 = 0.f, G1 = 0.f;
+    if (!oneD) burgers_face<true>(A, u3, u2, u1, un_, v3, v2, v1, vn_, 1, G0, G1);
+    // x faces of row a-2: the face below this lane needs lanes l-2, l-1 | l, l+1
+    const float ul2 = __shfl_up(u2, 2, 64), ul1 = __shfl_up(u2, 1, 64), ur1 = __shfl_down(u2, 1, 64);
+    const float vl2 = __shfl_up(v2, 2, 64), vl1 = __shfl_up(v2, 1, 64), vr1 = __shfl_down(v2, 1, 64);
+    float F0, F1;
+    burgers_face<true>(A, ul2, ul1, u2, ur1, vl2, vl1, v2, vr1, 0, F0, F1);
+    const float F0h = __shfl_down(F0, 1, 64), F1h = __shfl_down(F1, 1, 64);
+    // conservative update of row a-2 (update_convective, :458-487)
+    const float uc0 = A.u0 * fsinh(u2), vc0 = A.u0 * fsinh(v2);
+    const float unew = uc0 - dt * ((F0h - F0) * A.invdx + (G0 - g0) * invdy);
+    const float vnew = vc0 - dt * ((F1h - F1) * A.invdx + (G1 - g1) * invdy);
+    // viscosity pass on row a-3 from the updated rows a-4 (w0), a-3 (w1), a-2 (new), then store it
+    const int o = a - 3;
+    {
+      float u = w1a, v = w1b;
+      if (A.do_visc) {
+        const float ul = __shfl_up(w1a, 1, 64), ur = __shfl_down(w1a, 1, 64);
+        const float vl = __shfl_up(w1b, 1, 64), vr = __shfl_down(w1b, 1, 64);
+        const float lu = (ur - 2.0f * u + ul) * A.invdx2 + (unew - 2.0f * u + w0a) * invdy2;
+        const float lv = (vr - 2.0f * v + vl) * A.invdx2 + (vnew - 2.0f * v + w0b) * invdy2;
+        u += nudt * lu;
+        v += nudt * lv;
+      }
+      if (own && o >= j0 && o < j1) {
+        const size_t gi = (size_t)o * A.nx + xo;
+        A.out[0][gi] = fasinh(u * A.inv_u0);
+        A.out[1][gi] = fasinh(v * A.inv_u0);
+        red = fmaxf(red, fabsf(u) * A.invdx + fabsf(v) * ((A.ny > 1) ? A.invdy : 0.0f));
+      }
+    }
+    w0a = w1a; w0b = w1b; w1a = unew; w1b = vnew;
+    g0 = G0; g1 = G1;
+  }
+  if (A.reduce) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) red = fmaxf(red, __shfl_xor(red, o, 64));
+    if (lane == 0) tau::atomic_max_float_bits(&A.st->maxbits[(A.slot + 1) % 3], red);
+  }
+}
+
 // wavespeed metric of a state (first step after init / upload, and after extra Burgers viscosity passes)
 template <int KIND>
 __global__ __launch_bounds__(256) void k_metric(const Args A, int slot) {
@@ -622,6 +706,15 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
     const unsigned nwg = (unsigned)((nstrips * nchunks + 3) / 4);
     if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
     else hipLaunchKernelGGL(fl2::k_march<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+  }
+  else if (use_march && h->kind == 0 && A.muscl && P.nx >= 8 && P.ny >= 4 && (use_march > 1 || (long)P.nx * P.ny >= (1L << 21))) {
+    const int nstrips = (P.nx + fl2::MCOLS_M - 1) / fl2::MCOLS_M;
+    int rows = (int)((long)P.ny * nstrips / 8192);
+    rows = rows < 8 ? 8 : (rows > 48 ? 48 : rows);
+    static const int rows_env = [] { const char *e = getenv("TAU_FLOW_ROWS"); return e ? atoi(e) : 0; }();
+    if (rows_env >= 1) rows = rows_env;
+    const int nchunks = (P.ny + rows - 1) / rows;
+    hipLaunchKernelGGL(fl2::k_march_muscl, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
   }
   else if (h->kind == 0 && A.muscl) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, true>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   else if (h->kind == 0) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);

@@ -144,7 +144,8 @@ def test_full_size_translation_invariance(eng):
 
 @pytest.mark.parametrize("kind,nx,ny,kw", [("burgers", 256, 128, {}), ("burgers", 100, 61, {}), ("burgers", 512, 16, dict(oneD=1)),
                                            ("sw", 256, 128, {}), ("sw", 97, 50, dict(nu=0.0)), ("sw", 1000, 300, dict(nu=0.05)),
-                                           ("burgers", 300, 200, dict(visc_substeps=3))])
+                                           ("burgers", 300, 200, dict(visc_substeps=3)), ("burgers", 256, 128, dict(muscl=1)),
+                                           ("burgers", 131, 77, dict(muscl=1)), ("burgers", 512, 16, dict(muscl=1, oneD=1))])
 def test_marching_step_agrees_with_the_tile_step(eng, tmp_path, kind, nx, ny, kw):
     """plain Burgers and shallow water take the marching kernel (one wave per 60-column strip, everything in
     registers) from ~2 M cells on — TAU_FLOW_MARCH=2 forces it here, TAU_FLOW_MARCH=0 keeps the LDS-tile kernel.  Same faces, same update formulas — the two differ only
