@@ -440,9 +440,8 @@ __device__ __forceinline__ MCell lane_shift(const MCell &q, int d) {   // the ce
 __device__ __forceinline__ C4 ghost_sel(const C4 &wg, const MCell &n) {   // neigh_sel on a staged cell
   return C4{n.m ? wg.r : n.c.r, n.m ? wg.mx : n.c.mx, n.m ? wg.my : n.c.my, n.m ? wg.E : n.c.E};
 }
-// predict_axis on explicit neighbours (already ghost-selected, conserved)
-__device__ __forceinline__ void predict_from(const Args &A, P4 qc, const C4 &cm, const C4 &cp, int ax, float half, P4 &lo, P4 &hi) {
-  P4 qm = c2p(A, cm), qp = c2p(A, cp);
+// predict_axis on explicit neighbours (already ghost-selected, primitive)
+__device__ __forceinline__ void predict_from(const Args &A, P4 qc, const P4 &qm, const P4 &qp, int ax, float half, P4 &lo, P4 &hi) {
   float s_r = mc(qc.r - qm.r, 0.5f * (qp.r - qm.r), qp.r - qc.r);
   float s_u = mc(qc.u - qm.u, 0.5f * (qp.u - qm.u), qp.u - qc.u);
   float s_v = mc(qc.v - qm.v, 0.5f * (qp.v - qm.v), qp.v - qc.v);
@@ -506,22 +505,28 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
   C4 dFx{0.f, 0.f, 0.f, 0.f};                     // x flux difference of row a-2
   float smax = 0.f;
   MCell nxt = march_load(A, gx, j0);
+  P4 q3 = c2p(A, w3.c), q4 = c2p(A, w4.c), q2 = q3;   // primitives of rows a-2, a-1, a (after the slide): each row is converted once
   for (int a = j0; a <= j1 + 1; a++) {
     w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = nxt; // window = rows a-4 .. a
+    q2 = q3; q3 = q4; q4 = c2p(A, w4.c);
     if (a < j1 + 1) nxt = march_load(A, gx, a + 1);
     // ---- predict row p = a-1 (centre w3) along x and y
-    const int p = a - 1;
-    const bool has_p = w3.in && !w3.m;
-    const P4 qc = c2p(A, w3.c);
+    const P4 qc = q3;
     const MCell l1 = lane_shift(w3, 1), r1 = lane_shift(w3, -1);
-    C4 nl = l1.c, nr = r1.c, nd = w2.c, nu = w4.c;
+    // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried
+    P4 pl{__shfl_up(qc.r, 1, 64), __shfl_up(qc.u, 1, 64), __shfl_up(qc.v, 1, 64), __shfl_up(qc.p, 1, 64)};
+    P4 pr{__shfl_down(qc.r, 1, 64), __shfl_down(qc.u, 1, 64), __shfl_down(qc.v, 1, 64), __shfl_down(qc.p, 1, 64)};
+    P4 pd = q2, pu = q4;
     if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | w4.m) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
       const C4 wg = wall_ghost(A, qc);
-      nl = ghost_sel(wg, l1); nr = ghost_sel(wg, r1); nd = ghost_sel(wg, w2); nu = ghost_sel(wg, w4);
+      if (l1.m) pl = c2p(A, wg);
+      if (r1.m) pr = c2p(A, wg);
+      if (w2.m) pd = c2p(A, wg);
+      if (w4.m) pu = c2p(A, wg);
     }
     P4 xlo, xhi, ylo, yhi;
-    predict_from(A, qc, nl, nr, 0, half, xlo, xhi);
-    predict_from(A, qc, nd, nu, 1, half, ylo, yhi);
+    predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
+    predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     P4 xhi_l;
     xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
@@ -570,7 +575,6 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
         smax = fmaxf(smax, sp);
       }
     }
-    (void)p; (void)has_p;
     yhi_prev = yhi; Gy_lo = Gy; dFx = dFx_p;
   }
 #pragma unroll
