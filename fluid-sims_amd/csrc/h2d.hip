@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
   C4 Gy_lo{0.f, 0.f, 0.f, 0.f};                   // y-face flux below row a-2 (between a-3 and a-2)
   C4 dFx{0.f, 0.f, 0.f, 0.f};                     // x flux difference of row a-2
   float smax = 0.f;
+  const float in_sp = cell_speed(A, A.in_c);      // the inflow column's speed (its state is overwritten on load)
   MCell nxt = march_load(A, gx, j0);
   P4 q3 = c2p(A, w3.c), q4 = c2p(A, w4.c), q2 = q3;   // primitives of rows a-2, a-1, a (after the slide): each row is converted once
   for (int a = j0; a <= j1 + 1; a++) {
@@ -567,7 +568,9 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
           pp.p = fmaxf(pp.p, EPS_P);
           Un = p2c(A, pp);
         }
-        sp = cell_speed(A, (gx == 0) ? A.in_c : Un);
+        // wavespeed of the new state as the next step will see it; pp IS cons_to_prim(Un) (re-floored where repaired)
+        const float ca = sound(A, pp), cv = fmaxf(fabsf(pp.u) + ca, fabsf(pp.v) + ca);
+        sp = (gx == 0) ? in_sp : (isfinite(cv) ? cv : 1e-12f);
       }
       if (own) {
         const size_t gi = (size_t)j * A.W + gx;
