@@ -416,6 +416,131 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
   }
 }
 
+// Two columns per lane (even nx): a wave covers 128 columns and owns the inner 124 — the two halo cells a side are ONE
+// lane —, the face between a lane's two cells is local, and only the outer faces and the outer viscosity neighbours
+// cross lanes: half the lane shifts per cell, two independent cells of work per lane, float2 loads and stores.
+constexpr int MCOLS2 = 124;
+template <int KIND>
+__global__ __launch_bounds__(256) void k_march2(const Args A, int rows, int nstrips, int nchunks) {
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(nstrips * nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  float dt;
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float m = __uint_as_float(A.st->maxbits[A.slot]);
+    if (!(m >= 1e-12f)) m = 1e-12f;
+    dt = fminf(A.dt_try, A.CFL * A.cfl_len / m);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    A.st->dt_last = dt;
+    A.st->maxbits[(A.slot + 2) % 3] = 0u;
+  }
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)nstrips), chunk = (int)(wid / (unsigned)nstrips);
+  const int xo = strip * MCOLS2 + 2 * lane - 2;                  // first of this lane's two columns (even)
+  const int col = ((xo % A.nx) + A.nx) % A.nx;                   // nx is even: the pair never straddles the wrap
+  const bool own = lane >= 1 && lane < 63 && xo < A.nx;
+  const int j0 = chunk * rows, j1 = min(j0 + rows, A.ny);
+  const bool oneD = (KIND == K_BURGERS) && A.oneD;
+  const float invdy = oneD ? 0.0f : A.invdy, invdy2 = oneD ? 0.0f : A.invdy2;
+  const float nudt = A.nu * (dt * A.visc_frac);
+  auto wrapy = [&](int r) { return ((r % A.ny) + A.ny) % A.ny; };
+  auto load2 = [&](int r, MRow (&q)[2]) {
+    const size_t gi = (size_t)wrapy(r) * A.nx + col;
+    const float2 f0 = *reinterpret_cast<const float2 *>(A.in[0] + gi), f1 = *reinterpret_cast<const float2 *>(A.in[1] + gi);
+    if (KIND == K_BURGERS) {
+      q[0] = MRow{A.u0 * fsinh(f0.x), A.u0 * fsinh(f1.x), 0.f, 0.f};
+      q[1] = MRow{A.u0 * fsinh(f0.y), A.u0 * fsinh(f1.y), 0.f, 0.f};
+    } else {
+      const float2 f2 = *reinterpret_cast<const float2 *>(A.in[2] + gi);
+      const float h0 = __builtin_amdgcn_exp2f(f0.x * 1.44269504088896341f), h1 = __builtin_amdgcn_exp2f(f0.y * 1.44269504088896341f);
+      q[0] = MRow{h0, f1.x, f2.x, __builtin_amdgcn_sqrtf(A.g * h0)};
+      q[1] = MRow{h1, f1.y, f2.y, __builtin_amdgcn_sqrtf(A.g * h1)};
+    }
+  };
+  MRow P[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, N[2], nxt[2];
+  float g[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  float w0a[2] = {0.f, 0.f}, w0b[2] = {0.f, 0.f}, w1a[2] = {0.f, 0.f}, w1b[2] = {0.f, 0.f}, w1h[2] = {0.f, 0.f};
+  float red = 0.f;
+  load2(j0 - 2, N);
+  for (int r = j0 - 2; r <= j1 + 1; r++) {
+    nxt[0] = N[0]; nxt[1] = N[1];
+    if (r < j1 + 1) load2(r + 1, nxt);
+    float G[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    if (!oneD) {
+      march_face<KIND>(A, P[0], N[0], 1, G[0][0], G[0][1], G[0][2]);
+      march_face<KIND>(A, P[1], N[1], 1, G[1][0], G[1][1], G[1][2]);
+    }
+    // x faces of row r-1: left of cell 0 (from the lane below's cell 1), between the two cells, right of cell 1
+    MRow Pl;
+    Pl.a = __shfl_up(P[1].a, 1, 64); Pl.b = __shfl_up(P[1].b, 1, 64);
+    Pl.c = (KIND == K_SW) ? __shfl_up(P[1].c, 1, 64) : 0.f; Pl.d = (KIND == K_SW) ? __shfl_up(P[1].d, 1, 64) : 0.f;
+    float Fl[3], Fm[3], Fh[3];
+    march_face<KIND>(A, Pl, P[0], 0, Fl[0], Fl[1], Fl[2]);
+    march_face<KIND>(A, P[0], P[1], 0, Fm[0], Fm[1], Fm[2]);
+    Fh[0] = __shfl_down(Fl[0], 1, 64); Fh[1] = __shfl_down(Fl[1], 1, 64); Fh[2] = (KIND == K_SW) ? __shfl_down(Fl[2], 1, 64) : 0.f;
+    float un[2], vn[2], hn[2] = {0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      const float *lo = c ? Fm : Fl, *hi = c ? Fh : Fm;
+      if (KIND == K_BURGERS) {
+        un[c] = P[c].a - dt * ((hi[0] - lo[0]) * A.invdx + (G[c][0] - g[c][0]) * invdy);
+        vn[c] = P[c].b - dt * ((hi[1] - lo[1]) * A.invdx + (G[c][1] - g[c][1]) * invdy);
+      } else {
+        float h = P[c].a, mx = h * P[c].b, my = h * P[c].c;
+        h -= dt * ((hi[0] - lo[0]) * A.invdx + (G[c][0] - g[c][0]) * A.invdy);
+        mx -= dt * ((hi[1] - lo[1]) * A.invdx + (G[c][1] - g[c][1]) * A.invdy);
+        my -= dt * ((hi[2] - lo[2]) * A.invdx + (G[c][2] - g[c][2]) * A.invdy);
+        h = fmaxf(h, 1e-6f);
+        const float ih = __builtin_amdgcn_rcpf(h);
+        un[c] = mx * ih; vn[c] = my * ih; hn[c] = h;
+      }
+    }
+    // viscosity on row r-2, store
+    const int o = r - 2;
+    {
+      float u[2] = {w1a[0], w1a[1]}, v[2] = {w1b[0], w1b[1]};
+      if (A.do_visc) {
+        const float ul = __shfl_up(w1a[1], 1, 64), ur = __shfl_down(w1a[0], 1, 64);
+        const float vl = __shfl_up(w1b[1], 1, 64), vr = __shfl_down(w1b[0], 1, 64);
+        const float lu0 = (w1a[1] - 2.0f * w1a[0] + ul) * A.invdx2 + (un[0] - 2.0f * w1a[0] + w0a[0]) * invdy2;
+        const float lu1 = (ur - 2.0f * w1a[1] + w1a[0]) * A.invdx2 + (un[1] - 2.0f * w1a[1] + w0a[1]) * invdy2;
+        const float lv0 = (w1b[1] - 2.0f * w1b[0] + vl) * A.invdx2 + (vn[0] - 2.0f * w1b[0] + w0b[0]) * invdy2;
+        const float lv1 = (vr - 2.0f * w1b[1] + w1b[0]) * A.invdx2 + (vn[1] - 2.0f * w1b[1] + w0b[1]) * invdy2;
+        u[0] += nudt * lu0; u[1] += nudt * lu1; v[0] += nudt * lv0; v[1] += nudt * lv1;
+      }
+      if (own && o >= j0 && o < j1) {
+        const size_t gi = (size_t)o * A.nx + xo;
+        if (KIND == K_BURGERS) {
+          *reinterpret_cast<float2 *>(A.out[0] + gi) = make_float2(fasinh(u[0] * A.inv_u0), fasinh(u[1] * A.inv_u0));
+          *reinterpret_cast<float2 *>(A.out[1] + gi) = make_float2(fasinh(v[0] * A.inv_u0), fasinh(v[1] * A.inv_u0));
+          const float wy = (A.ny > 1) ? A.invdy : 0.0f;
+          red = fmaxf(red, fmaxf(fabsf(u[0]) * A.invdx + fabsf(v[0]) * wy, fabsf(u[1]) * A.invdx + fabsf(v[1]) * wy));
+        } else {
+          *reinterpret_cast<float2 *>(A.out[0] + gi) = make_float2(__builtin_amdgcn_logf(w1h[0]) * 0.69314718055994531f,
+                                                                  __builtin_amdgcn_logf(w1h[1]) * 0.69314718055994531f);
+          *reinterpret_cast<float2 *>(A.out[1] + gi) = make_float2(u[0], u[1]);
+          *reinterpret_cast<float2 *>(A.out[2] + gi) = make_float2(v[0], v[1]);
+          const float c0 = __builtin_amdgcn_sqrtf(A.g * w1h[0]), c1 = __builtin_amdgcn_sqrtf(A.g * w1h[1]);
+          red = fmaxf(red, fmaxf(fmaxf(fabsf(u[0]) + c0, fabsf(v[0]) + c0), fmaxf(fabsf(u[1]) + c1, fabsf(v[1]) + c1)));
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      w0a[c] = w1a[c]; w0b[c] = w1b[c]; w1a[c] = un[c]; w1b[c] = vn[c]; w1h[c] = hn[c];
+      g[c][0] = G[c][0]; g[c][1] = G[c][1]; g[c][2] = G[c][2];
+      P[c] = N[c]; N[c] = nxt[c];
+    }
+  }
+  if (A.reduce) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) red = fmaxf(red, __shfl_xor(red, o, 64));
+    if (lane == 0) tau::atomic_max_float_bits(&A.st->maxbits[(A.slot + 1) % 3], red);
+  }
+}
+
 // MUSCL Burgers as a march.  The limited reconstruction works on the ENCODED phi of four cells along the axis and
 // decodes the two face states (four sinh per face), so phi is carried raw: a four-row window for the y faces
 // (face a-2 | a-1 needs rows a-3 .. a), lanes l-2 .. l+1 for the x faces, three halo lanes a side (own 58 columns).
@@ -697,14 +822,18 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
   // thousands of strips x chunks to fill the chip: 1024^2 24.6 vs 15.9 us per step, 1536^2 28.8 vs 29.4, 4096^2 103 vs 146);
   // TAU_FLOW_MARCH=2 forces it at any size
   if (use_march && !(h->kind == 0 && A.muscl) && P.nx >= 8 && P.ny >= 4 && (use_march > 1 || (long)P.nx * P.ny >= (1L << 21))) {
-    const int nstrips = (P.nx + fl2::MCOLS - 1) / fl2::MCOLS;
+    static const int two = [] { const char *e = getenv("TAU_FLOW_COLS2"); return e ? atoi(e) : 1; }();
+    const bool pair = two && (P.nx % 2 == 0) && P.nx >= 16;        // two columns per lane
+    const int nstrips = pair ? (P.nx + fl2::MCOLS2 - 1) / fl2::MCOLS2 : (P.nx + fl2::MCOLS - 1) / fl2::MCOLS;
     int rows = (int)((long)P.ny * nstrips / 8192);                 // ~8k waves at least, chunks of 8..48 rows (8192^2: 32-48
     rows = rows < 8 ? 8 : (rows > 48 ? 48 : rows);                 // rows 184 Gcell/s, 16: 175, 64: 179, 128: 154)
     static const int rows_env = [] { const char *e = getenv("TAU_FLOW_ROWS"); return e ? atoi(e) : 0; }();
     if (rows_env >= 1) rows = rows_env;
     const int nchunks = (P.ny + rows - 1) / rows;
     const unsigned nwg = (unsigned)((nstrips * nchunks + 3) / 4);
-    if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    if (pair && h->kind == 0) hipLaunchKernelGGL(fl2::k_march2<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    else if (pair) hipLaunchKernelGGL(fl2::k_march2<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    else if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
     else hipLaunchKernelGGL(fl2::k_march<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
   }
   else if (use_march && h->kind == 0 && A.muscl && P.nx >= 8 && P.ny >= 4 && (use_march > 1 || (long)P.nx * P.ny >= (1L << 21))) {
