@@ -86,6 +86,11 @@ struct Args {
   float *out[6];
   const uint8_t *solid;      // halo layout, plane -3 first
   DevClock *clk;
+  // split step (k_flux_xy + k_update_z): decoded-primitive cache of the in / out state (same halo layout; always
+  // bitwise decode() of the encoded arrays) and the x/y flux divergence of the local planes (no halo)
+  const float *q[6];
+  float *qo[6];
+  float *dxy[6];
   int nx, ny, nz;            // global
   int nzl, z0;               // local planes, global index of local plane 0
   int zl_lo, zl_hi;          // local plane range to update
@@ -227,25 +232,29 @@ __device__ __forceinline__ void weno_weights(float t0, float t1, float t2, float
 template <bool FAST>
 __device__ __forceinline__ void weno_face(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
                                           float &R) {
+  // The one-sided slopes 3 D_a - D_b and the candidates 5 D_a - 2 D_b are written on the SECOND differences and with
+  // the factors 2 and 4 only: 3.0 and 5.0 are not inline constants, a VOP3 v_fma cannot carry a literal on gfx950, so
+  // hipcc parks them in SGPRs — and an SGPR source halves the issue rate (profiles/r02/valu_calib.txt: 4.3 against 2.3
+  // cycles).  3 D1 - D0 = 2 D1 + (D1 - D0);  5 D1 - 2 D0 = 2 (3 D1 - D0) - D1.
   const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
-  const float sA = sd_term<FAST>(D1 - D0), sB = sd_term<FAST>(D2 - D1), sC = sd_term<FAST>(D3 - D2),
-              sD = sd_term<FAST>(D4 - D3);
+  const float EA = D1 - D0, EB = D2 - D1, EC = D3 - D2, ED = D4 - D3;
+  const float sA = sd_term<FAST>(EA), sB = sd_term<FAST>(EB), sC = sd_term<FAST>(EC), sD = sd_term<FAST>(ED);
   float sumL, sumR;
   // left state (centre cell v2): stencils {0,1,2} {1,2,3} {2,3,4}
   {
     float a0, a1, a2;
-    weno_weights<FAST>(smooth_t<FAST>(sA, 3.f * D1 - D0), smooth_t<FAST>(sB, D1 + D2),
-                       smooth_t<FAST>(sC, 3.f * D2 - D3), a0, a1, a2);
-    float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    const float e0 = 2.f * D1 + EA;   // 3 D1 - D0
+    weno_weights<FAST>(smooth_t<FAST>(sA, e0), smooth_t<FAST>(sB, D1 + D2), smooth_t<FAST>(sC, 2.f * D2 - EC), a0, a1, a2);
+    float num = a0 * (2.f * e0 - D1) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
     sumL = a0 + a1 + a2;
     L = v2 + num * (rcp(sumL) * (1.f / 6.f));
   }
   // right state (centre cell v3): the mirror image, stencils {5,4,3} {4,3,2} {3,2,1}
   {
     float a0, a1, a2;
-    weno_weights<FAST>(smooth_t<FAST>(sD, 3.f * D3 - D4), smooth_t<FAST>(sC, D3 + D2),
-                       smooth_t<FAST>(sB, 3.f * D2 - D1), a0, a1, a2);
-    float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
+    const float e0 = 2.f * D3 - ED;   // 3 D3 - D4
+    weno_weights<FAST>(smooth_t<FAST>(sD, e0), smooth_t<FAST>(sC, D3 + D2), smooth_t<FAST>(sB, 2.f * D2 + EB), a0, a1, a2);
+    float num = a0 * (D3 - 2.f * e0) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
     sumR = a0 + a1 + a2;
     R = v3 + num * (rcp(sumR) * (1.f / 6.f));
   }
@@ -264,9 +273,11 @@ template <bool FAST>
 __device__ __forceinline__ void weno_face_xshare(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
                                                  float &R) {
   const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
-  const float sB = sd_term<FAST>(D2 - D1), sC = sd_term<FAST>(D3 - D2), sD = sd_term<FAST>(D4 - D3);
-  // own cell (v3): stencils {5,4,3} {4,3,2} {3,2,1}
-  const float t0 = smooth_t<FAST>(sD, 3.f * D3 - D4), t1 = smooth_t<FAST>(sC, D3 + D2), t2 = smooth_t<FAST>(sB, 3.f * D2 - D1);
+  const float EB = D2 - D1, EC = D3 - D2, ED = D4 - D3;
+  const float sB = sd_term<FAST>(EB), sC = sd_term<FAST>(EC), sD = sd_term<FAST>(ED);
+  // own cell (v3): stencils {5,4,3} {4,3,2} {3,2,1}   (inline-constant forms: see weno_face)
+  const float eR = 2.f * D3 - ED;   // 3 D3 - D4
+  const float t0 = smooth_t<FAST>(sD, eR), t1 = smooth_t<FAST>(sC, D3 + D2), t2 = smooth_t<FAST>(sB, 2.f * D2 + EB);
   float w0, w1, w2;
   if (FAST) {
     const float u0 = t1 * t2, u1 = t0 * t2, u2 = t0 * t1;
@@ -276,12 +287,13 @@ __device__ __forceinline__ void weno_face_xshare(float v0, float v1, float v2, f
   }
   {
     const float a0 = 0.1f * w0, a1 = 0.6f * w1, a2 = 0.3f * w2;
-    const float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
+    const float num = a0 * (D3 - 2.f * eR) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
     R = v3 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
   }
   { // cell v2 = the own cell of the lane below: its stencils {0,1,2} {1,2,3} {2,3,4} are that lane's {3,2,1} {4,3,2} {5,4,3}
     const float a0 = 0.1f * lane_below(w2), a1 = 0.6f * lane_below(w1), a2 = 0.3f * lane_below(w0);
-    const float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    const float eL = 2.f * D1 + (D1 - D0);   // 3 D1 - D0
+    const float num = a0 * (2.f * eL - D1) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
     L = v2 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
   }
 }
@@ -290,21 +302,32 @@ __device__ __forceinline__ void weno_face_xshare(float v0, float v1, float v2, f
 template <bool FAST>
 __device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
   const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
+  const float E0 = D1 - D0, E1 = D2 - D1, E2 = D3 - D2;
+  const float eL = 2.f * D1 + E0, eR = 2.f * D2 - E2;   // 3 D1 - D0, 3 D2 - D3 (inline-constant forms: see weno_face)
   float w0, w1, w2; // 0.1 i0, 0.6 i1, 0.3 i2 with i_k = 1 / t_k^2 up to a common factor
-  weno_weights<FAST>(smooth_t<FAST>(sd_term<FAST>(D1 - D0), 3.f * D1 - D0), smooth_t<FAST>(sd_term<FAST>(D2 - D1), D1 + D2),
-                     smooth_t<FAST>(sd_term<FAST>(D3 - D2), 3.f * D2 - D3), w0, w1, w2);
+  weno_weights<FAST>(smooth_t<FAST>(sd_term<FAST>(E0), eL), smooth_t<FAST>(sd_term<FAST>(E1), D1 + D2),
+                     smooth_t<FAST>(sd_term<FAST>(E2), eR), w0, w1, w2);
   float sumL, sumR;
   {
-    float num = w0 * (5.f * D1 - 2.f * D0) + w1 * (2.f * D2 + D1) + w2 * (4.f * D2 - D3);
+    float num = w0 * (2.f * eL - D1) + w1 * (2.f * D2 + D1) + w2 * (4.f * D2 - D3);
     sumL = w0 + w1 + w2;
     Lhi = c0 + num * (rcp(sumL) * (1.f / 6.f));
   }
   { // mirrored roles: a0 = 0.1 i2, a1 = 0.6 i1, a2 = 0.3 i0
     float a0 = (1.f / 3.f) * w2, a2 = 3.f * w0;
-    float num = a0 * (2.f * D3 - 5.f * D2) - w1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
+    float num = a0 * (D2 - 2.f * eR) - w1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
     sumR = a0 + w1 + a2;
     Rlo = c0 + num * (rcp(sumR) * (1.f / 6.f));
   }
+}
+
+// one edge state of a cell only (HI: left state at its high face, else right state at its low face): the same
+// arithmetic as weno_cell, for the ring cells around a tile whose other state nobody reads
+template <bool FAST, bool HI>
+__device__ __forceinline__ float weno_cell_side(float m2, float m1, float c0, float p1, float p2) {
+  float Lhi, Rlo;
+  weno_cell<FAST>(m2, m1, c0, p1, p2, Lhi, Rlo);
+  return HI ? Lhi : Rlo;
 }
 
 __device__ __forceinline__ void prim_floor(Prim &q) { // :565-571
@@ -315,7 +338,17 @@ __device__ __forceinline__ void prim_floor(Prim &q) { // :565-571
 
 // ---------------------------------------------------------------- HLLC blended with HLL, :383-460
 // axis may be a literal (specialised after inlining) or a lane-varying value in {0,1}.
-__device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R, int axis) {
+// The three gas constants hllc needs.  From kernel arguments they are SGPRs, and a VALU instruction with an SGPR source
+// issues at half rate on gfx950 (profiles/r02/valu_calib.txt); kernels with registers to spare copy them to VGPRs once.
+struct Gas { float gamma, gm1, inv_gm1; };
+__device__ __forceinline__ float vreg(float s) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+__device__ __forceinline__ Gas gas_sgpr(const Args &A) { return Gas{A.gamma, A.gm1, A.inv_gm1}; }
+__device__ __forceinline__ Gas gas_vgpr(const Args &A) { return Gas{vreg(A.gamma), vreg(A.gm1), vreg(A.inv_gm1)}; }
+__device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R, int axis) {
   const float rL = L.q[IR], rR = R.q[IR], pL = L.q[IP], pR = R.q[IP];
   const float irL = rcp(rL), irR = rcp(rR);
   const float aL = fsqrt(fmaxf(A.gamma * pL * irL, DENOM_EPS));
@@ -406,6 +439,7 @@ __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R
   }
   return F;
 }
+__device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R, int axis) { return hllc(gas_sgpr(A), L, R, axis); }
 
 // Solid handling of a face between cells `lo` | `hi` (branch structure of :1125-1143): s = solid
 // bits of the six cells around the face (bit 2 = lo, bit 3 = hi).  Any solid in the stencil ->
@@ -474,6 +508,32 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
   } else {
     size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + gx;
     p = decode(A, gi);
+    sol = A.solid[gi] != 0;
+  }
+#pragma unroll
+  for (int m = 0; m < 6; m++) q[m] = p.q[m];
+}
+
+// one field of decode(): what the primitive cache holds for encoded value e of field m
+__device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
+  return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
+}
+// fetch_cell on the primitive cache (no transcendental work)
+__device__ __forceinline__ void fetch_cell_q(const Args &A, int gx, int gyw, int zh, int zg, float (&q)[6], bool &sol) {
+  Prim p;
+  if (gx < 0) {
+    p = inflow_prim(A);
+    sol = sdf_solid(A, gx, gyw, zg);
+  } else if (gx >= A.nx) {
+    const size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + (A.nx - 1);
+#pragma unroll
+    for (int m = 0; m < 6; m++) p.q[m] = A.q[m][gi];
+    p = outflow_prim(A, p);
+    sol = sdf_solid(A, gx, gyw, zg);
+  } else {
+    const size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + gx;
+#pragma unroll
+    for (int m = 0; m < 6; m++) p.q[m] = A.q[m][gi];
     sol = A.solid[gi] != 0;
   }
 #pragma unroll
@@ -784,6 +844,470 @@ __global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
   else step_body<false>(A, S);
 }
 
+// ---------------------------------------------------------------- the split step: k_flux_xy + k_update_z
+// The fused kernel above carries a five-plane register window through a tile that also stages LDS planes: 168 VGPRs,
+// three waves per SIMD, two barriers per plane — and a gfx950 wave issues at most one VALU instruction every ~6-7
+// cycles (profiles/r02/valu_calib.txt), so three resident waves only just cover a ~2.3-cycle pipe and every stall of
+// one of them is lost issue time (measured: 4.0 cycles per instruction against ~3.1 for the instruction mix).
+// The split trades HBM traffic, of which this VALU-bound step uses a tenth, for occupancy:
+//   k_flux_xy   one plane per workgroup, no z dependence at all (so it needs no z halo): stage the tile + x/y halo of
+//               the PRIMITIVE CACHE in LDS, every x / y face once, write the x/y flux divergence (6 floats per cell);
+//   k_update_z  one column per lane, no LDS, no barrier: the z window in registers, every z face once, add the x/y
+//               divergence, update, re-encode, and write the new state AND its decoded primitives.
+// The primitive cache q is bitwise decode() of the encoded state wherever a kernel reads it (k_update_z decodes what
+// it has just encoded; uploads, init and halo refreshes run decode_field on what they wrote), so results are the
+// fused kernel's; what disappears is the exp / sinh work of decoding every cell ~2.7 times per step.
+#ifndef TAU3D_XY_TY
+#define TAU3D_XY_TY 16
+#endif
+constexpr int XT = 32, YT = TAU3D_XY_TY;   // k_flux_xy tile; XT * YT threads
+constexpr int XNT = XT * YT, XNW = XNT / 64;
+constexpr int XPY = YT + 2 * HALO, XPLANE = XPY * PXS;
+static_assert(YT % 2 == 0 && XT + YT <= 64 && 2 * HALO * (XT + YT) <= XNT, "ring rounds are one wave each, halo staging one round");
+// Cell-centred reconstruction in x and y as well: a thread weights its own cell ONCE per axis (weno_cell: the three
+// smoothness indicators serve the left state at the high face and the right state at the low face) and the two states
+// of a face meet through LDS (y) or a lane shift (x).  Around the tile, one ring of cells on each side is evaluated
+// for the one state the tile's outermost faces need: XT + YT lanes of one wave per side, and the XT + YT far faces in a
+// third partial round; the three rounds go to three different waves, rotating with the plane.
+struct XyLds {
+  float sP[6][XPLANE];          // the plane, primitives, x/y halo 3
+  uint8_t sS[XPLANE];
+  float sLy[6][YT + 1][XT];     // [r][x]: left state of the face below row r (from the cell in row r-1; r = 0: ring)
+  float sFy[6][YT + 1][XT];     // flux through that face
+  float sLx0[6][YT];            // left state of the tile's low-x faces (ring cell x = -1)
+  float sLxT[6][YT];            // left state of the far x faces (own column XT-1)
+  float sRxT[6][YT];            // right state of the far x faces (ring cell x = XT)
+  float sRyT[6][XT];            // right state of the far y faces (ring cell y = YT)
+  float sFxT[6][YT];            // flux through the far x faces
+};
+__device__ __forceinline__ float lane_above(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+
+template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S) {
+  auto &sP = S.sP; auto &sS = S.sS;
+  const int tid = threadIdx.x;
+  const int tx = tid & (XT - 1), ty = tid >> 5;
+  const int lane = tid & 63, wave = tid >> 6;
+  const Gas G = gas_vgpr(A);
+
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
+  const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
+  const int by = (int)(b % (unsigned)A.nty);
+  const int bz = (int)(b / (unsigned)A.nty);
+  const int bx0 = bx * XT, by0 = by * YT;
+  const int z = (bz >= A.nzc1) ? A.zl_lo2 + (bz - A.nzc1) : A.zl_lo + bz;   // here a "chunk" is one plane
+
+  const int x = bx0 + tx, y = by0 + ty;
+  const bool in_xy = (x < A.nx) && (y < A.ny);
+  const int yw = wrapi(y, A.ny);
+  const int zh = z + HALO;
+  const int zg = wrapi(A.z0 + z, A.nz);
+  const int lc = (ty + HALO) * PXS + (tx + HALO);
+
+  bool own_solid;
+  size_t hcol;   // column of the halo cell this thread staged (for the next-plane prefetch)
+  { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
+    float q[6];
+    fetch_cell_q(A, x, yw, zh, zg, q, own_solid);
+#pragma unroll
+    for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
+    sS[lc] = own_solid ? 1 : 0;
+    constexpr int NROWS = 2 * HALO * XT;
+    constexpr int NHALO = NROWS + YT * 2 * HALO;
+    hcol = (size_t)yw * A.nx + min(x, A.nx - 1);
+    if (tid < NHALO) {
+      const int p = tid;
+      int ly, lx;
+      if (p < NROWS) {
+        const int r = p / XT;
+        ly = (r < HALO) ? r : r + YT;
+        lx = HALO + (p - r * XT);
+      } else {
+        const int qq = p - NROWS;
+        const int r = qq / (2 * HALO), c = qq - r * (2 * HALO);
+        ly = HALO + r;
+        lx = (c < HALO) ? c : c + XT;
+      }
+      const int gx = bx0 + lx - HALO;
+      const int gy = wrapi(by0 + ly - HALO, A.ny);
+      bool sol;
+      fetch_cell_q(A, gx, gy, zh, zg, q, sol);
+      const int li = ly * PXS + lx;
+#pragma unroll
+      for (int m = 0; m < 6; m++) sP[m][li] = q[m];
+      sS[li] = sol ? 1 : 0;
+      hcol = (size_t)gy * A.nx + min(max(gx, 0), A.nx - 1);
+    }
+  }
+  __syncthreads();
+  // A workgroup lives for one plane, so nothing of its own can hide the HBM latency of that plane's loads.  It pulls
+  // the SAME tile of the next plane into L2 instead (loads into one scratch register, never read): the workgroup that
+  // stages that plane runs about one round of resident workgroups later, on the same XCD (tiles are XCD-contiguous).
+  float pf = 0.f;
+  if (A.zchunk == 1 && zh + 1 < A.nzl + 2 * HALO) {
+    const size_t pn = (size_t)A.nx * A.ny;
+    const size_t o0 = (size_t)(zh + 1) * pn + (size_t)yw * A.nx + min(x, A.nx - 1), o1 = (size_t)(zh + 1) * pn + hcol;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(A.q[m] + o0));
+      asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(A.q[m] + o1));
+    }
+  }
+
+  // ---- edge states of the own cell; ring cells
+  // One variable at a time.  Left alone, hipcc runs the six variables breadth-first (all first differences, then all
+  // smoothness indicators, ...) and needs ~140 VGPRs for it; occupancy is worth more than that ILP here.  The empty asm
+  // ties the next variable's LDS address to this variable's results, which orders them.
+  float Rx[6], Ry[6], Lxo[6];
+  int lcs = lc;
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    const float *p = &sP[m][lcs];
+    float Ly;
+    weno_cell<FAST>(p[-2], p[-1], p[0], p[1], p[2], Lxo[m], Rx[m]);
+    weno_cell<FAST>(p[-2 * PXS], p[-PXS], p[0], p[PXS], p[2 * PXS], Ly, Ry[m]);
+    S.sLy[m][ty + 1][tx] = Ly;
+    asm volatile("" : "+v"(lcs), "+v"(Lxo[m]), "+v"(Rx[m]), "+v"(Ry[m]));
+  }
+  if (tx == XT - 1) {
+#pragma unroll
+    for (int m = 0; m < 6; m++) S.sLxT[m][ty] = Lxo[m];
+  }
+  const int wA = (int)((unsigned)z % (unsigned)XNW), wB = (wA + 1) % XNW, wC = (wA + 2) % XNW;
+  if (wave == wA && lane < XT + YT) { // low ring: left states of the cells at x = -1 and y = -1
+    const bool isx = lane < YT;
+    const int c0 = isx ? (lane + HALO) * PXS + (HALO - 1) : (HALO - 1) * PXS + (lane - YT + HALO);
+    const int st = isx ? 1 : PXS;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      const float *p = &sP[m][c0];
+      const float v = weno_cell_side<FAST, true>(p[-2 * st], p[-st], p[0], p[st], p[2 * st]);
+      if (isx) S.sLx0[m][lane] = v; else S.sLy[m][0][lane - YT] = v;
+    }
+  }
+  if (wave == wB && lane < XT + YT) { // high ring: right states of the cells at x = XT and y = YT
+    const bool isx = lane < YT;
+    const int c0 = isx ? (lane + HALO) * PXS + (XT + HALO) : (YT + HALO) * PXS + (lane - YT + HALO);
+    const int st = isx ? 1 : PXS;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      const float *p = &sP[m][c0];
+      const float v = weno_cell_side<FAST, false>(p[-2 * st], p[-st], p[0], p[st], p[2 * st]);
+      if (isx) S.sRxT[m][lane] = v; else S.sRyT[m][lane - YT] = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- faces: low-x and low-y of the own cell; the tile's far faces
+  float Fx[6], Fy[6];
+  {
+    Prim L, R;
+    float lo[6], hi[6];
+    unsigned s = 0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      const float l = lane_below(Lxo[m]);
+      L.q[m] = (tx == 0) ? S.sLx0[m][ty] : l;
+      R.q[m] = Rx[m];
+      lo[m] = sP[m][lc - 1]; hi[m] = sP[m][lc];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) s |= (unsigned)sS[lc + (k - 3)] << k;
+    solid_override(L, R, lo, hi, s, 0);
+    prim_floor(L);
+    prim_floor(R);
+    const Cons F = hllc(G, L, R, 0);
+#pragma unroll
+    for (int m = 0; m < 6; m++) Fx[m] = F.c[m];
+  }
+#ifdef TAU3D_XY_SCHED_BARRIER
+  __builtin_amdgcn_sched_barrier(0);   // do not start fetching the y face's operands while the x face is in flight
+#endif
+  {
+    Prim L, R;
+    float lo[6], hi[6];
+    unsigned s = 0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      L.q[m] = S.sLy[m][ty][tx];
+      R.q[m] = Ry[m];
+      lo[m] = sP[m][lc - PXS]; hi[m] = sP[m][lc];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) s |= (unsigned)sS[lc + (k - 3) * PXS] << k;
+    solid_override(L, R, lo, hi, s, 1);
+    prim_floor(L);
+    prim_floor(R);
+    const Cons F = hllc(G, L, R, 1);
+#pragma unroll
+    for (int m = 0; m < 6; m++) { Fy[m] = F.c[m]; S.sFy[m][ty][tx] = F.c[m]; }
+  }
+  if (wave == wC && lane < XT + YT) { // far faces: x faces at column XT (rows 0 .. YT-1), y faces at row YT
+    const bool isx = lane < YT;
+    const int c0 = isx ? (lane + HALO) * PXS + (XT + HALO) : (YT + HALO) * PXS + (lane - YT + HALO);   // the cell above the face
+    const int st = isx ? 1 : PXS;
+    Prim L, R;
+    float lo[6], hi[6];
+    unsigned s = 0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      L.q[m] = isx ? S.sLxT[m][lane] : S.sLy[m][YT][lane - YT];
+      R.q[m] = isx ? S.sRxT[m][lane] : S.sRyT[m][lane - YT];
+      lo[m] = sP[m][c0 - st]; hi[m] = sP[m][c0];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) s |= (unsigned)sS[c0 + (k - 3) * st] << k;
+    solid_override_xy(L, R, lo, hi, s, isx);
+    prim_floor(L);
+    prim_floor(R);
+    const Cons F = hllc(G, L, R, isx ? 0 : 1);
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      if (isx) S.sFxT[m][lane] = F.c[m]; else S.sFy[m][YT][lane - YT] = F.c[m];
+    }
+  }
+  __syncthreads();
+
+  // ---- x/y flux divergence of the own cell
+  const size_t di = (size_t)z * ((size_t)A.nx * A.ny) + (size_t)yw * A.nx + min(x, A.nx - 1);
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    const float up = lane_above(Fx[m]);
+    const float fxh = (tx == XT - 1) ? S.sFxT[m][ty] : up;
+    const float d = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
+    if (in_xy && !own_solid) A.dxy[m][di] = d;
+  }
+  // the prefetch register must stay allocated until its loads have returned
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf));
+}
+
+#ifndef TAU3D_XY_WAVES
+#define TAU3D_XY_WAVES 6
+#endif
+__global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
+  __shared__ XyLds S;
+  if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) flux_xy_body<true>(A, S);
+  else flux_xy_body<false>(A, S);
+}
+
+// k_update_z: a wave owns 64 consecutive x of one row and marches a chunk of planes; ZT_Y rows per workgroup.
+// The five-plane window of the column (planes z-1 .. z+3) lives in LDS, one private slot per thread and plane
+// (ring of five, no barrier: a thread only ever reads what it wrote): in registers it costs 30 VGPRs and 24 moves
+// per plane to slide, and pushed the kernel to 148 VGPRs / three waves.
+constexpr int ZT_X = 64, ZT_Y = 4, ZNT = ZT_X * ZT_Y;
+typedef float ZRing[5][6][ZNT];
+template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring) {
+  const int tid = threadIdx.x;
+  const int lx = tid & (ZT_X - 1), ly = tid >> 6;
+  const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
+  const unsigned nb = (unsigned)(nbx * nby * A.nzc);
+  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
+  const int bx = (int)(b % (unsigned)nbx); b /= (unsigned)nbx;
+  const int by = (int)(b % (unsigned)nby);
+  const int bz = (int)(b / (unsigned)nby);
+  const bool second = bz >= A.nzc1;
+  const int zc_lo = second ? A.zl_lo2 + (bz - A.nzc1) * A.zchunk : A.zl_lo + bz * A.zchunk;
+  const int zc_hi = min(zc_lo + A.zchunk, second ? A.zl_hi2 : A.zl_hi);
+
+  const int x = bx * ZT_X + lx, y = by * ZT_Y + ly;
+  const bool in_xy = (x < A.nx) && (y < A.ny);
+  const size_t plane_n = (size_t)A.nx * A.ny;
+  const size_t col = (size_t)min(y, A.ny - 1) * A.nx + min(x, A.nx - 1);
+
+  const float dt = A.clk->dt;
+  const float gain = A.clk->gain;
+
+  unsigned ws = 0;
+  auto load_own = [&](int zl, float (&dst)[6]) -> unsigned {
+    const size_t gi = (size_t)(zl + HALO) * plane_n + col;
+#pragma unroll
+    for (int m = 0; m < 6; m++) dst[m] = A.q[m][gi];
+    return A.solid[gi] != 0 ? 1u : 0u;
+  };
+
+  // prologue: planes zc_lo-2 .. zc_lo+2 into slots 0 .. 4 (plane zc_lo-3 is only needed here); flux through the low
+  // face of plane zc_lo and the left state cell zc_lo contributes to its high face
+  float Fz_lo[6], Lz[6];
+  {
+    float T[6], P[6];
+    ws |= load_own(zc_lo - 3, T) << 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      ws |= load_own(zc_lo - 2 + k, P) << (k + 1);
+#pragma unroll
+      for (int m = 0; m < 6; m++) ring[k][m][tid] = P[m];
+    }
+    Prim L, R;
+    float lo[6], hi[6];
+    int ts = tid;
+#pragma unroll
+    for (int m = 0; m < 6; m++) {
+      const float w0 = ring[0][m][ts], w1 = ring[1][m][ts], w2 = ring[2][m][ts], w3 = ring[3][m][ts], w4 = ring[4][m][ts];
+      L.q[m] = weno_cell_side<FAST, true>(T[m], w0, w1, w2, w3);
+      weno_cell<FAST>(w0, w1, w2, w3, w4, Lz[m], R.q[m]);
+      lo[m] = w1; hi[m] = w2;
+      asm volatile("" : "+v"(ts), "+v"(L.q[m]), "+v"(Lz[m]), "+v"(R.q[m]));
+    }
+    solid_override(L, R, lo, hi, ws, 2);
+    prim_floor(L);
+    prim_floor(R);
+    Cons F = hllc(A, L, R, 2);
+#pragma unroll
+    for (int m = 0; m < 6; m++) Fz_lo[m] = F.c[m];
+  }
+
+  float smax = 0.f, fmx = 0.f;
+  // plane z+3 of the first iteration; afterwards every iteration fetches the plane the NEXT one slides in
+  float Nx[6];
+  unsigned nsol = load_own(zc_lo + 3, Nx);
+  int base = 0;      // ring slot that plane z+3 takes over (it held plane z-2); plane z-1+k sits in slot (base+1+k) % 5
+
+  for (int z = zc_lo; z < zc_hi; z++) {
+#pragma unroll
+    for (int m = 0; m < 6; m++) ring[base][m][tid] = Nx[m];
+    ws = (ws >> 1) | (nsol << 5);
+    if (z + 1 < zc_hi) nsol = load_own(z + 4, Nx);
+    const int s0 = base + 1 >= 5 ? base - 4 : base + 1, s1 = base + 2 >= 5 ? base - 3 : base + 2,
+              s2 = base + 3 >= 5 ? base - 2 : base + 3, s3 = base + 4 >= 5 ? base - 1 : base + 4, s4 = base;
+    base = s0;
+
+    const size_t gi = (size_t)(z + HALO) * plane_n + col;
+    const size_t di = (size_t)z * plane_n + col;
+    const bool own_solid = (ws >> 2) & 1u;
+
+    float Fz_hi[6];
+    float own[6];
+    {
+      Prim L, R;
+      float hi[6];
+#pragma unroll
+      for (int m = 0; m < 6; m++) L.q[m] = Lz[m];
+      int ts = tid;   // one variable at a time (see k_flux_xy): the empty asm orders the next variable's LDS reads behind this one
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        const float w0 = ring[s0][m][ts], w1 = ring[s1][m][ts], w2 = ring[s2][m][ts], w3 = ring[s3][m][ts], w4 = ring[s4][m][ts];
+        weno_cell<FAST>(w0, w1, w2, w3, w4, Lz[m], R.q[m]);
+        own[m] = w1; hi[m] = w2;
+        asm volatile("" : "+v"(ts), "+v"(Lz[m]), "+v"(R.q[m]));
+      }
+      solid_override(L, R, own, hi, ws, 2);
+      prim_floor(L);
+      prim_floor(R);
+      Cons F = hllc(A, L, R, 2);
+#pragma unroll
+      for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
+    }
+
+    float D[6];
+#pragma unroll
+    for (int m = 0; m < 6; m++) D[m] = (in_xy && !own_solid) ? A.dxy[m][di] : 0.f;
+
+    if (in_xy) {
+      if (own_solid) { // :1063-1072 copy-through
+#pragma unroll
+        for (int m = 0; m < 6; m++) { A.out[m][gi] = A.in[m][gi]; A.qo[m][gi] = own[m]; }
+      } else {
+        const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
+        float U0[6];
+        U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
+        {
+          float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
+          float eth = p0 * rcp(fmaxf(A.gm1 * r0, RHO_P_FLOOR));
+          U0[4] = r0 * (ke + eth + e0);
+          U0[5] = r0 * e0;
+        }
+        float U1[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          float dU = -(D[m] + (Fz_hi[m] - Fz_lo[m]) * A.inv_dz);
+          U1[m] = U0[m] + dU * dt;
+        }
+        float r1 = fmaxf(U1[0], RHO_P_FLOOR);
+        float ir1 = rcp(r1);
+        float u1 = U1[1] * ir1, v1 = U1[2] * ir1, w1 = U1[3] * ir1;
+        float ke = 0.5f * (u1 * u1 + v1 * v1 + w1 * w1);
+        float ev1 = fmaxf(U1[5] * ir1, 0.f);
+        float e_th = fmaxf(U1[4] * ir1 - ke - ev1, THERMAL_ENERGY_FLOOR);
+        float p1 = fmaxf(A.gm1 * r1 * e_th, RHO_P_FLOOR);
+        const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
+                           __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
+                         r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
+        if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; }
+        float T1 = p1 * rcp(r1 * A.R);
+        ev1 = fmaxf(ev1 + (evib_eq(A, T1) - ev1) * (dt * A.inv_tau_vib), 0.f);
+
+        if (A.sponge_n > 0 && x < A.sponge_n) {
+          float s = 1.0f - (float)x / (float)A.sponge_n;
+          s = fminf(fmaxf(s, 0.0f), 1.0f);
+          float k = A.sponge_strength * (s * s);
+          r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
+          p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
+          u1 = u1 + k * (gain * A.in_u - u1);
+          v1 = v1 + k * (gain * A.in_v - v1);
+          w1 = w1 + k * (gain * A.in_w - w1);
+          ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+        }
+        if (A.sponge_out_n > 0 && x >= (A.nx - A.sponge_out_n)) {
+          int xo2 = x - (A.nx - A.sponge_out_n);
+          float s = (float)xo2 / (float)A.sponge_out_n;
+          s = fminf(fmaxf(s, 0.0f), 1.0f);
+          float k = A.sponge_out_strength * (s * s);
+          r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
+          p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
+          u1 = u1 + k * (0.0f - u1);
+          v1 = v1 + k * (0.0f - v1);
+          w1 = w1 + k * (0.0f - w1);
+          ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+        }
+        float a = soundspeed(A, p1, r1);
+        float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
+        if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
+        fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
+
+        float E[6];
+        E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
+        E[1] = fasinh(u1 * A.inv_u_ref);
+        E[2] = fasinh(v1 * A.inv_u_ref);
+        E[3] = fasinh(w1 * A.inv_u_ref);
+        E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
+        E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
+#pragma unroll
+        for (int m = 0; m < 6; m++) { A.out[m][gi] = E[m]; A.qo[m][gi] = decode_field(A.u_ref, m, E[m]); }
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+  }
+
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+    fmx = fmaxf(fmx, __shfl_xor(fmx, o, 64));
+  }
+  if (lx == 0) {
+    tau::atomic_max_float_bits(&A.clk->maxs_bits, smax);
+    tau::atomic_max_float_bits(&A.clk->fmax_bits, fmx);
+  }
+}
+
+// W = waves per SIMD the register allocator is asked for (the launch picks one: TAU3D_Z_WAVES, default 4)
+template <int W> __global__ __launch_bounds__(ZNT, W) void k_update_z(const Args A) {
+  __shared__ ZRing ring;
+  if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) update_z_body<true>(A, ring);
+  else update_z_body<false>(A, ring);
+}
+
+// primitive cache of planes [zh_lo, zh_hi) of the halo layout from the encoded arrays (after init / upload / a halo refresh)
+__global__ __launch_bounds__(256) void k_decode_planes(Args A, int zh_lo, int zh_hi) {
+  const size_t n0 = (size_t)A.nx * A.ny * zh_lo, n1 = (size_t)A.nx * A.ny * zh_hi;
+  for (size_t i = n0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (size_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int m = 0; m < 6; m++) A.qo[m][i] = decode_field(A.u_ref, m, A.in[m][i]);
+  }
+}
+
 // ---------------------------------------------------------------- small kernels
 __global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes included
   size_t n = (size_t)A.nx * A.ny * (A.nzl + 2 * HALO);
@@ -833,7 +1357,7 @@ __device__ __forceinline__ void clock_end(DevClock *c) { // d_tau controller, :1
 // The single-domain step loop folds the two 1-thread clock kernels into the halo copy that precedes every k_step
 // (controller of the step before, then the clock of this one): two dependent dispatches per step instead of four,
 // which is what a 64^3 run is made of (clk == nullptr: plain halo copy).
-struct HaloArgs { float *f[6]; size_t plane_n; int nzl; DevClock *clk; int do_end; };
+struct HaloArgs { float *f[12]; size_t plane_n; int nzl; DevClock *clk; int do_end; };   // 6 encoded fields (+ 6 of the primitive cache)
 __global__ void k_halo_periodic(HaloArgs H) {
   if (H.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (H.do_end) clock_end(H.clk);
@@ -849,7 +1373,7 @@ __global__ void k_halo_periodic(HaloArgs H) {
 }
 
 // packed halo exchange: boundary planes of 6 fields <-> one contiguous buffer per side
-struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; };
+struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; float *q[6]; float u_ref; };   // q: primitive cache to refresh on unpack (or null)
 // dir 0: pack (send side s <- first / last 3 interior planes); dir 1: unpack (recv side s -> halo planes)
 __global__ void k_halo_pack(PackArgs P, int dir) {
   const size_t n3 = (size_t)HALO * P.plane_n;
@@ -858,12 +1382,22 @@ __global__ void k_halo_pack(PackArgs P, int dir) {
   float *b = P.buf[side] + (size_t)f * n3;
   float *planes = dir == 0 ? (side == 0 ? fld + (size_t)HALO * P.plane_n : fld + (size_t)P.nzl * P.plane_n)
                            : (side == 0 ? fld : fld + (size_t)(P.nzl + HALO) * P.plane_n);
+  float *qpl = (dir == 1 && P.q[f]) ? (side == 0 ? P.q[f] : P.q[f] + (size_t)(P.nzl + HALO) * P.plane_n) : nullptr;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n3; i += (size_t)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n3) {
       if (dir == 0) *reinterpret_cast<float4 *>(b + i) = *reinterpret_cast<const float4 *>(planes + i);
-      else *reinterpret_cast<float4 *>(planes + i) = *reinterpret_cast<const float4 *>(b + i);
+      else {
+        const float4 v = *reinterpret_cast<const float4 *>(b + i);
+        *reinterpret_cast<float4 *>(planes + i) = v;
+        if (qpl)
+          *reinterpret_cast<float4 *>(qpl + i) = make_float4(decode_field(P.u_ref, f, v.x), decode_field(P.u_ref, f, v.y),
+                                                             decode_field(P.u_ref, f, v.z), decode_field(P.u_ref, f, v.w));
+      }
     } else {
-      for (size_t k = i; k < n3; k++) { if (dir == 0) b[k] = planes[k]; else planes[k] = b[k]; }
+      for (size_t k = i; k < n3; k++) {
+        if (dir == 0) b[k] = planes[k];
+        else { planes[k] = b[k]; if (qpl) qpl[k] = decode_field(P.u_ref, f, b[k]); }
+      }
     }
   }
 }
@@ -1053,6 +1587,9 @@ struct tau3d {
   bool own_stream;
   size_t plane_n, field_n;  // floats per plane, floats per field incl. halo
   float *buf[2][6];         // ping-pong, halo layout
+  float *qbuf[2][6];        // split step: primitive cache of buf (same layout), bitwise decode() of it
+  float *dxy[6];            // split step: x/y flux divergence of the local planes
+  bool split;               // step = k_flux_xy + k_update_z (else the fused k_step)
   uint8_t *solid;
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
@@ -1136,8 +1673,21 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   h->own_stream = (stream == nullptr);
   if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   else h->stream = (hipStream_t)stream;
+  // the split step pays off where the fused kernel is occupancy bound (large planes); small grids are bound by
+  // the latency between dependent dispatches and keep the one-kernel step.  TAU3D_SPLIT=0/1 overrides.
+  h->split = (long)p->nx * p->ny >= 128L * 128L;
+  if (const char *e = getenv("TAU3D_SPLIT")) h->split = atoi(e) != 0;
   for (int s = 0; s < 2; s++)
-    for (int f = 0; f < 6; f++) TAU_HIP(hipMalloc(&h->buf[s][f], h->field_n * sizeof(float)));
+    for (int f = 0; f < 6; f++) {
+      TAU_HIP(hipMalloc(&h->buf[s][f], h->field_n * sizeof(float)));
+      TAU_HIP(hipMemsetAsync(h->buf[s][f], 0, h->field_n * sizeof(float), h->stream));
+      if (h->split) {
+        TAU_HIP(hipMalloc(&h->qbuf[s][f], h->field_n * sizeof(float)));
+        TAU_HIP(hipMemsetAsync(h->qbuf[s][f], 0, h->field_n * sizeof(float), h->stream));
+      }
+    }
+  if (h->split)
+    for (int f = 0; f < 6; f++) TAU_HIP(hipMalloc(&h->dxy[f], h->plane_n * (size_t)nzl * sizeof(float)));
   TAU_HIP(hipMalloc(&h->solid, h->field_n));
   TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
   for (int k = 0; k < 2; k++)
@@ -1145,6 +1695,10 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
   fill_consts(h);
+  // the solid mask depends on the parameters and the slab only: a caller that goes create -> upload -> step
+  // (without tau3d_init) must find it built (and the state buffers defined: zeroed above)
+  hipLaunchKernelGGL(h3d::k_build_solid, dim3(1024), dim3(256), 0, h->stream, h->solid, h->base);
+  TAU_LAUNCH_CHECK("k_build_solid");
   { // nothing is known about the state yet: the first k_step takes the reciprocal form unless init / upload measured it
     h3d::DevClock c0;
     memset(&c0, 0, sizeof(c0));
@@ -1163,7 +1717,8 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   for (int s = 0; s < 2; s++)
-    for (int f = 0; f < 6; f++) hipFree(h->buf[s][f]);
+    for (int f = 0; f < 6; f++) { hipFree(h->buf[s][f]); hipFree(h->qbuf[s][f]); }
+  for (int f = 0; f < 6; f++) hipFree(h->dxy[f]);
   hipFree(h->solid);
   hipFree(h->clk);
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
@@ -1201,6 +1756,11 @@ static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
   for (int f = 0; f < 6; f++) a.in[f] = h->buf[h->cur][f];
   hipLaunchKernelGGL(h3d::k_field_max, dim3(1024), dim3(256), 0, h->stream, a, zl_lo + h3d::HALO, zl_hi + h3d::HALO);
   TAU_LAUNCH_CHECK("k_field_max");
+  if (h->split) { // ... and their primitive cache
+    for (int f = 0; f < 6; f++) a.qo[f] = h->qbuf[h->cur][f];
+    hipLaunchKernelGGL(h3d::k_decode_planes, dim3(2048), dim3(256), 0, h->stream, a, zl_lo + h3d::HALO, zl_hi + h3d::HALO);
+    TAU_LAUNCH_CHECK("k_decode_planes");
+  }
   return 0;
 }
 
@@ -1292,9 +1852,9 @@ static int flush_clock(tau3d_t *h) { // the deferred k_clock_end of tau3d_step_a
 static int fill_halo(tau3d_t *h, bool with_clock) {
   h3d::HaloArgs H;
   H.clk = with_clock ? h->clk : nullptr; H.do_end = h->end_pending ? 1 : 0;
-  for (int f = 0; f < 6; f++) H.f[f] = h->buf[h->cur][f];
+  for (int f = 0; f < 6; f++) { H.f[f] = h->buf[h->cur][f]; H.f[6 + f] = h->split ? h->qbuf[h->cur][f] : nullptr; }
   H.plane_n = h->plane_n; H.nzl = h->nzl;
-  hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, 12), dim3(256), 0, h->stream, H);
+  hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, h->split ? 24 : 12), dim3(256), 0, h->stream, H);
   TAU_LAUNCH_CHECK("k_halo_periodic");
   if (with_clock) h->end_pending = false;
   return 0;
@@ -1310,6 +1870,42 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
   for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
   int nplanes = zl_hi - zl_lo;           // chunking is chosen for the first range; a second range has the same length
+  if (h->split) {
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+    for (int f = 0; f < 6; f++) { A.q[f] = h->qbuf[h->cur][f]; A.qo[f] = h->qbuf[h->cur ^ 1][f]; A.dxy[f] = h->dxy[f]; }
+    A.zl_lo2 = zl_lo2; A.zl_hi2 = zl_hi2;
+    const int n2 = two ? zl_hi2 - zl_lo2 : 0;
+    const bool tm = h->timing && h->n_ev < 4096;
+    if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s));
+    { // x/y faces: one plane per workgroup
+      h3d::Args X = A;
+      X.zchunk = 1; X.nzc1 = nplanes; X.nzc = nplanes + n2;
+      X.ntx = (A.nx + h3d::XT - 1) / h3d::XT; X.nty = (A.ny + h3d::YT - 1) / h3d::YT;
+      hipLaunchKernelGGL(h3d::k_flux_xy, dim3((unsigned)(X.ntx * X.nty * X.nzc)), dim3(h3d::XNT), 0, s, X);
+      TAU_LAUNCH_CHECK("k_flux_xy");
+    }
+    { // z faces + update: a wave marches a chunk of planes; ~4k workgroups (four rounds of the 1024 resident ones)
+      h3d::Args Z = A;
+      const long tz = (long)((A.nx + h3d::ZT_X - 1) / h3d::ZT_X) * ((A.ny + h3d::ZT_Y - 1) / h3d::ZT_Y);
+      int zc = h->zchunk;
+      if (zc <= 0) { zc = (int)((long)(nplanes + n2) * tz / 4096); zc = zc < 4 ? 4 : (zc > 64 ? 64 : zc); }
+      Z.zchunk = zc < nplanes ? zc : nplanes;
+      Z.nzc1 = (nplanes + Z.zchunk - 1) / Z.zchunk;
+      Z.nzc = Z.nzc1 + (two ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
+      static const int zw = [] { const char *e = getenv("TAU3D_Z_WAVES"); return e ? atoi(e) : 4; }();
+      const dim3 g((unsigned)(tz * Z.nzc)), bl(h3d::ZNT);
+      if (zw <= 3) hipLaunchKernelGGL(h3d::k_update_z<3>, g, bl, 0, s, Z);
+      else if (zw == 4) hipLaunchKernelGGL(h3d::k_update_z<4>, g, bl, 0, s, Z);
+      else hipLaunchKernelGGL(h3d::k_update_z<5>, g, bl, 0, s, Z);
+      TAU_LAUNCH_CHECK("k_update_z");
+    }
+    if (tm) {
+      TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
+      h->n_ev++;
+      h->ev_cells += (double)(nplanes + n2) * (double)h->plane_n;
+    }
+    return 0;
+  }
   // Planes marched by one workgroup.  Large grids: enough workgroups (~32k) to load-balance 256 CUs x 3 resident
   // groups, chunks of 8..32 planes (a chunk re-decodes 4 warm-up planes, so longer is cheaper).  Small grids are
   // LATENCY bound instead — a 64^3 launch is 128 workgroups of 13 serial plane iterations with chunks of 8 — so
@@ -1417,7 +2013,8 @@ static int halo_pack(tau3d_t *h, int which, int dir) {
   h3d::PackArgs P;
   for (int f = 0; f < 6; f++) P.f[f] = h->buf[h->cur ^ (which & 1)][f];
   P.buf[0] = h->xbuf[dir][0]; P.buf[1] = h->xbuf[dir][1];
-  P.plane_n = h->plane_n; P.nzl = h->nzl;
+  P.plane_n = h->plane_n; P.nzl = h->nzl; P.u_ref = h->p.u_ref;
+  for (int f = 0; f < 6; f++) P.q[f] = (h->split && dir == 1) ? h->qbuf[h->cur ^ (which & 1)][f] : nullptr;
   hipLaunchKernelGGL(h3d::k_halo_pack, dim3(32, 12), dim3(256), 0, h->stream, P, dir);
   TAU_LAUNCH_CHECK("k_halo_pack");
   return 0;
