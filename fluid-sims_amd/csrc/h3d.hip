@@ -36,6 +36,9 @@
 
 namespace h3d {
 
+#ifndef TAU3D_STEP_WAVES
+#define TAU3D_STEP_WAVES 2
+#endif
 constexpr int HALO = 3;            // WENO_HALO, tau_hypersonic_3d_cuda.cu:58
 // TY = 12 (six waves: the 56 edge faces would be shared by six waves instead of 48 by four) was measured: a
 // six-wave workgroup lands 2+2+1+1 on the four SIMDs and a second one no longer fits under the 3-waves-per-SIMD
@@ -321,6 +324,81 @@ __device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1
   }
 }
 
+// ---- the r01 forms of the three reconstructions (3.0 / 5.0 factors, SGPR-resident): the fused k_step keeps them — with
+// the inline-constant forms it needs 174 VGPRs instead of 168 and drops from three waves per SIMD to two
+template <bool FAST>
+__device__ __forceinline__ void weno_face_r01(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
+                                          float &R) {
+  const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
+  const float sA = sd_term<FAST>(D1 - D0), sB = sd_term<FAST>(D2 - D1), sC = sd_term<FAST>(D3 - D2),
+              sD = sd_term<FAST>(D4 - D3);
+  float sumL, sumR;
+  // left state (centre cell v2): stencils {0,1,2} {1,2,3} {2,3,4}
+  {
+    float a0, a1, a2;
+    weno_weights<FAST>(smooth_t<FAST>(sA, 3.f * D1 - D0), smooth_t<FAST>(sB, D1 + D2),
+                       smooth_t<FAST>(sC, 3.f * D2 - D3), a0, a1, a2);
+    float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    sumL = a0 + a1 + a2;
+    L = v2 + num * (rcp(sumL) * (1.f / 6.f));
+  }
+  // right state (centre cell v3): the mirror image, stencils {5,4,3} {4,3,2} {3,2,1}
+  {
+    float a0, a1, a2;
+    weno_weights<FAST>(smooth_t<FAST>(sD, 3.f * D3 - D4), smooth_t<FAST>(sC, D3 + D2),
+                       smooth_t<FAST>(sB, 3.f * D2 - D1), a0, a1, a2);
+    float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
+    sumR = a0 + a1 + a2;
+    R = v3 + num * (rcp(sumR) * (1.f / 6.f));
+  }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void weno_face_xshare_r01(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
+                                                 float &R) {
+  const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
+  const float sB = sd_term<FAST>(D2 - D1), sC = sd_term<FAST>(D3 - D2), sD = sd_term<FAST>(D4 - D3);
+  // own cell (v3): stencils {5,4,3} {4,3,2} {3,2,1}
+  const float t0 = smooth_t<FAST>(sD, 3.f * D3 - D4), t1 = smooth_t<FAST>(sC, D3 + D2), t2 = smooth_t<FAST>(sB, 3.f * D2 - D1);
+  float w0, w1, w2;
+  if (FAST) {
+    const float u0 = t1 * t2, u1 = t0 * t2, u2 = t0 * t1;
+    w0 = u0 * u0; w1 = u1 * u1; w2 = u2 * u2;
+  } else {
+    w0 = inv_sq(t0); w1 = inv_sq(t1); w2 = inv_sq(t2);
+  }
+  {
+    const float a0 = 0.1f * w0, a1 = 0.6f * w1, a2 = 0.3f * w2;
+    const float num = a0 * (2.f * D4 - 5.f * D3) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
+    R = v3 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+  { // cell v2 = the own cell of the lane below: its stencils {0,1,2} {1,2,3} {2,3,4} are that lane's {3,2,1} {4,3,2} {5,4,3}
+    const float a0 = 0.1f * lane_below(w2), a1 = 0.6f * lane_below(w1), a2 = 0.3f * lane_below(w0);
+    const float num = a0 * (5.f * D1 - 2.f * D0) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
+    L = v2 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
+  }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void weno_cell_r01(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
+  const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
+  float w0, w1, w2; // 0.1 i0, 0.6 i1, 0.3 i2 with i_k = 1 / t_k^2 up to a common factor
+  weno_weights<FAST>(smooth_t<FAST>(sd_term<FAST>(D1 - D0), 3.f * D1 - D0), smooth_t<FAST>(sd_term<FAST>(D2 - D1), D1 + D2),
+                     smooth_t<FAST>(sd_term<FAST>(D3 - D2), 3.f * D2 - D3), w0, w1, w2);
+  float sumL, sumR;
+  {
+    float num = w0 * (5.f * D1 - 2.f * D0) + w1 * (2.f * D2 + D1) + w2 * (4.f * D2 - D3);
+    sumL = w0 + w1 + w2;
+    Lhi = c0 + num * (rcp(sumL) * (1.f / 6.f));
+  }
+  { // mirrored roles: a0 = 0.1 i2, a1 = 0.6 i1, a2 = 0.3 i0
+    float a0 = (1.f / 3.f) * w2, a2 = 3.f * w0;
+    float num = a0 * (2.f * D3 - 5.f * D2) - w1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
+    sumR = a0 + w1 + a2;
+    Rlo = c0 + num * (rcp(sumR) * (1.f / 6.f));
+  }
+}
+
 // one edge state of a cell only (HI: left state at its high face, else right state at its low face): the same
 // arithmetic as weno_cell, for the ring cells around a tile whose other state nobody reads
 template <bool FAST, bool HI>
@@ -485,8 +563,8 @@ __device__ __forceinline__ Cons face_flux6(const Args &A, const float (&v)[6][6]
   Prim L, R;
 #pragma unroll
   for (int m = 0; m < 6; m++) {
-    if (XSHARE) weno_face_xshare<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
-    else weno_face<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+    if (XSHARE) weno_face_xshare_r01<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+    else weno_face_r01<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
   }
   solid_override(L, R, v[2], v[3], s, axis);
   prim_floor(L);
@@ -598,8 +676,8 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
 #pragma unroll
     for (int m = 0; m < 6; m++) {
       float Rdummy;
-      weno_cell<FAST>(T[m], W[0][m], W[1][m], W[2][m], W[3][m], L.q[m], Rdummy);      // cell zc_lo-1 -> L at zc_lo-1/2
-      weno_cell<FAST>(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lz[m], R.q[m]);     // cell zc_lo -> R there, L above
+      weno_cell_r01<FAST>(T[m], W[0][m], W[1][m], W[2][m], W[3][m], L.q[m], Rdummy);      // cell zc_lo-1 -> L at zc_lo-1/2
+      weno_cell_r01<FAST>(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lz[m], R.q[m]);     // cell zc_lo -> R there, L above
     }
     solid_override(L, R, W[1], W[2], ws, 2);
     prim_floor(L);
@@ -706,7 +784,7 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
       }
       Prim L, R;
 #pragma unroll
-      for (int m = 0; m < 6; m++) weno_face<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
+      for (int m = 0; m < 6; m++) weno_face_r01<FAST>(v[0][m], v[1][m], v[2][m], v[3][m], v[4][m], v[5][m], L.q[m], R.q[m]);
       solid_override_xy(L, R, v[2], v[3], s, isx);
       prim_floor(L);
       prim_floor(R);
@@ -727,7 +805,7 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
 #pragma unroll
       for (int m = 0; m < 6; m++) L.q[m] = Lz[m];
 #pragma unroll
-      for (int m = 0; m < 6; m++) weno_cell<FAST>(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lnext[m], R.q[m]);
+      for (int m = 0; m < 6; m++) weno_cell_r01<FAST>(W[0][m], W[1][m], W[2][m], W[3][m], W[4][m], Lnext[m], R.q[m]);
       solid_override(L, R, W[1], W[2], ws, 2);
       prim_floor(L);
       prim_floor(R);
@@ -837,7 +915,7 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
   }
 }
 
-__global__ __launch_bounds__(NT, 2) void k_step(const Args A) {
+__global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
   __shared__ StepLds S;
   // one scalar decision for the whole launch (see WLAM above); NaN in fmax_in takes the reciprocal form
   if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) step_body<true>(A, S);
@@ -1118,6 +1196,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 
   const float dt = A.clk->dt;
   const float gain = A.clk->gain;
+  const Gas G = gas_vgpr(A);
 
   unsigned ws = 0;
   auto load_own = [&](int zl, float (&dst)[6]) -> unsigned {
@@ -1153,7 +1232,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     solid_override(L, R, lo, hi, ws, 2);
     prim_floor(L);
     prim_floor(R);
-    Cons F = hllc(A, L, R, 2);
+    Cons F = hllc(G, L, R, 2);
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = F.c[m];
   }
@@ -1195,7 +1274,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       solid_override(L, R, own, hi, ws, 2);
       prim_floor(L);
       prim_floor(R);
-      Cons F = hllc(A, L, R, 2);
+      Cons F = hllc(G, L, R, 2);
 #pragma unroll
       for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
     }
