@@ -94,6 +94,7 @@ struct Args {
   const float *q[6];
   float *qo[6];
   float *dxy[6];
+  float *send[2];            // Z-slab ring: packed send buffers the step writes its new boundary planes into (or null)
   int nx, ny, nz;            // global
   int nzl, z0;               // local planes, global index of local plane 0
   int zl_lo, zl_hi;          // local plane range to update
@@ -1284,9 +1285,21 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     for (int m = 0; m < 6; m++) D[m] = (in_xy && !own_solid) ? A.dxy[m][di] : 0.f;
 
     if (in_xy) {
+      // Z-slab ring: the first / last three local planes of the NEW state go straight into the packed send buffers
+      // (what k_halo_pack would copy afterwards): wave-uniform branch, one dispatch less per step
+      const size_t n3 = (size_t)HALO * plane_n;
+      float *snd = nullptr;
+      if (A.send[0]) {
+        if (z < HALO) snd = A.send[0] + (size_t)z * plane_n + col;
+        else if (z >= A.nzl - HALO) snd = A.send[1] + (size_t)(z - (A.nzl - HALO)) * plane_n + col;
+      }
       if (own_solid) { // :1063-1072 copy-through
 #pragma unroll
-        for (int m = 0; m < 6; m++) { A.out[m][gi] = A.in[m][gi]; A.qo[m][gi] = own[m]; }
+        for (int m = 0; m < 6; m++) {
+          const float e = A.in[m][gi];
+          A.out[m][gi] = e; A.qo[m][gi] = own[m];
+          if (snd) snd[m * n3] = e;
+        }
       } else {
         const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
         float U0[6];
@@ -1353,7 +1366,10 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
         E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
 #pragma unroll
-        for (int m = 0; m < 6; m++) { A.out[m][gi] = E[m]; A.qo[m][gi] = decode_field(A.u_ref, m, E[m]); }
+        for (int m = 0; m < 6; m++) {
+          A.out[m][gi] = E[m]; A.qo[m][gi] = decode_field(A.u_ref, m, E[m]);
+          if (snd) snd[m * n3] = E[m];
+        }
       }
     }
 #pragma unroll
@@ -1452,9 +1468,13 @@ __global__ void k_halo_periodic(HaloArgs H) {
 }
 
 // packed halo exchange: boundary planes of 6 fields <-> one contiguous buffer per side
-struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; float *q[6]; float u_ref; };   // q: primitive cache to refresh on unpack (or null)
+struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; float *q[6]; float u_ref; DevClock *clk; int do_end; };   // q: primitive cache to refresh on unpack (or null); clk: also run the controller / clock (tau3d_slab_begin_async)
 // dir 0: pack (send side s <- first / last 3 interior planes); dir 1: unpack (recv side s -> halo planes)
 __global__ void k_halo_pack(PackArgs P, int dir) {
+  if (P.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // as k_halo_periodic does for the single domain
+    if (P.do_end) clock_end(P.clk);
+    clock_begin(P.clk);
+  }
   const size_t n3 = (size_t)HALO * P.plane_n;
   const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
   float *fld = P.f[f];
@@ -1940,6 +1960,48 @@ static int fill_halo(tau3d_t *h, bool with_clock) {
 }
 extern "C" int tau3d_fill_halo_periodic_async(tau3d_t *h) { return fill_halo(h, false); }
 
+// ---- the two launches of the split step over planes [lo, hi) (+ [lo2, hi2) in the same launch)
+static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi2) {
+  A = h->base;
+  for (int f = 0; f < 6; f++) {
+    A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f];
+    A.q[f] = h->qbuf[h->cur][f]; A.qo[f] = h->qbuf[h->cur ^ 1][f]; A.dxy[f] = h->dxy[f];
+  }
+  A.zl_lo = lo; A.zl_hi = hi; A.zl_lo2 = lo2; A.zl_hi2 = hi2;
+  A.send[0] = A.send[1] = nullptr;
+}
+static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s) {   // x/y faces: one plane per workgroup
+  h3d::Args X;
+  split_args(h, X, lo, hi, lo2, hi2);
+  const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
+  X.zchunk = 1; X.nzc1 = n1; X.nzc = n1 + n2;
+  X.ntx = (X.nx + h3d::XT - 1) / h3d::XT; X.nty = (X.ny + h3d::YT - 1) / h3d::YT;
+  hipLaunchKernelGGL(h3d::k_flux_xy, dim3((unsigned)(X.ntx * X.nty * X.nzc)), dim3(h3d::XNT), 0, s, X);
+  TAU_LAUNCH_CHECK("k_flux_xy");
+  return 0;
+}
+// z faces + update: a wave marches a chunk of planes; ~4k workgroups (four rounds of the ~1k resident ones).
+// `pack`: the new boundary planes also go into the packed send buffers (Z-slab ring)
+static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipStream_t s) {
+  h3d::Args Z;
+  split_args(h, Z, lo, hi, lo2, hi2);
+  const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
+  const long tz = (long)((Z.nx + h3d::ZT_X - 1) / h3d::ZT_X) * ((Z.ny + h3d::ZT_Y - 1) / h3d::ZT_Y);
+  int zc = h->zchunk;
+  if (zc <= 0) { zc = (int)((long)(n1 + n2) * tz / 4096); zc = zc < 4 ? 4 : (zc > 64 ? 64 : zc); }
+  Z.zchunk = zc < n1 ? zc : n1;
+  Z.nzc1 = (n1 + Z.zchunk - 1) / Z.zchunk;
+  Z.nzc = Z.nzc1 + (n2 ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
+  if (pack) { Z.send[0] = h->xbuf[0][0]; Z.send[1] = h->xbuf[0][1]; }
+  static const int zw = [] { const char *e = getenv("TAU3D_Z_WAVES"); return e ? atoi(e) : 4; }();
+  const dim3 g((unsigned)(tz * Z.nzc)), bl(h3d::ZNT);
+  if (zw <= 3) hipLaunchKernelGGL(h3d::k_update_z<3>, g, bl, 0, s, Z);
+  else if (zw == 4) hipLaunchKernelGGL(h3d::k_update_z<4>, g, bl, 0, s, Z);
+  else hipLaunchKernelGGL(h3d::k_update_z<5>, g, bl, 0, s, Z);
+  TAU_LAUNCH_CHECK("k_update_z");
+  return 0;
+}
+
 // steps planes [zl_lo, zl_hi) and, if zl_lo2 < zl_hi2, also [zl_lo2, zl_hi2) in the SAME launch
 static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2, void *stream) {
   if (zl_lo < 0 || zl_hi > h->nzl || zl_lo >= zl_hi) return tau::fail("tau3d_step_range: bad plane range [%d,%d)", zl_lo, zl_hi);
@@ -1950,38 +2012,15 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
   int nplanes = zl_hi - zl_lo;           // chunking is chosen for the first range; a second range has the same length
   if (h->split) {
-    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    for (int f = 0; f < 6; f++) { A.q[f] = h->qbuf[h->cur][f]; A.qo[f] = h->qbuf[h->cur ^ 1][f]; A.dxy[f] = h->dxy[f]; }
-    A.zl_lo2 = zl_lo2; A.zl_hi2 = zl_hi2;
-    const int n2 = two ? zl_hi2 - zl_lo2 : 0;
     const bool tm = h->timing && h->n_ev < 4096;
+    hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s));
-    { // x/y faces: one plane per workgroup
-      h3d::Args X = A;
-      X.zchunk = 1; X.nzc1 = nplanes; X.nzc = nplanes + n2;
-      X.ntx = (A.nx + h3d::XT - 1) / h3d::XT; X.nty = (A.ny + h3d::YT - 1) / h3d::YT;
-      hipLaunchKernelGGL(h3d::k_flux_xy, dim3((unsigned)(X.ntx * X.nty * X.nzc)), dim3(h3d::XNT), 0, s, X);
-      TAU_LAUNCH_CHECK("k_flux_xy");
-    }
-    { // z faces + update: a wave marches a chunk of planes; ~4k workgroups (four rounds of the 1024 resident ones)
-      h3d::Args Z = A;
-      const long tz = (long)((A.nx + h3d::ZT_X - 1) / h3d::ZT_X) * ((A.ny + h3d::ZT_Y - 1) / h3d::ZT_Y);
-      int zc = h->zchunk;
-      if (zc <= 0) { zc = (int)((long)(nplanes + n2) * tz / 4096); zc = zc < 4 ? 4 : (zc > 64 ? 64 : zc); }
-      Z.zchunk = zc < nplanes ? zc : nplanes;
-      Z.nzc1 = (nplanes + Z.zchunk - 1) / Z.zchunk;
-      Z.nzc = Z.nzc1 + (two ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
-      static const int zw = [] { const char *e = getenv("TAU3D_Z_WAVES"); return e ? atoi(e) : 4; }();
-      const dim3 g((unsigned)(tz * Z.nzc)), bl(h3d::ZNT);
-      if (zw <= 3) hipLaunchKernelGGL(h3d::k_update_z<3>, g, bl, 0, s, Z);
-      else if (zw == 4) hipLaunchKernelGGL(h3d::k_update_z<4>, g, bl, 0, s, Z);
-      else hipLaunchKernelGGL(h3d::k_update_z<5>, g, bl, 0, s, Z);
-      TAU_LAUNCH_CHECK("k_update_z");
-    }
+    if (split_xy(h, zl_lo, zl_hi, zl_lo2, zl_hi2, s)) return 1;
+    if (split_z(h, zl_lo, zl_hi, zl_lo2, zl_hi2, false, s)) return 1;
     if (tm) {
       TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
       h->n_ev++;
-      h->ev_cells += (double)(nplanes + n2) * (double)h->plane_n;
+      h->ev_cells += (double)(nplanes + (two ? zl_hi2 - zl_lo2 : 0)) * (double)h->plane_n;
     }
     return 0;
   }
@@ -2027,6 +2066,35 @@ extern "C" int tau3d_step_edges_async(tau3d_t *h, int depth, void *stream) {
   if (depth < h3d::HALO) return tau::fail("tau3d_step_edges: depth %d is less than the %d halo planes", depth, h3d::HALO);
   if (2 * depth >= h->nzl) return step_ranges(h, 0, h->nzl, 0, 0, stream);
   return step_ranges(h, 0, depth, h->nzl - depth, h->nzl, stream);
+}
+
+// ---- Z-slab ring step in (at most) four dispatches: see include/taueng.h
+static int halo_pack(tau3d_t *h, int which, int dir, bool with_clock);
+extern "C" int tau3d_slab_begin_async(tau3d_t *h) {
+  TAU_HIP(hipSetDevice(h->device));
+  return halo_pack(h, 0, 1, true);   // controller of the step before (if pending) + clock of this one + received halos
+}
+extern "C" int tau3d_slab_edges_async(tau3d_t *h, int depth) {
+  if (depth < h3d::HALO) return tau::fail("tau3d_slab_edges: depth %d is less than the %d halo planes", depth, h3d::HALO);
+  const int nzl = h->nzl;
+  const bool whole = 2 * depth >= nzl;
+  if (h->split) {
+    if (split_xy(h, 0, nzl, 0, 0, h->stream)) return 1;            // no z dependence: every local plane, before any halo is needed
+    return whole ? split_z(h, 0, nzl, 0, 0, true, h->stream) : split_z(h, 0, depth, nzl - depth, nzl, true, h->stream);
+  }
+  if (whole ? step_ranges(h, 0, nzl, 0, 0, nullptr) : step_ranges(h, 0, depth, nzl - depth, nzl, nullptr)) return 1;
+  return halo_pack(h, 1, 0, false);
+}
+extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
+  const int nzl = h->nzl;
+  if (2 * depth >= nzl) return 0;
+  if (h->split) return split_z(h, depth, nzl - depth, 0, 0, false, h->stream);
+  return step_ranges(h, depth, nzl - depth, 0, 0, nullptr);
+}
+extern "C" int tau3d_slab_end_async(tau3d_t *h) {
+  h->cur ^= 1;             // std::swap x6, :1706-1711
+  h->end_pending = true;   // the controller update (after the caller's all-reduce) rides on the next tau3d_slab_begin_async
+  return 0;
 }
 
 extern "C" int tau3d_clock_begin_async(tau3d_t *h) {
@@ -2088,8 +2156,10 @@ extern "C" int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, f
   *p = side == 0 ? b : b + (size_t)(h->nzl + h3d::HALO) * h->plane_n;
   return 0;
 }
-static int halo_pack(tau3d_t *h, int which, int dir) {
+static int halo_pack(tau3d_t *h, int which, int dir, bool with_clock) {
   h3d::PackArgs P;
+  P.clk = with_clock ? h->clk : nullptr; P.do_end = h->end_pending ? 1 : 0;
+  if (with_clock) h->end_pending = false;
   for (int f = 0; f < 6; f++) P.f[f] = h->buf[h->cur ^ (which & 1)][f];
   P.buf[0] = h->xbuf[dir][0]; P.buf[1] = h->xbuf[dir][1];
   P.plane_n = h->plane_n; P.nzl = h->nzl; P.u_ref = h->p.u_ref;
@@ -2098,8 +2168,8 @@ static int halo_pack(tau3d_t *h, int which, int dir) {
   TAU_LAUNCH_CHECK("k_halo_pack");
   return 0;
 }
-extern "C" int tau3d_pack_halos_async(tau3d_t *h, int which) { return halo_pack(h, which, 0); }
-extern "C" int tau3d_unpack_halos_async(tau3d_t *h, int which) { return halo_pack(h, which, 1); }
+extern "C" int tau3d_pack_halos_async(tau3d_t *h, int which) { return halo_pack(h, which, 0, false); }
+extern "C" int tau3d_unpack_halos_async(tau3d_t *h, int which) { return halo_pack(h, which, 1, false); }
 extern "C" int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, size_t *nfloats) {
   if ((kind | 1) != 1 || (side | 1) != 1 || !p) return tau::fail("tau3d_halo_buf_ptr: bad argument");
   *p = h->xbuf[kind][side];

@@ -5,15 +5,18 @@ The reference is single-GPU (no NCCL/MPI anywhere); this layer is ne
 (SURVEY §8e).  nz is split into `world` contiguous slabs; z is periodic
 (tau_hypersonic_3d_cuda.cu:1029-1030) so the neighbours form a ring.  Per step and rank:
 
-    clock_begin                          t *= exp(d_tau), dt, gain              (device)
-    wait + unpack halos(n)               received while step n-1 computed its interior
-    step edge planes [0,3) , [nzl-3,nzl) need the halos; produce next state's boundary planes
-    pack those planes, isend/irecv       2 sends + 2 recvs of one packed buffer each (comm stream, async)
-    step interior planes [3, nzl-3)      overlaps the exchange
+    begin      ONE kernel: d_tau controller of step n-1 (it needs the all-reduced max word), clock of step n
+               (t *= exp(d_tau), dt, gain), and the halos received while step n-1 computed its interior unpacked
+    edges      [large planes: the x/y flux kernel over ALL local planes — no z dependence, no halo needed —, then]
+               edge planes [0,E) , [nzl-E,nzl) in one launch that also writes the new boundary planes into the packed
+               send buffers
+    isend/irecv  2 sends + 2 recvs of one packed buffer each (async)
+    interior   planes [E, nzl-E): overlaps the exchange
     all_reduce(MAX) of the max-wavespeed and max-|primitive| words (8 bytes)
-    clock_end                            d_tau controller (device) + swap
+    end        swap (host bookkeeping; the controller rides on the next begin)
 
-Only 3 planes x 6 fields cross each link per step (18.9 MB at 512^2 planes); each direction of a
+Four dispatches (three below 128^2 planes, where the step is one fused kernel — plus a pack kernel there) and two
+collectives per step.  Only 3 planes x 6 fields cross each link per step (18.9 MB at 512^2 planes); each direction of a
 neighbour pair has its own xGMI link, so the exchange costs ~0.12 ms against multi-ms slab
 compute and hides behind the interior launch.  No other collective is on the data path.
 
@@ -79,17 +82,18 @@ class EngineSlabBackend:
     def max_tensor(self):
         return self._max
 
-    def clock_begin(self):
-        self.h.clock_begin_async()
+    # ---- one step = begin, edges, <exchange posted>, interior, <all-reduce>, end  (include/taueng.h)
+    def begin(self):
+        self.h.slab_begin_async()
 
-    def step_range(self, lo, hi):
-        self.h.step_range_async(lo, hi)
+    def edges(self, depth):
+        self.h.slab_edges_async(depth)
 
-    def step_edges(self, depth):
-        self.h.step_edges_async(depth)
+    def interior(self, depth):
+        self.h.slab_interior_async(depth)
 
-    def clock_end(self):
-        self.h.clock_end_async()
+    def end(self):
+        self.h.slab_end_async()
 
     def sync(self):
         self.h.sync()
@@ -100,14 +104,20 @@ class EngineSlabBackend:
 
 class SlabRing:
     """Steps a Z-slab with ring halo exchange.  `backend` provides buf(kind, side) (flat tensors: the packed
-    3 planes x 6 fields a side sends / receives), pack(which), unpack(which), max_tensor(), clock_begin(),
-    step_range(lo, hi), clock_end(), sync(); `which` = 0 current state, 1 next state."""
+    3 planes x 6 fields a side sends / receives), pack(which), unpack(which) (`which` = 0: current state),
+    max_tensor(), sync(), clock() and the four pieces of a step:
+        begin()      controller of the previous step (it needs the all-reduced max), clock of this one, received halos
+                     unpacked into the current state
+        edges(E)     planes [0,E) and [nzl-E,nzl) of the new state, boundary planes packed into the send buffers
+        interior(E)  planes [E, nzl-E)
+        end()        swap"""
 
     def __init__(self, backend, rank, world, group=None):
         self.b, self.rank, self.world, self.group = backend, rank, world, group
         self.lo = (rank - 1) % world
         self.hi = (rank + 1) % world
         self._pending = None
+        self._primed = False
         self.edge = max(3, min(8, backend.nzl // 2))   # planes per edge launch (>= the 3 halo planes, <= half a slab)
 
     def _post_exchange(self):
@@ -125,47 +135,48 @@ class SlabRing:
                dist.P2POp(dist.irecv, b.buf("recv", 0), self.lo, self.group, tag=1)]
         return dist.batch_isend_irecv(ops)
 
-    def _land(self, which):
-        """wait for the exchange in flight and unpack it into the halos of state `which`"""
-        if self._pending is None:
-            return
-        for r in self._pending:
-            r.wait()
-        self._pending = None
-        self.b.unpack(which)
+    def _wait(self):
+        if self._pending is not None:
+            for r in self._pending:
+                r.wait()
+            self._pending = None
 
     def prime(self):
-        """exchange the halos of the current state (after init / upload)"""
-        self.b.pack(0)
+        """exchange the halos of the current state and agree on its field range (after init / upload).  step() does it
+        itself when the caller has not: without it the first step would read undefined halo planes and every slab could
+        pick its own WENO weight form."""
+        b = self.b
+        b.pack(0)
         self._pending = self._post_exchange()
-        self._land(0)
+        self._wait()
+        b.unpack(0)
         if self.world > 1:                             # the field range init / upload measured, over all slabs
-            dist.all_reduce(self.b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
+        self._primed = True                            # (the first begin() unpacks the same buffers once more: idempotent)
+
+    def invalidate(self):
+        """the backend's state was re-initialised or uploaded: exchange again before the next step"""
+        self._primed = False
 
     def step(self, n=1):
-        b, nzl = self.b, self.b.nzl
+        b = self.b
+        if not self._primed:
+            self.prime()
+        E = self.edge
         for _ in range(n):
-            b.clock_begin()
-            self._land(0)                              # halos of the current state
-            # Edge launches are E planes deep, not just the 3 that are sent: the z-marching kernel re-decodes 5
-            # warm-up planes per chunk, so a 3-plane launch is 8 plane iterations for 3 useful ones.  With E = 8
-            # a 64-plane slab costs 13 + 13 + 58 iterations instead of 8 + 8 + 98 — the same ~76 % duty as the
-            # single-GPU launch — and the interior that hides the exchange is still ~0.6 ms at 512^2 x 48.
-            E = self.edge
-            if hasattr(b, "step_edges"):
-                b.step_edges(E)                        # both edges in one launch (engine backend)
-            else:
-                b.step_range(0, E)
-                b.step_range(nzl - E, nzl)
-            b.pack(1)                                  # next state's boundary planes
-            self._pending = self._post_exchange()      # async; lands at the start of the next step
-            if nzl > 2 * E:
-                b.step_range(E, nzl - E)               # overlaps the exchange
+            self._wait()                               # the halos posted during the previous step have landed
+            b.begin()
+            # Edge launches are E planes deep, not just the 3 that are sent: a marching launch pays a warm-up per chunk,
+            # so E = 8 keeps the edge launch at the duty of the interior one; the interior that hides the exchange is
+            # still ~0.5 ms at 512^2 x 48.
+            b.edges(E)
+            self._pending = self._post_exchange()      # async; lands before the next begin()
+            b.interior(E)                              # overlaps the exchange
             if self.world > 1:
                 dist.all_reduce(b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
-            b.clock_end()
+            b.end()
         return self
 
     def finish(self):
-        self._land(0)
+        self._wait()
         self.b.sync()

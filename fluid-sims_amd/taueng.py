@@ -134,6 +134,8 @@ def load():
         "tau3d_step_range_async": ([vp, i32, i32, vp], i32),
         "tau3d_step_edges_async": ([vp, i32, vp], i32),
         "tau3d_clock_end_async": ([vp], i32),
+        "tau3d_slab_begin_async": ([vp], i32), "tau3d_slab_edges_async": ([vp, i32], i32),
+        "tau3d_slab_interior_async": ([vp, i32], i32), "tau3d_slab_end_async": ([vp], i32),
         "tau3d_fill_halo_periodic_async": ([vp], i32),
         "tau3d_halo_send_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
         "tau3d_halo_recv_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
@@ -351,6 +353,18 @@ class Tau3D:
 
     def clock_end_async(self):
         _ck(self._L.tau3d_clock_end_async(self._h))
+
+    def slab_begin_async(self):
+        _ck(self._L.tau3d_slab_begin_async(self._h))
+
+    def slab_edges_async(self, depth):
+        _ck(self._L.tau3d_slab_edges_async(self._h, depth))
+
+    def slab_interior_async(self, depth):
+        _ck(self._L.tau3d_slab_interior_async(self._h, depth))
+
+    def slab_end_async(self):
+        _ck(self._L.tau3d_slab_end_async(self._h))
 
     def fill_halo_periodic_async(self):
         _ck(self._L.tau3d_fill_halo_periodic_async(self._h))

@@ -7,6 +7,10 @@ from importlib import import_module
 slab = import_module("fluid_sims_amd.slab")
 n = 512
 L = f.load(); params = f.Tau3DParams(); L.tau3d_params_default(ctypes.byref(params), n, n, n)
+e = f.Tau3D(n); e.init(1); e.set_clock(0.02, 1e-4); e.step_async(5); e.sync()
+t0 = time.perf_counter(); e.step_async(10); e.sync(); IDEAL = (time.perf_counter() - t0) / 10 * 1e3   # single-domain ms per step, same box
+e.close(); del e
+print("single domain: %.3f ms/step" % IDEAL)
 for world in (8, 4, 2):
     nzl = n // world
     be = slab.EngineSlabBackend(f.taueng, params, 0, nzl, 0)
@@ -14,11 +18,11 @@ for world in (8, 4, 2):
     E = max(3, min(8, nzl // 2))
     def step(k):
         for _ in range(k):
-            be.clock_begin(); be.unpack(0)
-            be.step_edges(E); be.pack(1)
-            be.step_range(E, nzl - E)
-            be.clock_end()
+            be.begin()            # controller + clock + unpack: one kernel
+            be.edges(E)           # (x/y flux kernel over all planes +) edge planes, boundary planes packed by the same launch
+            be.interior(E)
+            be.end()
     step(5); be.sync()
     t0 = time.perf_counter(); step(20); be.sync(); el = (time.perf_counter() - t0) / 20
-    print("world %d: slab %d planes, %.3f ms/step per rank (no comm)  -> %.1f Gcell/s aggregate if comm hides, ideal %.3f ms" % (world, nzl, el * 1e3, n**3 / el / 1e9, 8.40 / world))
+    print("world %d: slab %d planes, %.3f ms/step per rank (no comm)  -> %.1f Gcell/s aggregate if comm hides, ideal %.3f ms (%.0f %%)" % (world, nzl, el * 1e3, n**3 / el / 1e9, IDEAL / world, 100 * IDEAL / world / (el * 1e3)))
     del be

@@ -1,5 +1,5 @@
 """CPU slab backend for the gloo tests: the oracle stands in for the HIP engine behind the same
-five calls (halo_tensor / max_tensor / clock_begin / step_range / clock_end).  Lives in tests/ —
+calls (buf / pack / unpack / max_tensor / begin / edges / interior / end).  Lives in tests/ —
 the product package never imports the oracle."""
 import numpy as np
 import torch
@@ -14,6 +14,7 @@ class OracleSlabBackend:
         self.cur = self.o.new_state()
         self.nxt = self.o.new_state()
         self._max = torch.zeros(1, dtype=torch.float32)
+        self._end_pending = False
         self.plane = params.nx * params.ny
         self._xn = {(k, sd): np.zeros((6, 3 * self.plane), np.float32) for k in ("send", "recv") for sd in (0, 1)}
         self._x = {key: torch.from_numpy(a.reshape(-1)) for key, a in self._xn.items()}
@@ -39,21 +40,42 @@ class OracleSlabBackend:
     def max_tensor(self):
         return self._max
 
-    def clock_begin(self):
+    def _flush(self):
+        if self._end_pending:                       # d_tau controller of the previous step, with the all-reduced max
+            self.o.clock_end(float(self._max[0]))
+            self._end_pending = False
+
+    def begin(self):
+        self._flush()
         self.o.clock_begin()
         self._max.zero_()
+        self.unpack(0)
 
     def step_range(self, lo, hi):
         c = self.o.clock
         m = self.o.step_range(self.cur, self.nxt, c.dt, c.gain, lo, hi)
         self._max[0] = max(float(self._max[0]), m)
 
-    def clock_end(self):
-        self.o.clock_end(float(self._max[0]))
+    def edges(self, depth):
+        n = self.nzl
+        if 2 * depth >= n:
+            self.step_range(0, n)
+        else:
+            self.step_range(0, depth)
+            self.step_range(n - depth, n)
+        self.pack(1)
+
+    def interior(self, depth):
+        if 2 * depth < self.nzl:
+            self.step_range(depth, self.nzl - depth)
+
+    def end(self):
         self.cur, self.nxt = self.nxt, self.cur
+        self._end_pending = True
 
     def sync(self):
         pass
 
     def clock(self):
+        self._flush()
         return self.o.clock

@@ -62,8 +62,9 @@ def test_rccl_on_aliased_tensors(eng):
         be = slab.EngineSlabBackend(eng.taueng, _params(eng, n), 0, 32, 0)
         be.h.init(1)
         be.h.set_clock(0.02, 1e-4)
-        be.clock_begin()
-        be.step_range(0, 32)
+        be.begin()
+        be.edges(8)
+        be.interior(8)
         m = be.max_tensor()                      # [max wavespeed, max |primitive|] of the step in flight
         assert m.shape == (2,)
         before, fbefore = (float(v) for v in m.tolist())
@@ -71,7 +72,7 @@ def test_rccl_on_aliased_tensors(eng):
         dist.broadcast(be.buf("send", 0), src=0)
         torch.cuda.synchronize()
         assert before > 0 and fbefore >= 99.9 and m.tolist() == [before, fbefore]   # inflow u = 100
-        be.clock_end()
+        be.end()
         be.sync()
         assert be.clock().maxs == before
     finally:

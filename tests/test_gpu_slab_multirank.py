@@ -1,7 +1,7 @@
 """GPU, multi-process: the Z-slab ring with the REAL HIP engine on every rank.  The GPU box has one device, so the
 ranks share it and the transport is gloo with the packed halo buffers staged through host memory — everything else
-is the production path (EngineSlabBackend: device-side pack / unpack, tau3d_step_edges_async, interior range, the max
-word, the device clock).  Result: bit-identical to the single-domain engine run."""
+is the production path (EngineSlabBackend: tau3d_slab_begin / edges / interior / end, the max word, the device
+clock).  Result: bit-identical to the single-domain engine run."""
 import os
 import socket
 import sys
@@ -41,31 +41,52 @@ def _worker(rank, world, port, shape, steps, outdir):
             super().__init__(*a)
             self._host = {k: torch.empty(v.shape, dtype=v.dtype) for k, v in self._buf.items()}
             self._hmax = torch.zeros(self._max.shape, dtype=torch.float32)
+            self._hmax_valid = False
 
         def buf(self, kind, side):
             return self._host[(kind, side)]
 
-        def pack(self, which):
-            super().pack(which)
+        def _send_to_host(self):
             self.h.sync()
             for side in (0, 1):
                 self._host[("send", side)].copy_(self._buf[("send", side)])
 
-        def unpack(self, which):
+        def _recv_to_device(self):
             for side in (0, 1):
                 self._buf[("recv", side)].copy_(self._host[("recv", side)])
+            if self._hmax_valid:                     # the all-reduced max words go back before the controller reads them
+                self._max.copy_(self._hmax)
+                self._hmax_valid = False
             torch.cuda.current_stream().synchronize()
+
+        def pack(self, which):
+            super().pack(which)
+            self._send_to_host()
+
+        def unpack(self, which):
+            self._recv_to_device()
             super().unpack(which)
 
-        def max_tensor(self):                     # SlabRing all-reduces this in place just before clock_end
+        def begin(self):
+            self._recv_to_device()
+            super().begin()
+
+        def edges(self, depth):
+            super().edges(depth)                      # writes the send buffers itself
+            self._send_to_host()
+
+        def max_tensor(self):                     # SlabRing all-reduces this in place
             self.h.sync()
             self._hmax.copy_(self._max)
+            self._hmax_valid = True
             return self._hmax
 
-        def clock_end(self):
-            self._max.copy_(self._hmax)
-            torch.cuda.current_stream().synchronize()
-            super().clock_end()
+        def clock(self):
+            if self._hmax_valid:
+                self._max.copy_(self._hmax)
+                self._hmax_valid = False
+                torch.cuda.current_stream().synchronize()
+            return super().clock()
 
     nx, ny, nz = shape
     L = f.load()
@@ -87,7 +108,9 @@ def _worker(rank, world, port, shape, steps, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,steps", [(2, (64, 48, 40), 6), (4, (48, 32, 64), 5), (3, (40, 40, 50), 4)])
+@pytest.mark.parametrize("world,shape,steps", [(2, (64, 48, 40), 6), (4, (48, 32, 64), 5), (3, (40, 40, 50), 4),
+                                               (8, (32, 32, 64), 4),        # BASELINE's world size: 8 planes per rank, E = 4
+                                               (2, (160, 128, 24), 3)])     # planes >= 128^2: the split step (k_flux_xy + k_update_z)
 def test_engine_ring_equals_single_domain(eng, tmp_path, world, shape, steps):
     mp.spawn(_worker, args=(world, _free_port(), shape, steps, str(tmp_path)), nprocs=world, join=True)
     nx, ny, nz = shape

@@ -50,7 +50,8 @@ def _worker(rank, world, port, shape, steps, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape", [(2, (16, 16, 24)), (3, (24, 16, 20)), (4, (16, 8, 24))])
+@pytest.mark.parametrize("world,shape", [(2, (16, 16, 24)), (3, (24, 16, 20)), (4, (16, 8, 24)),
+                                         (8, (8, 8, 64))])   # BASELINE's world size: 8 planes per rank, E = 4
 def test_slab_ring_equals_single_domain(oracle_built, tmp_path, world, shape):
     steps = 3
     mp.spawn(_worker, args=(world, _free_port(), shape, steps, str(tmp_path)), nprocs=world, join=True)
