@@ -13,9 +13,11 @@ controller has settled, then exactly K timed steps bracketed by barrier + device
 N > 1: the SAME 512^3 grid is Z-slab partitioned over the ranks (strong scaling, as BASELINE.json's
 metric states: "512^3 at 1/2/4/8 MI355X"); per step each rank exchanges 3 boundary planes x 6 fields
 with both ring neighbours (RCCL send/recv over xGMI, overlapped with the interior planes) and one
-4-byte all-reduce(max) feeds the device-side d_tau controller.
+8-byte all-reduce(max) (max wavespeed + max |primitive|) feeds the device-side d_tau controller.
 
-Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`.
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`; at N = 1 the
+line also carries `configs`: the other four BASELINE.json configurations (2D Euler 4096^2, Gray-Scott 8192^2,
+SPH 4 194 304 particles, the CPU program at 256^2), each with its own event-timed roofline.
 """
 import argparse
 import ctypes
@@ -123,6 +125,97 @@ def input_variants(f, n, steps=6):
     return out
 
 
+def _event_timed(torch, stream, enqueue, sync):
+    """ms of `enqueue()` on `stream`, from events recorded ON that stream (the handles launch on it)"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    sync()
+    e0.record(stream)
+    enqueue()
+    e1.record(stream)
+    e1.synchronize()
+    sync()
+    return e0.elapsed_time(e1)
+
+
+def _roof(kernel, ms_per_launch, units_per_launch, bytes_per_unit, bound, note=None):
+    gbs = units_per_launch * bytes_per_unit / (ms_per_launch * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+         "traffic": None, "kernel": kernel, "avg_launch_ms": round(ms_per_launch, 5),
+         "algorithmic_bytes_per_launch": units_per_launch * bytes_per_unit, "binding_bound": bound}
+    if note:
+        r["note"] = note
+    return r
+
+
+def other_configs(f, torch, dev):
+    """BASELINE.json configs C1-C4 with SURVEY §8d's inputs and step counts, each event-timed on its handle's stream."""
+    import ctypes as C
+    out = []
+    stream = torch.cuda.Stream(dev)
+    sp = C.c_void_p(stream.cuda_stream)
+
+    # ---- C2: tau_hypersonic_cuda 2D 4096^2 fp32, k_init geometry scaled to the grid, 50 warm-up + 200 timed steps
+    n = 4096
+    e = f.Hypersonic2D(n, n, stream=sp)
+    e.init()
+    e.step_async(50)
+    ms = _event_timed(torch, stream, lambda: e.step_async(200), e.sync)
+    out.append({"config": f"tau_hypersonic_cuda 2D {n}x{n} fp32 (one fused kernel per step)", "steps": 200, "warmup": 50,
+                "value": round(n * n * 200 / ms / 1e6, 3), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 200, 5),
+                "roofline": _roof("h2d::k_march", ms / 200, n * n, 33, "valu")})
+    e.close()
+
+    # ---- C3: tau_gray_scott 8192^2, init_pattern(seed 1337), 1000 steps: four time levels per pass (the default), and the
+    #      single-step kernel (one launch per step)
+    n = 8192
+    g = f.GrayScott(n, n, stream=sp)
+    g.init_pattern(1337)
+    g.step_async(40)
+    ms = _event_timed(torch, stream, lambda: g.step_async(1000), g.sync)
+    out.append({"config": f"tau_gray_scott {n}x{n}, 4 time levels per pass (default)", "steps": 1000, "warmup": 40,
+                "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
+                "roofline": _roof("st2::k_fused<GS,4> (one launch = 4 steps)", ms / 250, 4 * n * n, 16, "valu + hbm",
+                                  "16 B per update is the single-step algorithmic figure; a 4-level pass moves ~4.6 B per "
+                                  "update (profiles/r01i), so frac > 1 is traffic removed, not bandwidth exceeded")})
+
+    def single():
+        for _ in range(1000):
+            g.step_async(1)
+    ms = _event_timed(torch, stream, single, g.sync)
+    out.append({"config": f"tau_gray_scott {n}x{n}, one step per launch", "steps": 1000, "warmup": 0,
+                "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
+                "roofline": _roof("st2::k_march<GS>", ms / 1000, n * n, 16, "hbm")})
+    g.close()
+
+    # ---- C4: tau_sph 4 194 304 particles, reset_particles(seed 69420), rain off, 200 sub-steps: on the lattice start
+    #      and on the developed (collapsing dam) state 1500 sub-steps later
+    N = 1 << 22
+    s = f.Sph2D(N, stream=sp)
+    s.reset_particles()
+    s.step_async(20)
+    for label, pre in (("lattice start (after 20 sub-steps)", 0), ("developed state (after 1500 more sub-steps)", 1500)):
+        if pre:
+            s.step_async(pre)
+        ms = _event_timed(torch, stream, lambda: s.step_async(200), s.sync)
+        out.append({"config": f"tau_sph {N} particles, {label}", "steps": 200,
+                    "value": round(N * 200 / ms / 1e6, 3), "unit": "Gparticle-sub-steps/s", "ms_per_step": round(ms / 200, 5),
+                    "roofline": _roof("sph sub-step (cell build + k_density + k_forces)", ms / 200, N, 100,
+                                      "valu (pair evaluation)")})
+    s.close()
+
+    # ---- C1: tau_hypersonic.c restated (fp64 scalar CPU program), 256^2, 100 steps after init_sim, 1 thread
+    from importlib import import_module
+    m = import_module("fluid_sims_amd.cpu2d")
+    c = m.CpuHypersonic2D(256, 256, simd=False)
+    t0 = time.perf_counter()
+    c.step(100)
+    el = time.perf_counter() - t0
+    out.append({"config": "tau_hypersonic.c restated, 2D 256x256 fp64 scalar, CPU, 1 thread", "steps": 100,
+                "value": round(256 * 256 * 100 / el / 1e9, 6), "unit": "Gcell-updates/s", "ms_per_step": round(el * 10, 4),
+                "roofline": None})
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +224,7 @@ def main():
     ap.add_argument("--n", type=int, default=512, help="grid edge (headline: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the two extra SURVEY 8d inputs (reference IC, no body)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configs (2D Euler, Gray-Scott, SPH, CPU)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab ring driver even on one GPU (self-neighbour halo copies): exercises the N>1 code path")
     args = ap.parse_args()
@@ -207,23 +301,30 @@ def main():
     value = cells_total / el / 1e9
 
     if rank == 0:
-        # dominant kernel: k_step.  achieved = algorithmic bytes of the launches / their summed duration
+        # The step is two kernels over the same planes (k_flux_xy, then k_update_z): the events bracket the pair, so
+        # achieved = algorithmic bytes of a step / the summed duration of both.  `traffic` is NOT measured in this run:
+        # it is the PMC figure of the committed profile (profiles/k_step_traffic.json names the passes it came from).
         k_s = k_ms * 1e-3
         achieved = ALGO_BYTES_PER_CELL * k_cells / k_s / 1e9 if k_s > 0 else 0.0
-        traffic = None
+        traffic, tsrc = None, None
         tpath = os.path.join(ROOT, "profiles", "k_step_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
             except Exception:
                 traffic = None
+        split = n * n >= 128 * 128 and os.environ.get("TAU3D_SPLIT", "1") != "0"
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "h3d::k_step", "launches": k_launches,
+                "traffic_source": f"profile-derived, not this run: {tsrc}" if traffic else None,
+                "kernel": "h3d::k_flux_xy + h3d::k_update_z (one step = the pair)" if split else "h3d::k_step",
+                "launches": k_launches,
                 "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(k_launches, 1),
-                "note": "kernel is FP32-VALU bound (WENO5+HLLC, ~2.4k VALU instr/cell executed, ~74 % of the measured v_fma_f32 issue peak); the HBM fraction is "
-                        "reported because BASELINE.json's metric asks for it"}
+                "note": "the step is FP32-VALU bound (WENO5 + HLLC, ~2.25 k VALU instructions per cell at ~3.4 cycles each against a "
+                        "~2.3-cycle full-rate issue, profiles/r02/valu_calib.txt); the HBM fraction is reported because "
+                        "BASELINE.json's metric asks for it"}
         out = {"metric": "Gcell-updates/s, 3D hypersonic 512^3 fp32", "value": round(value, 4),
                "unit": "Gcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
@@ -242,8 +343,19 @@ def main():
             planes = 8
             zc = n // 2 - 40 if n >= 128 else 0
             planes = min(planes, n)
+            h.fill_halo_periodic_async()                   # the sample may reach into the halo planes: make them current
+            h.sync()
             st = h.download_planes(zc - 3, zc + planes + 3)
-            out["cpu_baseline"] = cpu_baseline(n, [np.ascontiguousarray(a) for a in st], clk.dt, zc, planes)
+            cpu_sample = ([np.ascontiguousarray(a) for a in st], clk.dt, zc, planes)
+        if world == 1 and not args.no_configs and not args.force_slab:
+            h.close()                                      # the 512^3 state (20 GB with the primitive cache) is not needed below
+            h = None
+            try:
+                out["configs"] = other_configs(f, torch, dev)
+            except Exception as e:  # extras never take the headline down
+                out["configs"] = [{"error": str(e)}]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n, *cpu_sample)
             try:
                 out["cpu_baseline_2d_simd"] = cpu_baseline_2d()
                 out["cpu_baseline_2d_simd_256"] = cpu_baseline_2d(n=256)      # BASELINE config 1 size
