@@ -48,6 +48,7 @@ int main(int argc, char **argv) {
 
   double t0 = cli_now();
   tau3d_clock c;
+  TAU_CK(tau3d_get_clock(h, &c));   /* --frames 0 --dump prints it without ever entering the loop */
   for (int f = 0; f < frames; f++) {
     /* the clock lives on the device: only the frames that print it pay for the read-back (the reference copies
        maxs to the host every step, :1697) */

@@ -120,6 +120,22 @@ __device__ __forceinline__ C4 neigh(const Args &A, const Tile &T, P4 center, int
   return T.cons(xn, yn);
 }
 
+// ONE staging rule for both step kernels (the tile kernel's LDS staging and the march's row loads) and for the
+// known-answer check of tau_hypersonic_cuda_tests.cu:567-640 (k_unit_neighbors below):
+struct MCell { C4 c; bool m, in; };   // staged conserved state, body mask, "a cell of the domain" (for has-state tests)
+
+__device__ __forceinline__ MCell march_load(const Args &A, int gx, int row) {
+  MCell q;
+  const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(row, A.H - 1));
+  const size_t gi = (size_t)sy * A.W + sx;
+  const bool mk = A.mask[gi] != 0;
+  q.m = (gx < 0 || gx >= A.W) ? false : mk;
+  q.c = C4{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
+  if ((sx == 0 && !mk) || gx < 0) q.c = A.in_c;
+  q.in = gx >= 0 && gx < A.W && row >= 0 && row < A.H;
+  return q;
+}
+
 // The same function without branches, for the twelve calls per cell of the predictor and the diffusion stencil.
 // Staging has already resolved the two x cases — halo columns left of x = 0 hold the inflow state, columns right of
 // x = W-1 hold cell W-1, both with the mask cleared — and clamps y like the reference's tile load; the caller forms
@@ -292,16 +308,11 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
   //         the inflow column overwrite of k_apply_inflow_left happens here
   for (int t = tid; t < UH * UW; t += NT) {
     const int ly = t / UW, lx = t - ly * UW;
-    const int gx = bx0 - 2 + lx;
-    const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(by0 - 2 + ly, A.H - 1));
-    const size_t gi = (size_t)sy * A.W + sx;
     // columns outside the domain: left = the inflow state, right = a copy of cell W-1; neither is ever "wall"
-    // (neighbor_or_wall tests x before the mask, :266-290)
-    const uint8_t m = (gx < 0 || gx >= A.W) ? (uint8_t)0 : A.mask[gi];
-    C4 c{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
-    if ((sx == 0 && !A.mask[gi]) || gx < 0) c = A.in_c;
-    sU[0][t] = c.r; sU[1][t] = c.mx; sU[2][t] = c.my; sU[3][t] = c.E;
-    sM[t] = m;
+    // (neighbor_or_wall tests x before the mask, :266-290); rows clamp: march_load is that rule
+    const MCell q = march_load(A, bx0 - 2 + lx, by0 - 2 + ly);
+    sU[0][t] = q.c.r; sU[1][t] = q.c.mx; sU[2][t] = q.c.my; sU[3][t] = q.c.E;
+    sM[t] = q.m ? 1 : 0;
   }
   __syncthreads();
   const Tile T{sU[0], sU[1], sU[2], sU[3], sM, bx0 - 2, by0 - 2};
@@ -411,19 +422,6 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
 // (columns left of x = 0 hold the inflow state, columns right of W-1 a copy of cell W-1, rows are clamped, all
 // with the mask cleared / taken from the clamped cell), applied where a row is loaded.
 constexpr int MCOLS = 60;
-struct MCell { C4 c; bool m, in; };   // staged conserved state, body mask, "a cell of the domain" (for has-state tests)
-
-__device__ __forceinline__ MCell march_load(const Args &A, int gx, int row) {
-  MCell q;
-  const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(row, A.H - 1));
-  const size_t gi = (size_t)sy * A.W + sx;
-  const bool mk = A.mask[gi] != 0;
-  q.m = (gx < 0 || gx >= A.W) ? false : mk;
-  q.c = C4{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
-  if ((sx == 0 && !mk) || gx < 0) q.c = A.in_c;
-  q.in = gx >= 0 && gx < A.W && row >= 0 && row < A.H;
-  return q;
-}
 __device__ __forceinline__ MCell lane_shift(const MCell &q, int d) {   // the cell d lanes away (own value at the wave's ends)
   MCell o;
   if (d > 0) {   // from the lane below
@@ -625,6 +623,19 @@ __global__ void k_unit(const Args A, float *out) {
   { P4 qc{1.0f, 2.0f, -1.0f, 1.0f}, qm{0.8f, 2.2f, -0.9f, 1.1f}, qp{1.2f, 1.8f, -1.2f, 0.9f}; enforce_positive(qm, qc, qp);   // :328-338
     out[37] = qm.r; out[38] = qm.p; out[39] = qp.r; out[40] = qp.p; }
   { C4 g = p2c(A, P4{1.0f, -3.0f, 0.5f, 1.0f}); C4 w = p2c(A, P4{1.0f, 3.0f, -0.5f, 1.0f}); out[41] = g.mx + w.mx; out[42] = g.my + w.my; } // no-slip ghost, :262-264
+}
+
+// the hand-built-field neighbour lookups of tau_hypersonic_cuda_tests.cu:348-371, 567-640 on the engine's own staging
+// rule: a neighbour is march_load() (inflow left of x = 0, copy of cell W-1 right of it, clamped rows) and, where that
+// is a body cell, the no-slip ghost of the centre — exactly what both step kernels evaluate.  The centre is read raw:
+// the reference test does not run k_apply_inflow_left before its lookups, the step kernels apply it on load.
+__global__ void k_unit_neighbors(const Args A, int x, int y, float *out) {
+  const size_t ic = (size_t)y * A.W + x;
+  const C4 wg = wall_ghost(A, c2p(A, C4{A.in[0][ic], A.in[1][ic], A.in[2][ic], A.in[3][ic]}));
+  const C4 left = ghost_sel(wg, march_load(A, x - 1, y)), right = ghost_sel(wg, march_load(A, x + 1, y)),
+           up = ghost_sel(wg, march_load(A, x, y + 1)), top = ghost_sel(wg, march_load(A, x, A.H + 20));
+  out[0] = left.r; out[1] = left.mx; out[2] = right.r; out[3] = right.mx; out[4] = up.mx;     // k_test_neighbors
+  out[5] = left.r; out[6] = left.mx; out[7] = up.mx; out[8] = top.r;                          // k_test_neighbor_for_diff
 }
 
 // ---------------------------------------------------------------- rendering
@@ -921,12 +932,30 @@ extern "C" int tauh2_unit_eval(tauh2_t *h, float out[48]) {
   TAU_HIP(hipSetDevice(h->device));
   float *d = nullptr;
   TAU_HIP(hipMalloc(&d, 48 * sizeof(float)));
-  TAU_HIP(hipMemsetAsync(d, 0, 48 * sizeof(float), h->stream));
-  hipLaunchKernelGGL(h2d::k_unit, dim3(1), dim3(1), 0, h->stream, h->base, d);
-  TAU_LAUNCH_CHECK("h2d::k_unit");
-  TAU_HIP(hipMemcpyAsync(out, d, 48 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  TAU_HIP(hipStreamSynchronize(h->stream));
-  TAU_HIP(hipFree(d));
+  hipError_t e = hipMemsetAsync(d, 0, 48 * sizeof(float), h->stream);   // from here on `d` is freed on every path
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(h2d::k_unit, dim3(1), dim3(1), 0, h->stream, h->base, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, 48 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return tau::fail("tauh2_unit_eval: %s", hipGetErrorString(e));
+  return 0;
+}
+extern "C" int tauh2_unit_neighbors(tauh2_t *h, int x, int y, float out[9]) {
+  if (x < 0 || x >= h->p.W || y < 0 || y >= h->p.H) return tau::fail("tauh2_unit_neighbors: cell (%d,%d) outside the grid", x, y);
+  TAU_HIP(hipSetDevice(h->device));
+  float *d = nullptr;
+  TAU_HIP(hipMalloc(&d, 9 * sizeof(float)));
+  h2d::Args A = h->base;
+  for (int f = 0; f < 4; f++) A.in[f] = h->buf[h->cur][f];
+  hipLaunchKernelGGL(h2d::k_unit_neighbors, dim3(1), dim3(1), 0, h->stream, A, x, y, d);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, 9 * sizeof(float), hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return tau::fail("tauh2_unit_neighbors: %s", hipGetErrorString(e));
   return 0;
 }
 /* signed distance of the rounded sphere-cone body (host fp64, the expression k_init evaluates) */

@@ -215,6 +215,9 @@ __device__ __forceinline__ int wrapi(int i, int n) { i %= n; return (i < 0) ? i 
 // Mach-100 flow (stagnation pressure 1.3e4) runs FAST.
 constexpr float WLAM = 0x1p-10f;
 constexpr float W_FLIM = 6.0e4f;
+// Both operands are tested on their own: fmaxf(NaN, x) returns x, so a NaN range (nothing known about the input) would
+// otherwise select the fast form — the one case where t^4 may overflow.  A NaN comparison is false: reciprocal form.
+__host__ __device__ __forceinline__ bool fast_form(float fmax_in, float in_fmax) { return (fmax_in <= W_FLIM) && (in_fmax <= W_FLIM); }
 __device__ __forceinline__ float inv_sq(float t) { return rcp(t * t); }
 // t_k = eps + 13/12 d^2 + 1/4 e^2
 template <bool FAST> __device__ __forceinline__ float smooth_t(float sd, float e) {
@@ -918,8 +921,8 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
 
 __global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
   __shared__ StepLds S;
-  // one scalar decision for the whole launch (see WLAM above); NaN in fmax_in takes the reciprocal form
-  if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) step_body<true>(A, S);
+  // one scalar decision for the whole launch (see WLAM above)
+  if (fast_form(A.clk->fmax_in, A.in_fmax)) step_body<true>(A, S);
   else step_body<false>(A, S);
 }
 
@@ -1167,7 +1170,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 #endif
 __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyLds S;
-  if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) flux_xy_body<true>(A, S);
+  if (fast_form(A.clk->fmax_in, A.in_fmax)) flux_xy_body<true>(A, S);
   else flux_xy_body<false>(A, S);
 }
 
@@ -1390,7 +1393,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 // W = waves per SIMD the register allocator is asked for (the launch picks one: TAU3D_Z_WAVES, default 4)
 template <int W> __global__ __launch_bounds__(ZNT, W) void k_update_z(const Args A) {
   __shared__ ZRing ring;
-  if (fmaxf(A.clk->fmax_in, A.in_fmax) <= W_FLIM) update_z_body<true>(A, ring);
+  if (fast_form(A.clk->fmax_in, A.in_fmax)) update_z_body<true>(A, ring);
   else update_z_body<false>(A, ring);
 }
 
@@ -2189,7 +2192,7 @@ extern "C" int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max
   memcpy(&w, &c.fmax_bits, 4);
   if (read_max) *read_max = c.fmax_in;
   if (written_max) *written_max = w;
-  if (fast_form) *fast_form = fmaxf(c.fmax_in, h->base.in_fmax) <= h3d::W_FLIM ? 1 : 0;
+  if (fast_form) *fast_form = h3d::fast_form(c.fmax_in, h->base.in_fmax) ? 1 : 0;
   return 0;
 }
 extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {

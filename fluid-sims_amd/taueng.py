@@ -167,6 +167,7 @@ def load():
         "tauh2_get_time": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
         "tauh2_sync": ([vp], i32),
         "tauh2_unit_eval": ([vp, C.POINTER(f32)], i32),
+        "tauh2_unit_neighbors": ([vp, i32, i32, C.POINTER(f32)], i32),
         "tauh2_body_sdf": ([C.c_double] * 5, C.c_double),
         "tausph_params_default": ([C.POINTER(SphParams), i32], None),
         "tausph_create": ([C.POINTER(vp), C.POINTER(SphParams), i32, vp], i32),
@@ -509,6 +510,11 @@ class Hypersonic2D:
     def unit_eval(self):
         out = (C.c_float * 48)()
         _ck(self._L.tauh2_unit_eval(self._h, out))
+        return np.array(out, np.float32)
+
+    def unit_neighbors(self, x, y):
+        out = (C.c_float * 9)()
+        _ck(self._L.tauh2_unit_neighbors(self._h, x, y, out))
         return np.array(out, np.float32)
 
     def time(self):

@@ -195,6 +195,10 @@ int tauh2_render(tauh2_t *h, int view_mode, uint32_t *host_rgba, float *host_val
  * evaluates the kernel's device helpers on the known answers of tau_hypersonic_cuda_tests.cu:245-346;
  * out[48] layout is documented at h2d::k_unit */
 int tauh2_unit_eval(tauh2_t *h, float out[48]);
+/* The hand-built-field neighbour lookups of tau_hypersonic_cuda_tests.cu:348-371 / 567-640 evaluated by the engine's own
+ * staging rule on the handle's CURRENT state (upload the test field first), centre cell (x, y):
+ * out = left.rho, left.mx, right.rho, right.mx, up.mx | left.rho, left.mx, wall(x,y+1).mx, top_clamped(x,H+20).rho */
+int tauh2_unit_neighbors(tauh2_t *h, int x, int y, float out[9]);
 double tauh2_body_sdf(double x, double y, double Rb, double Rn, double theta); /* sdSphereConeCapsule, :644-686 */
 int tauh2_get_time(tauh2_t *h, double *t, double *dt_last, double *maxs, int *step);
 int tauh2_sync(tauh2_t *h);

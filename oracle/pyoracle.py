@@ -61,8 +61,8 @@ def _ptrs(arrs):
 class Oracle3D:
     """3D hypersonic oracle on a Z-slab in halo layout: arrays of shape (nzl+6, ny, nx)."""
 
-    def __init__(self, nx, ny=None, nz=None, z0=0, nzl=None, params=None):
-        self.L = _lib("libtauoracle3d.so")
+    def __init__(self, nx, ny=None, nz=None, z0=0, nzl=None, params=None, lib="libtauoracle3d.so"):
+        self.L = _lib(lib)   # "libtauoracle3d_fma.so": the same source with FMA contraction on (tests/test_oracle_spread.py)
         self.L.o3_clock_end.argtypes = [C.POINTER(Clock), C.c_float, C.c_float]
         self.L.o3_step.restype = C.c_float
         self.L.o3_step.argtypes = [C.POINTER(P3), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
@@ -276,8 +276,8 @@ class SphParams(C.Structure):
 class OracleSph:
     """2D WCSPH oracle (tau_sph.cu), linked-list neighbour order = descending particle index."""
 
-    def __init__(self, N, **kw):
-        L = _lib("libtauoraclesph.so")
+    def __init__(self, N, lib="libtauoraclesph.so", **kw):
+        L = _lib(lib)        # "libtauoraclesph_asc.so": cell lists walked in ascending particle order
         L.osph_create.restype = C.c_void_p
         L.osph_create.argtypes = [C.POINTER(SphParams)]
         L.osph_destroy.argtypes = [C.c_void_p]

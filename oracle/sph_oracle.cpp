@@ -142,7 +142,14 @@ void osph_substep(osph *S, float dt) {
   const int N = P.N, Gx = S->Gx, Gy = S->Gy;
   const float cell = S->cell, h = S->h, mass = S->mass;
   std::fill(S->head.begin(), S->head.end(), -1);
-  for (int i = 0; i < N; i++) { /* k_build_cells, ascending i == descending list order */
+  /* k_build_cells.  Inserting in ascending i leaves each list in DESCENDING particle order — what the block emulator
+   * produced for the reference.  -DTAU_SPH_ORACLE_ASCENDING inserts in descending i instead: lists in
+   * ascending order, the other legal fp32 summation order (a GPU's atomicExch order is arbitrary). */
+#ifdef TAU_SPH_ORACLE_ASCENDING
+  for (int i = N - 1; i >= 0; i--) {
+#else
+  for (int i = 0; i < N; i++) {
+#endif
     int gx = grid_c(S->pos[i].x, cell, Gx), gy = grid_c(S->pos[i].y, cell, Gy);
     int c = gy * Gx + gx;
     S->cellOf[i] = c;

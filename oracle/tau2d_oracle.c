@@ -429,6 +429,42 @@ void o2h_unit_inflow(double gamma, double mach, double out[4]) {
   out[0] = p.rho; out[1] = p.u; out[2] = p.v; out[3] = p.p;
 }
 
+/* k_test_clamps, tau_hypersonic_cuda_tests.cu:255-264 (expectations :395-401) */
+void o2h_unit_clamps(double gamma, double out[4], double eps[2]) {
+  tauh2_params c; memset(&c, 0, sizeof(c)); c.gamma = gamma;
+  ctx_t X = {1, 1, c, 0, 0, 0, 0, 0};
+  prim_t badp = {-2.0, 1.5, -0.5, -7.0};
+  cons_t cc = prim_to_cons(&X, badp);
+  cons_t in = {1.0, 3.0, 4.0, 1e-20};
+  prim_t q = cons_to_prim(&X, in);
+  out[0] = cc.rho; out[1] = cc.E; out[2] = q.rho; out[3] = q.p;
+  eps[0] = EPS_RHO; eps[1] = EPS_P;
+}
+/* k_test_enforce_positive / _no_change, :316-338 (expectations :455-478) */
+void o2h_unit_enforce_positive(int valid, double out[4]) {
+  prim_t qc, qm, qp;
+  if (!valid) { qc = (prim_t){1.0, 4.0, -2.0, 1.0}; qm = (prim_t){-1.0, 8.0, -4.0, -3.0}; qp = (prim_t){-2.0, -8.0, 4.0, -2.0}; }
+  else { qc = (prim_t){1.0, 2.0, -1.0, 1.0}; qm = (prim_t){0.8, 2.2, -0.9, 1.1}; qp = (prim_t){1.2, 1.8, -1.2, 0.9}; }
+  enforce_positive_faces(&qm, qc, &qp);
+  out[0] = qm.rho; out[1] = qm.p; out[2] = qp.rho; out[3] = qp.p;
+}
+/* k_test_sdf, :340-346 (expectations :480-484) */
+void o2h_unit_sdf(double out[2]) {
+  out[0] = sdSphereConeCapsule(1.0, 0.0, 5.0, 2.0, 0.6);
+  out[1] = sdSphereConeCapsule(40.0, 0.0, 5.0, 2.0, 0.6);
+}
+/* k_test_neighbors + k_test_neighbor_for_diff on a caller-built field, :348-371 (expectations :613-631):
+ * out = left.rho, left.mx, right.rho, right.mx, up.mx | left.rho, left.mx, wall(x, y+1).mx, top_clamped(x, H+20).rho */
+void o2h_unit_neighbors(const tauh2_params *P, const double *rho, const double *mx, const double *my, const double *E,
+                        const uint8_t *mask, int x, int y, double out[9]) {
+  ctx_t X = {P->W, P->H, *P, rho, mx, my, E, mask};
+  prim_t center = cons_to_prim(&X, load_cons(&X, y * P->W + x));
+  cons_t left = neighbor(&X, center, x - 1, y), right = neighbor(&X, center, x + 1, y), up = neighbor(&X, center, x, y + 1);
+  cons_t top = neighbor(&X, center, x, P->H + 20);
+  out[0] = left.rho; out[1] = left.mx; out[2] = right.rho; out[3] = right.mx; out[4] = up.mx;
+  out[5] = left.rho; out[6] = left.mx; out[7] = up.mx; out[8] = top.rho;
+}
+
 /* ---------------------------------------------------------------- rendering */
 
 /* sample_prim_bc, :706-727 */

@@ -277,3 +277,31 @@ def test_fast_weights_keep_small_smooth_corrections(eng, oracle_built):
     print("smooth", {k: (f"{rep[k]:.1e}", f"{rep2[k]:.1e}") for k in rep})
     for k in ("xi", "phix", "phiy", "phiz", "rho", "mx", "my", "mz", "E"):
         assert rep[k] < 2e-6 and rep[k] <= 1.5 * rep2[k] + 1e-7, (k, rep[k], rep2[k])
+
+
+def test_lam_zet_error_is_the_oracles_own_two_build_spread(eng, oracle_built):
+    """tests/parity.py compares lam = ln p and zet = ln e_vib at 1e-5 * kappa, kappa = (gamma-1) E / p.  The justification
+    is measured here, not asserted: on the same developed state the ORACLE built with FMA contraction (how the
+    reference's GPU build rounds) differs from the IEEE oracle by more than the literal 1e-5 in lam — and the engine's
+    error against the IEEE oracle is of that size, not larger (tests/test_oracle_spread.py is the CPU half)."""
+    from tests.test_oracle_spread import two_build_spread_3d
+    n = 32
+    e = eng.Tau3D(n)
+    o = oracle_built.Oracle3D(n)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(40)
+    state = e.download()
+    dt, gain = 2.0e-6, 1.0
+    st = o.from_interior(state)
+    o.fill_halo_periodic(st)
+    ieee, fma, fluid = two_build_spread_3d(oracle_built, o, st, dt, gain)
+    e.step_explicit(dt, gain)
+    got = e.download()
+    for name, idx in (("lam", 4), ("zet", 5)):
+        spread = np.abs(fma[idx].astype(np.float64) - ieee[idx])[fluid].max()
+        err = np.abs(got[idx].astype(np.float64) - ieee[idx])[fluid].max()
+        print(f"{name}: engine vs IEEE oracle {err:.2e}, FMA oracle vs IEEE oracle {spread:.2e}")
+        assert err <= 3.0 * spread + 1e-6, (name, err, spread)
+    assert np.abs(fma[4].astype(np.float64) - ieee[4])[fluid].max() > 1e-5     # the literal 1e-5 is not attainable for lam
+    e.close()

@@ -163,3 +163,27 @@ def test_marching_step_agrees_with_the_tile_step(eng, tmp_path, W, H, steps):
         assert np.isfinite(a[k]).all()
         scale = max(float(np.abs(b[k]).max()), 1e-30)
         assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= 2e-5 * scale, k
+
+
+def test_neighbor_lookups_on_the_reference_field(eng):
+    """The nine known answers of the reference's neighbour tests (tau_hypersonic_cuda_tests.cu:348-371, 567-640: inflow at
+    x < 0, fluid neighbour, NO-SLIP reflection mx 3 -> -3 at a body cell, clamped y) evaluated by the engine's own staging
+    rule (h2d::march_load + ghost_sel — what both step kernels stage their tiles / rows with), on the hand-built field."""
+    nf = GOLD["unit_known_answers_tau_hypersonic_cuda_tests"]["neighbors_field"]
+    W, H = 64, 32
+    x, y = nf["x"], nf["y"]
+    rho = np.full((H, W), nf["rest"]["rho"], np.float32)
+    mx = np.zeros((H, W), np.float32)
+    my = np.zeros((H, W), np.float32)
+    E = np.full((H, W), nf["rest"]["p"] / (GAMMA - 1.0), np.float32)
+    mask = np.zeros((H, W), np.uint8)
+    mx[y, x] = nf["mx_center"]
+    mx[y, x + 1] = nf["mx_right"]
+    mask[y + 1, x] = nf["mask_up"]
+    e = eng.Hypersonic2D(W, H)
+    e.upload([rho, mx, my, E], mask)
+    got = e.unit_neighbors(x, y)
+    infl_mx = 25.0 * np.sqrt(np.float32(GAMMA))          # default_config: Mach 25 (tau_hypersonic_cuda.cu:1394-1409)
+    want = [1.0, infl_mx, 1.0, 7.0, -3.0, 1.0, infl_mx, -3.0, 1.0]
+    np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)   # fp32 engine: the reference's 1e-12 at double becomes 1 ulp
+    e.close()
