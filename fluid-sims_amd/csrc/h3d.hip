@@ -989,7 +989,6 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   const int lc = (ty + HALO) * PXS + (tx + HALO);
 
   bool own_solid;
-  size_t hcol;   // column of the halo cell this thread staged (for the next-plane prefetch)
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
     fetch_cell_q(A, x, yw, zh, zg, q, own_solid);
@@ -998,7 +997,6 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
     sS[lc] = own_solid ? 1 : 0;
     constexpr int NROWS = 2 * HALO * XT;
     constexpr int NHALO = NROWS + YT * 2 * HALO;
-    hcol = (size_t)yw * A.nx + min(x, A.nx - 1);
     if (tid < NHALO) {
       const int p = tid;
       int ly, lx;
@@ -1020,24 +1018,9 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
       sS[li] = sol ? 1 : 0;
-      hcol = (size_t)gy * A.nx + min(max(gx, 0), A.nx - 1);
     }
   }
   __syncthreads();
-  // A workgroup lives for one plane, so nothing of its own can hide the HBM latency of that plane's loads.  It pulls
-  // the SAME tile of the next plane into L2 instead (loads into one scratch register, never read): the workgroup that
-  // stages that plane runs about one round of resident workgroups later, on the same XCD (tiles are XCD-contiguous).
-  float pf = 0.f;
-  if (A.zchunk == 1 && zh + 1 < A.nzl + 2 * HALO) {
-    const size_t pn = (size_t)A.nx * A.ny;
-    const size_t o0 = (size_t)(zh + 1) * pn + (size_t)yw * A.nx + min(x, A.nx - 1), o1 = (size_t)(zh + 1) * pn + hcol;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(A.q[m] + o0));
-      asm volatile("global_load_dword %0, %1, off" : "+v"(pf) : "v"(A.q[m] + o1));
-    }
-  }
-
   // ---- edge states of the own cell; ring cells
   // One variable at a time.  Left alone, hipcc runs the six variables breadth-first (all first differences, then all
   // smoothness indicators, ...) and needs ~140 VGPRs for it; occupancy is worth more than that ILP here.  The empty asm
@@ -1161,8 +1144,6 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
     const float d = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
     if (in_xy && !own_solid) A.dxy[m][di] = d;
   }
-  // the prefetch register must stay allocated until its loads have returned
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf));
 }
 
 #ifndef TAU3D_XY_WAVES

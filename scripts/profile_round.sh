@@ -4,11 +4,11 @@
 # copied into profiles/ and committed.  Counters are collected in their own passes (FETCH_SIZE and
 # WRITE_SIZE do not fit one pass; never combined with sys/hip traces).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
-CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-variants"
+CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-variants --no-configs"
 run() { # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
@@ -19,6 +19,7 @@ run kernel_stats --kernel-trace --stats
 run pmc_fetch --pmc FETCH_SIZE
 run pmc_write --pmc WRITE_SIZE
 run pmc_sq --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY
+run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CU_CYCLES
 run pmc_lds --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 # secondary kernels: Gray-Scott / Laplacians / 2D Euler / SPH through one script
 CMD="python scripts/bench_secondary.py --quick"
