@@ -525,7 +525,16 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
     }
     P4 xlo, xhi, ylo, yhi;
     predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
+#ifdef TAU_H2_SERIAL
+    // phase by phase: hipcc otherwise interleaves the two predictors and the two faces for ILP and needs 164 VGPRs (three
+    // waves per SIMD); a wave issues at most every ~6 cycles whatever its ILP (profiles/r02/valu_calib.txt), so occupancy
+    // is worth more.  The empty asm makes the next phase's inputs wait for this phase's results.
+    asm volatile("" : "+v"(xlo.r), "+v"(xlo.p), "+v"(xhi.r), "+v"(xhi.p), "+v"(pd.r), "+v"(pu.r));
+#endif
     predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
+#ifdef TAU_H2_SERIAL
+    asm volatile("" : "+v"(ylo.r), "+v"(ylo.p), "+v"(yhi.r), "+v"(yhi.p), "+v"(xhi.u), "+v"(xlo.u));
+#endif
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     P4 xhi_l;
     xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
@@ -533,6 +542,9 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
     const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my,
                    __shfl_down(Fx.E, 1, 64) - Fx.E};
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
+#ifdef TAU_H2_SERIAL
+    { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
+#endif
     const C4 Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
     // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175
     const int j = a - 2;
