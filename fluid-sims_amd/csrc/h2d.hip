@@ -422,6 +422,9 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
 // (columns left of x = 0 hold the inflow state, columns right of W-1 a copy of cell W-1, rows are clamped, all
 // with the mask cleared / taken from the clamped cell), applied where a row is loaded.
 constexpr int MCOLS = 60;
+#ifndef TAU_H2_LDS_WAVES
+#define TAU_H2_LDS_WAVES 4
+#endif
 __device__ __forceinline__ MCell lane_shift(const MCell &q, int d) {   // the cell d lanes away (own value at the wave's ends)
   MCell o;
   if (d > 0) {   // from the lane below
@@ -571,6 +574,172 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
         Un.my += (A.visc_nu * dt) * D2(my);
         Un.E += (A.visc_e * dt) * D2(E);
 #undef D2
+        Un.r = fmaxf(Un.r, EPS_RHO);
+        P4 pp = c2p(A, Un);
+        if (pp.p <= EPS_P || !isfinite(pp.p) || !isfinite(pp.r) || !isfinite(pp.u) || !isfinite(pp.v)) {
+          pp.r = fmaxf(pp.r, EPS_RHO);
+          pp.p = fmaxf(pp.p, EPS_P);
+          Un = p2c(A, pp);
+        }
+        // wavespeed of the new state as the next step will see it; pp IS cons_to_prim(Un) (re-floored where repaired)
+        const float ca = sound(A, pp), cv = fmaxf(fabsf(pp.u) + ca, fabsf(pp.v) + ca);
+        sp = (gx == 0) ? in_sp : (isfinite(cv) ? cv : 1e-12f);
+      }
+      if (own) {
+        const size_t gi = (size_t)j * A.W + gx;
+        A.out[0][gi] = Un.r; A.out[1][gi] = Un.mx; A.out[2][gi] = Un.my; A.out[3][gi] = Un.E;
+        smax = fmaxf(smax, sp);
+      }
+    }
+    yhi_prev = yhi; Gy_lo = Gy; dFx = dFx_p;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+  if (lane == 0) tau::atomic_max_float_bits(&A.st->maxs_bits[(A.slot + 1) % 3], smax);
+}
+
+// The same march with the five-row input window in LDS instead of registers (one private [5 rows][5 words][64 lanes] ring
+// per wave, 6.4 KB: rows are written once and read where they are used, a neighbour d lanes away is an LDS read at
+// lane + d instead of a shuffle, and nothing slides): the register window cost the kernel ~30 VGPRs and 25 moves per
+// trip and held it at 164 VGPRs = three waves per SIMD, where a wave's ~6-cycle issue interval (profiles/r02/
+// valu_calib.txt) leaves the VALU idle whenever one of the three stalls.
+struct MRing {
+  float (*w)[5][64];   // [slot][r, mx, my, E, flags][lane]
+  int lane;
+  __device__ __forceinline__ void put(int slot, const MCell &q) const {
+    w[slot][0][lane] = q.c.r; w[slot][1][lane] = q.c.mx; w[slot][2][lane] = q.c.my; w[slot][3][lane] = q.c.E;
+    w[slot][4][lane] = __int_as_float((int)q.m | ((int)q.in << 1));
+  }
+  __device__ __forceinline__ MCell get(int slot, int d) const {   // the cell d lanes below (d > 0) / above; own value at the wave's ends
+    const int l = min(max(lane - d, 0), 63);
+    MCell q;
+    q.c = C4{w[slot][0][l], w[slot][1][l], w[slot][2][l], w[slot][3][l]};
+    const int f = __float_as_int(w[slot][4][l]);
+    q.m = f & 1; q.in = (f >> 1) & 1;
+    return q;
+  }
+  __device__ __forceinline__ C4 cons(int slot) const { return C4{w[slot][0][lane], w[slot][1][lane], w[slot][2][lane], w[slot][3][lane]}; }
+  __device__ __forceinline__ bool flag(int slot, int d) const { return __float_as_int(w[slot][4][min(max(lane - d, 0), 63)]) & 1; }
+  __device__ __forceinline__ float fld(int slot, int f, int ln, int d) const { return w[slot][f][min(max(ln - d, 0), 63)]; }
+};
+__global__ __launch_bounds__(256, TAU_H2_LDS_WAVES) void k_march_lds(const Args A, int rows, int nstrips, int nchunks) {
+  __shared__ float sW[4][5][5][64];
+  const int lane = threadIdx.x & 63;
+  const unsigned nwork = (unsigned)(nstrips * nchunks);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  float dt;
+  if (A.dt_explicit > 0.f) dt = A.dt_explicit;
+  else {
+    float maxs = __uint_as_float(A.st->maxs_bits[A.slot]);
+    if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
+    dt = fminf(A.cfl / maxs, A.dt_diff);
+  }
+  const float half = 0.5f * dt;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { // the step's bookkeeping: sim_t += dt, :1888
+    A.st->t += (double)dt;
+    A.st->dt_last = dt;
+    A.st->step += 1;
+    A.st->maxs_bits[(A.slot + 2) % 3] = 0u;
+  }
+  if (wid >= nwork) return;
+  const int strip = (int)(wid % (unsigned)nstrips), chunk = (int)(wid / (unsigned)nstrips);
+  const int gx = strip * MCOLS + lane - 2;
+  const bool own = lane >= 2 && lane < 2 + MCOLS && gx < A.W;
+  const int j0 = chunk * rows, j1 = min(j0 + rows, A.H);
+
+  const MRing R{sW[threadIdx.x >> 6], lane};
+  // slots: row a sits in slot s4, rows a-1 .. a-4 in s3 .. s0 (a ring of five, rotated once per trip).  Before the first
+  // trip rows j0-2, j0-2, j0-1 stand in for a-3 .. a-1 as in k_march (the first two rows a trip completes are j0, j0+1).
+  int s0 = 0, s1 = 1, s2 = 2, s3 = 3, s4 = 4;
+  {
+    const MCell a2 = march_load(A, gx, j0 - 2), a1 = march_load(A, gx, j0 - 1);
+    R.put(s1, a2); R.put(s2, a2); R.put(s3, a2); R.put(s4, a1);
+  }
+  P4 yhi_prev{1.f, 0.f, 0.f, 1.f};                // predicted high-y state of row a-2
+  C4 Gy_lo{0.f, 0.f, 0.f, 0.f};                   // y-face flux below row a-2 (between a-3 and a-2)
+  C4 dFx{0.f, 0.f, 0.f, 0.f};                     // x flux difference of row a-2
+  float smax = 0.f;
+  const float in_sp = cell_speed(A, A.in_c);      // the inflow column's speed (its state is overwritten on load)
+  MCell nxt = march_load(A, gx, j0);
+  P4 q3 = c2p(A, R.cons(s3)), q4 = c2p(A, R.cons(s4)), q2 = q3;   // primitives of rows a-2, a-1, a (after the slide): each row is converted once
+  for (int a = j0; a <= j1 + 1; a++) {
+    { const int t = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = t; }   // window = rows a-4 .. a in slots s0 .. s4
+    R.put(s4, nxt);
+    q2 = q3; q3 = q4; q4 = c2p(A, nxt.c);
+    const bool m4 = nxt.m;
+    if (a < j1 + 1) nxt = march_load(A, gx, a + 1);
+    // ---- predict row p = a-1 (centre w3) along x and y
+    const P4 qc = q3;
+    const MCell w3 = R.get(s3, 0), l1 = R.get(s3, 1), r1 = R.get(s3, -1);
+    const MCell w2 = R.get(s2, 0);
+    // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried
+    P4 pl{__shfl_up(qc.r, 1, 64), __shfl_up(qc.u, 1, 64), __shfl_up(qc.v, 1, 64), __shfl_up(qc.p, 1, 64)};
+    P4 pr{__shfl_down(qc.r, 1, 64), __shfl_down(qc.u, 1, 64), __shfl_down(qc.v, 1, 64), __shfl_down(qc.p, 1, 64)};
+    P4 pd = q2, pu = q4;
+    if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | m4) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
+      const C4 wg = wall_ghost(A, qc);
+      if (l1.m) pl = c2p(A, wg);
+      if (r1.m) pr = c2p(A, wg);
+      if (w2.m) pd = c2p(A, wg);
+      if (m4) pu = c2p(A, wg);
+    }
+    P4 xlo, xhi, ylo, yhi;
+    predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
+#ifdef TAU_H2_SERIAL
+    // phase by phase: hipcc otherwise interleaves the two predictors and the two faces for ILP and needs 164 VGPRs (three
+    // waves per SIMD); a wave issues at most every ~6 cycles whatever its ILP (profiles/r02/valu_calib.txt), so occupancy
+    // is worth more.  The empty asm makes the next phase's inputs wait for this phase's results.
+    asm volatile("" : "+v"(xlo.r), "+v"(xlo.p), "+v"(xhi.r), "+v"(xhi.p), "+v"(pd.r), "+v"(pu.r));
+#endif
+    predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
+#ifdef TAU_H2_SERIAL
+    asm volatile("" : "+v"(ylo.r), "+v"(ylo.p), "+v"(yhi.r), "+v"(yhi.p), "+v"(xhi.u), "+v"(xlo.u));
+#endif
+    // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
+    P4 xhi_l;
+    xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
+    const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
+    const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my,
+                   __shfl_down(Fx.E, 1, 64) - Fx.E};
+    // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
+#ifdef TAU_H2_SERIAL
+    { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
+#endif
+    const C4 Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
+    // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175
+    const int j = a - 2;
+    if (j >= j0 && j < j1) {   // wave-uniform
+      const C4 Uc = w2.c;
+      C4 Un = Uc;
+      float sp = 0.f;
+      if (!w2.m) {
+        Un.r -= dt * dFx.r; Un.mx -= dt * dFx.mx; Un.my -= dt * dFx.my; Un.E -= dt * dFx.E;
+        Un.r -= dt * (Gy.r - Gy_lo.r); Un.mx -= dt * (Gy.mx - Gy_lo.mx);
+        Un.my -= dt * (Gy.my - Gy_lo.my); Un.E -= dt * (Gy.E - Gy_lo.E);
+        // 4th-order diffusion, ONE FIELD AT A TIME: the eight neighbours of a field are read from the ring where they are
+        // used (all 32 values at once were the register peak of the kernel); a body neighbour is the wall ghost of the centre
+        const bool bxm2 = R.flag(s2, 2), bxm1 = R.flag(s2, 1), bxp1 = R.flag(s2, -1), bxp2 = R.flag(s2, -2);
+        const bool bym2 = R.flag(s0, 0), bym1 = R.flag(s1, 0), byp1 = w3.m, byp2 = m4;
+        const bool anyb = __builtin_amdgcn_ballot_w64(bxm2 | bxm1 | bxp1 | bxp2 | bym2 | bym1 | byp1 | byp2) != 0ull;
+        C4 wgc{0.f, 0.f, 0.f, 0.f};
+        if (anyb) wgc = wall_ghost(A, c2p(A, Uc));
+        const float i12 = 1.0f / 12.0f;
+        int ls = lane;
+        auto d2 = [&](int f, float uc, float wg) -> float {
+          float xm2 = R.fld(s2, f, ls, 2), xm1 = R.fld(s2, f, ls, 1), xp1 = R.fld(s2, f, ls, -1), xp2 = R.fld(s2, f, ls, -2);
+          float ym2 = R.fld(s0, f, ls, 0), ym1 = R.fld(s1, f, ls, 0), yp1 = R.fld(s3, f, ls, 0), yp2 = R.fld(s4, f, ls, 0);
+          if (anyb) {
+            xm2 = bxm2 ? wg : xm2; xm1 = bxm1 ? wg : xm1; xp1 = bxp1 ? wg : xp1; xp2 = bxp2 ? wg : xp2;
+            ym2 = bym2 ? wg : ym2; ym1 = bym1 ? wg : ym1; yp1 = byp1 ? wg : yp1; yp2 = byp2 ? wg : yp2;
+          }
+          float r = ((-xm2 + 16.0f * xm1 - 30.0f * uc + 16.0f * xp1 - xp2) * i12) + ((-ym2 + 16.0f * ym1 - 30.0f * uc + 16.0f * yp1 - yp2) * i12);
+          asm volatile("" : "+v"(r), "+v"(ls));
+          return r;
+        };
+        Un.r += (A.visc_rho * dt) * d2(0, Uc.r, wgc.r);
+        Un.mx += (A.visc_nu * dt) * d2(1, Uc.mx, wgc.mx);
+        Un.my += (A.visc_nu * dt) * d2(2, Uc.my, wgc.my);
+        Un.E += (A.visc_e * dt) * d2(3, Uc.E, wgc.E);
         Un.r = fmaxf(Un.r, EPS_RHO);
         P4 pp = c2p(A, Un);
         if (pp.p <= EPS_P || !isfinite(pp.p) || !isfinite(pp.r) || !isfinite(pp.u) || !isfinite(pp.v)) {
@@ -898,12 +1067,16 @@ static int h2_launch_step(tauh2 *h, float dt_explicit) {
   static const int use_march = [] { const char *e = getenv("TAU_H2_MARCH"); return e ? atoi(e) : 1; }();
   if (use_march && A.W >= 8 && A.H >= 4 && (use_march > 1 || (long)A.W * A.H >= (1L << 21))) {
     const int nstrips = (A.W + h2d::MCOLS - 1) / h2d::MCOLS;
-    int rows = (int)((long)A.H * nstrips / 8192);
-    rows = rows < 8 ? 8 : (rows > 32 ? 32 : rows);                 // 4096^2: 16 rows 40.5, 32: 41.1, 48: 40.3, 96: 38.0 Gcell/s
+    // chunk length: ~16 k waves (four waves per SIMD are resident: 4096 at a time) — 4096^2 with the LDS window:
+    // 16 rows 46.7, 20: 46.3, 24: 45.8, 32: 45.2, 48: 42.8, 64: 38.8 Gcell/s (shorter chunks re-do 4 warm-up rows more often)
+    int rows = (int)((long)A.H * nstrips / 16384);
+    rows = rows < 8 ? 8 : (rows > 32 ? 32 : rows);
     static const int rows_env = [] { const char *e = getenv("TAU_H2_ROWS"); return e ? atoi(e) : 0; }();
     if (rows_env >= 1) rows = rows_env;
     const int nchunks = (A.H + rows - 1) / rows;
-    hipLaunchKernelGGL(h2d::k_march, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    static const int lds_win = [] { const char *e = getenv("TAU_H2_LDSWIN"); return e ? atoi(e) : 1; }();   // the window in LDS (default) or in registers
+    if (lds_win) hipLaunchKernelGGL(h2d::k_march_lds, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    else hipLaunchKernelGGL(h2d::k_march, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
   } else {
     hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);
   }
