@@ -319,9 +319,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                 "traffic_source": f"profile-derived, not this run: {tsrc}" if traffic else None,
                 "kernel": "h3d::k_flux_xy + h3d::k_update_z (one step = the pair)" if split else "h3d::k_step",
-                "launches": k_launches,
-                "avg_launch_ms": round(k_ms / max(k_launches, 1), 4),
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(k_launches, 1),
+                "launches": args.steps, "event_intervals": k_launches,   # a Z-slab step is two timed intervals (edges, interior)
+                "avg_launch_ms": round(k_ms / max(args.steps, 1), 4),    # kernel time of ONE step on this GPU (rank 0)
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(args.steps, 1),
+                "per_gpu": world > 1,                                     # N > 1: rank 0's slab (its cells / its kernel time)
                 "note": "the step is FP32-VALU bound (WENO5 + HLLC, ~2.25 k VALU instructions per cell at ~3.4 cycles each against a "
                         "~2.3-cycle full-rate issue, profiles/r02/valu_calib.txt); the HBM fraction is reported because "
                         "BASELINE.json's metric asks for it"}

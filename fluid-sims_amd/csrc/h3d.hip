@@ -2061,22 +2061,49 @@ extern "C" int tau3d_slab_begin_async(tau3d_t *h) {
   TAU_HIP(hipSetDevice(h->device));
   return halo_pack(h, 0, 1, true);   // controller of the step before (if pending) + clock of this one + received halos
 }
-extern "C" int tau3d_slab_edges_async(tau3d_t *h, int depth) {
-  if (depth < h3d::HALO) return tau::fail("tau3d_slab_edges: depth %d is less than the %d halo planes", depth, h3d::HALO);
+// event timing of a slab piece (tau3d_timing_*): the interval covers every launch of the piece
+static int slab_timed(tau3d_t *h, int planes, int (*body)(tau3d_t *, int), int depth) {
+  const bool tm = h->timing && h->n_ev < 4096;
+  if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream));
+  if (body(h, depth)) return 1;
+  if (tm) {
+    TAU_HIP(hipEventRecord(h->ev1[h->n_ev], h->stream));
+    h->n_ev++;
+    h->ev_cells += (double)planes * (double)h->plane_n;
+  }
+  return 0;
+}
+static int slab_edges_body(tau3d_t *h, int depth) {
   const int nzl = h->nzl;
   const bool whole = 2 * depth >= nzl;
   if (h->split) {
     if (split_xy(h, 0, nzl, 0, 0, h->stream)) return 1;            // no z dependence: every local plane, before any halo is needed
     return whole ? split_z(h, 0, nzl, 0, 0, true, h->stream) : split_z(h, 0, depth, nzl - depth, nzl, true, h->stream);
   }
-  if (whole ? step_ranges(h, 0, nzl, 0, 0, nullptr) : step_ranges(h, 0, depth, nzl - depth, nzl, nullptr)) return 1;
+  const bool t = h->timing;
+  h->timing = false;                                               // (step_ranges would open an interval of its own)
+  const int rc = whole ? step_ranges(h, 0, nzl, 0, 0, nullptr) : step_ranges(h, 0, depth, nzl - depth, nzl, nullptr);
+  h->timing = t;
+  if (rc) return 1;
   return halo_pack(h, 1, 0, false);
 }
-extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
+static int slab_interior_body(tau3d_t *h, int depth) {
   const int nzl = h->nzl;
-  if (2 * depth >= nzl) return 0;
   if (h->split) return split_z(h, depth, nzl - depth, 0, 0, false, h->stream);
-  return step_ranges(h, depth, nzl - depth, 0, 0, nullptr);
+  const bool t = h->timing;
+  h->timing = false;
+  const int rc = step_ranges(h, depth, nzl - depth, 0, 0, nullptr);
+  h->timing = t;
+  return rc;
+}
+extern "C" int tau3d_slab_edges_async(tau3d_t *h, int depth) {
+  if (depth < h3d::HALO) return tau::fail("tau3d_slab_edges: depth %d is less than the %d halo planes", depth, h3d::HALO);
+  TAU_HIP(hipSetDevice(h->device));
+  return slab_timed(h, 2 * depth >= h->nzl ? h->nzl : 2 * depth, slab_edges_body, depth);
+}
+extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
+  if (2 * depth >= h->nzl) return 0;
+  return slab_timed(h, h->nzl - 2 * depth, slab_interior_body, depth);
 }
 extern "C" int tau3d_slab_end_async(tau3d_t *h) {
   h->cur ^= 1;             // std::swap x6, :1706-1711
