@@ -39,6 +39,7 @@ struct Args {
   // Laplacian passes
   float invdx2, invdy2, nudt, u0, inv_u0;
   const float *dt_dev;   // when set: nudt = nudt * (*dt_dev)  (device-resident time step)
+  int burgers_fast;      // fused Burgers passes keep u decoded between their levels (TAU_ST2_BURGERS_FAST=1; default 0)
 };
 
 // -------- transcendental pair for the Burgers encoding, accurate to ~1e-7 relative
@@ -231,10 +232,10 @@ __global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A) {
       r.b.x = A.u0 * fsinh(r.b.x); r.b.y = A.u0 * fsinh(r.b.y); r.b.z = A.u0 * fsinh(r.b.z); r.b.w = A.u0 * fsinh(r.b.w);
     }
   };
-  // Burgers: the reference re-encodes phi = asinh(u/u0) after every pass and decodes it again in the next; a fused
-  // pass keeps u between its levels and encodes level t+K only — a deviation at the rounding of asinh(sinh(.)),
-  // ~1e-7 relative against the 1e-5 contract (this kind is not a bit-exact one), and 2(K-1)/K of the sinh/asinh
-  // pairs that bound the single pass are gone.
+  // Burgers: the reference re-encodes phi = asinh(u/u0) after every pass and decodes it again in the next.  The fused
+  // pass does the same round trip in registers between its levels (u0 sinh(asinh(u / u0)), the very two functions the
+  // single pass stores and loads through), so a K-level pass is BIT-IDENTICAL to K single passes.  TAU_ST2_BURGERS_FAST=1
+  // skips the round trip (u stays decoded between levels: a deviation of ~1e-7 relative, 600 instead of ~370 Gcell/s).
   constexpr int ARITH = (KIND == K_BURGERS) ? K_SW : KIND;
 
   const Lvl zero{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
@@ -254,8 +255,15 @@ __global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A) {
     for (int s = 0; s < K; s++) {
       Lvl o;
       row_step<ARITH>(A, st[s][0], st[s][1], st[s][2], o);         // level t+s+1, row r-1-s
-      if (s + 1 < K) { st[s + 1][0] = st[s + 1][1]; st[s + 1][1] = st[s + 1][2]; st[s + 1][2] = o; }
-      else out = o;
+      if (s + 1 < K) {
+        if (KIND == K_BURGERS && !A.burgers_fast) {                  // what the next single pass would load: decode(encode(u))
+          o.a.x = A.u0 * fsinh(fasinh(o.a.x * A.inv_u0)); o.a.y = A.u0 * fsinh(fasinh(o.a.y * A.inv_u0));
+          o.a.z = A.u0 * fsinh(fasinh(o.a.z * A.inv_u0)); o.a.w = A.u0 * fsinh(fasinh(o.a.w * A.inv_u0));
+          o.b.x = A.u0 * fsinh(fasinh(o.b.x * A.inv_u0)); o.b.y = A.u0 * fsinh(fasinh(o.b.y * A.inv_u0));
+          o.b.z = A.u0 * fsinh(fasinh(o.b.z * A.inv_u0)); o.b.w = A.u0 * fsinh(fasinh(o.b.w * A.inv_u0));
+        }
+        st[s + 1][0] = st[s + 1][1]; st[s + 1][1] = st[s + 1][2]; st[s + 1][2] = o;
+      } else out = o;
     }
     const int j = r - K;                                           // row of level t+K just produced
     if (owner && j >= j0) {
@@ -364,6 +372,8 @@ static int run_steps(Pair *pr, Args A, int nsteps) {
   static const int frows = getenv("TAU_ST2_FROWS") ? atoi(getenv("TAU_ST2_FROWS")) : 32;
   static const int kmax = getenv("TAU_ST2_LEVELS") ? atoi(getenv("TAU_ST2_LEVELS")) : 4;
   const bool fuse = fuse_env && kmax >= 2 && kmax <= 4 && (A.nx & 3) == 0 && A.nx >= 8 && A.ny >= 2;
+  static const int bfast = getenv("TAU_ST2_BURGERS_FAST") ? atoi(getenv("TAU_ST2_BURGERS_FAST")) : 0;
+  A.burgers_fast = bfast;
   int s = 0;
   while (s < nsteps) {
     A.a = pr->buf[pr->cur][0]; A.b = pr->buf[pr->cur][1];
