@@ -1879,8 +1879,11 @@ extern "C" int tau3d_upload_state(tau3d_t *h, const float *const host[6]) {
   for (int f = 0; f < 6; f++)
     TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f] + h3d::HALO * h->plane_n, host[f], n * sizeof(float),
                            hipMemcpyHostToDevice, h->stream));
-  // halo planes keep what they held (a periodic fill or an exchange refreshes them from measured planes)
-  if (measure_field(h, 0, h->nzl, false)) return 1;
+  // The whole local state was replaced: its range is what these planes hold.  The halo planes are not measured — every
+  // step refreshes them before it reads them (periodic fill / unpack), from planes that were (a ring all-reduces the
+  // range) — so what they held before does not matter, and a create -> upload -> step caller gets the fast weight form
+  // like one that called tau3d_init first.
+  if (measure_field(h, 0, h->nzl, true)) return 1;
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
