@@ -7,16 +7,14 @@ The reference is single-GPU (no NCCL/MPI anywhere); this layer is ne
 
     begin      ONE kernel: d_tau controller of step n-1 (it needs the all-reduced max word), clock of step n
                (t *= exp(d_tau), dt, gain), and the halos received while step n-1 computed its interior unpacked
-    edges      [large planes: the x/y flux kernel over ALL local planes — no z dependence, no halo needed —, then]
-               edge planes [0,E) , [nzl-E,nzl) in one launch that also writes the new boundary planes into the packed
-               send buffers
+    edges      edge planes [0,E) , [nzl-E,nzl): [large planes: their x/y flux kernel, then] one launch that steps both edges
+               and also writes the new boundary planes into the packed send buffers
     isend/irecv  2 sends + 2 recvs of one packed buffer each (async)
-    interior   planes [E, nzl-E): overlaps the exchange
+    interior   planes [E, nzl-E) [x/y flux kernel + z kernel]: overlaps the exchange
     all_reduce(MAX) of the max-wavespeed and max-|primitive| words (8 bytes)
     end        swap (host bookkeeping; the controller rides on the next begin)
 
-Four dispatches (three below 128^2 planes, where the step is one fused kernel — plus a pack kernel there) and two
-collectives per step.  Only 3 planes x 6 fields cross each link per step (18.9 MB at 512^2 planes); each direction of a
+Five dispatches (four below 128^2 planes: one fused kernel per piece plus a pack kernel) and two collectives per step.  Only 3 planes x 6 fields cross each link per step (18.9 MB at 512^2 planes); each direction of a
 neighbour pair has its own xGMI link, so the exchange costs ~0.12 ms against multi-ms slab
 compute and hides behind the interior launch.  No other collective is on the data path.
 

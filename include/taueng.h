@@ -97,14 +97,15 @@ int tau3d_step_range_async(tau3d_t *h, int zl_lo, int zl_hi, void *stream);
  * the 768 resident slots of the chip fill better); the whole slab if 2*depth >= nzl.  depth >= 3. */
 int tau3d_step_edges_async(tau3d_t *h, int depth, void *stream);
 int tau3d_clock_end_async(tau3d_t *h);
-/* The same Z-slab step in at most four dispatches and two collectives (what fluid-sims_amd/slab.py drives):
+/* The same Z-slab step in five dispatches (four with TAU3D_SLAB_XY_FIRST=1: the x/y flux kernel then runs once, over all
+ * planes, inside the edges piece — but the exchange has less to hide behind) and two collectives (what fluid-sims_amd/slab.py drives):
  *   tau3d_slab_begin_async        ONE kernel: d_tau controller of the previous step (if one is pending: it needs the
  *                                 all-reduced max word), clock of this step, received halos unpacked into the current state
- *   tau3d_slab_edges_async(E)     [large planes: the x/y flux kernel over ALL local planes — it has no z dependence and
- *                                 needs no halo —, then] planes [0,E) and [nzl-E,nzl) in one launch that also writes the
- *                                 new boundary planes into the packed send buffers (no separate pack kernel)
+ *   tau3d_slab_edges_async(E)     planes [0,E) and [nzl-E,nzl): [large planes: their x/y flux kernel, then] one launch that
+ *                                 steps both edges and also writes the new boundary planes into the packed send buffers
+ *                                 (no separate pack kernel)
  *   <caller: post the send / recv of tau3d_halo_buf_ptr(kind, side)>
- *   tau3d_slab_interior_async(E)  planes [E, nzl-E): overlaps the exchange
+ *   tau3d_slab_interior_async(E)  planes [E, nzl-E) [x/y flux kernel + z kernel]: overlaps the exchange
  *   <caller: all-reduce(max) the two words at tau3d_max_ptr>
  *   tau3d_slab_end_async          swap; host bookkeeping only — the controller rides on the next tau3d_slab_begin_async
  *                                 (or on tau3d_get_clock, which flushes it) */
