@@ -110,7 +110,8 @@ def _worker(rank, world, port, shape, steps, outdir):
 
 @pytest.mark.parametrize("world,shape,steps", [(2, (64, 48, 40), 6), (4, (48, 32, 64), 5), (3, (40, 40, 50), 4),
                                                (8, (32, 32, 64), 4),        # BASELINE's world size: 8 planes per rank, E = 4
-                                               (2, (160, 128, 24), 3)])     # planes >= 128^2: the split step (k_flux_xy + k_update_z)
+                                               (2, (160, 128, 24), 3),      # planes >= 128^2: the split step (k_flux_xy + k_update_z), whole slab in the edges piece
+                                               (2, (128, 128, 40), 3)])     # split step with an interior piece: 20 planes per rank, E = 8
 def test_engine_ring_equals_single_domain(eng, tmp_path, world, shape, steps):
     mp.spawn(_worker, args=(world, _free_port(), shape, steps, str(tmp_path)), nprocs=world, join=True)
     nx, ny, nz = shape
