@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, shape, steps, outdir):
+def _worker(rank, world, port, shape, steps, outdir, prime=True):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -40,8 +40,9 @@ def _worker(rank, world, port, shape, steps, outdir):
     be.o.clock.t = 0.02
     be.o.clock.d_tau = 1e-4
     ring = slab.SlabRing(be, rank, world)
-    ring.prime()
-    ring.step(steps)
+    if prime:
+        ring.prime()
+    ring.step(steps)          # primes itself when the caller has not
     ring.finish()
     c = be.clock()
     np.savez(os.path.join(outdir, f"r{rank}.npz"), z0=z0, nzl=nzl, t=c.t, d_tau=c.d_tau, maxs=c.maxs,
@@ -72,6 +73,23 @@ def test_slab_ring_equals_single_domain(oracle_built, tmp_path, world, shape):
         assert float(d["maxs"]) == o.clock.maxs, "every rank sees the global max wavespeed"
     for g, w in zip(got, want):
         assert np.array_equal(g, w)
+
+
+def test_slab_ring_primes_itself(oracle_built, tmp_path):
+    """SlabRing.step() without a prime() call: the ring exchanges the halos and agrees on the field range by itself"""
+    world, shape, steps = 2, (16, 16, 24), 2
+    mp.spawn(_worker, args=(world, _free_port(), shape, steps, str(tmp_path), False), nprocs=world, join=True)
+    nx, ny, nz = shape
+    o = oracle_built.Oracle3D(nx, ny, nz)
+    st = o.init(1)
+    o.clock.t = 0.02
+    o.clock.d_tau = 1e-4
+    want = o.interior(o.run(st, steps))
+    for r in range(world):
+        d = np.load(os.path.join(tmp_path, f"r{r}.npz"))
+        z0, nzl = int(d["z0"]), int(d["nzl"])
+        for f in range(6):
+            assert np.array_equal(d[f"f{f}"], want[f][z0:z0 + nzl])
 
 
 def test_slab_bounds():
