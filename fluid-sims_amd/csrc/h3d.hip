@@ -236,73 +236,10 @@ __device__ __forceinline__ void weno_weights(float t0, float t1, float t2, float
   }
 }
 
-template <bool FAST>
-__device__ __forceinline__ void weno_face(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
-                                          float &R) {
-  // The one-sided slopes 3 D_a - D_b and the candidates 5 D_a - 2 D_b are written on the SECOND differences and with
-  // the factors 2 and 4 only: 3.0 and 5.0 are not inline constants, a VOP3 v_fma cannot carry a literal on gfx950, so
-  // hipcc parks them in SGPRs — and an SGPR source halves the issue rate (profiles/r02/valu_calib.txt: 4.3 against 2.3
-  // cycles).  3 D1 - D0 = 2 D1 + (D1 - D0);  5 D1 - 2 D0 = 2 (3 D1 - D0) - D1.
-  const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
-  const float EA = D1 - D0, EB = D2 - D1, EC = D3 - D2, ED = D4 - D3;
-  const float sA = sd_term<FAST>(EA), sB = sd_term<FAST>(EB), sC = sd_term<FAST>(EC), sD = sd_term<FAST>(ED);
-  float sumL, sumR;
-  // left state (centre cell v2): stencils {0,1,2} {1,2,3} {2,3,4}
-  {
-    float a0, a1, a2;
-    const float e0 = 2.f * D1 + EA;   // 3 D1 - D0
-    weno_weights<FAST>(smooth_t<FAST>(sA, e0), smooth_t<FAST>(sB, D1 + D2), smooth_t<FAST>(sC, 2.f * D2 - EC), a0, a1, a2);
-    float num = a0 * (2.f * e0 - D1) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
-    sumL = a0 + a1 + a2;
-    L = v2 + num * (rcp(sumL) * (1.f / 6.f));
-  }
-  // right state (centre cell v3): the mirror image, stencils {5,4,3} {4,3,2} {3,2,1}
-  {
-    float a0, a1, a2;
-    const float e0 = 2.f * D3 - ED;   // 3 D3 - D4
-    weno_weights<FAST>(smooth_t<FAST>(sD, e0), smooth_t<FAST>(sC, D3 + D2), smooth_t<FAST>(sB, 2.f * D2 + EB), a0, a1, a2);
-    float num = a0 * (D3 - 2.f * e0) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
-    sumR = a0 + a1 + a2;
-    R = v3 + num * (rcp(sumR) * (1.f / 6.f));
-  }
-}
-
-// x faces of the own cells, one lane per cell along x: the LEFT state of face i-1/2 is built on the three stencils
-// of cell i-1 — exactly the stencils lane i-1 has just weighted for ITS right state (in mirrored order).  So a lane
-// computes the un-normalised weights w_k (without the c_k) of its own cell only and takes the left ones from lane
-// i-1 with a DPP wave shift: per variable 3 v_mov_dpp instead of one second difference, three smoothness
-// indicators and their weights.  Lanes at tx = 0 receive another row's values: their face is not used (the
-// tile's low-x edge faces are done with weno_face in the edge round).
+// x faces of the own cells share weights across lanes (weno_face_xshare_r01 below, the fused kernel) and the split step's
+// k_flux_xy takes the left state of a face from the lane below: a DPP wave shift
 __device__ __forceinline__ float lane_below(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
-}
-template <bool FAST>
-__device__ __forceinline__ void weno_face_xshare(float v0, float v1, float v2, float v3, float v4, float v5, float &L,
-                                                 float &R) {
-  const float D0 = v1 - v0, D1 = v2 - v1, D2 = v3 - v2, D3 = v4 - v3, D4 = v5 - v4;
-  const float EB = D2 - D1, EC = D3 - D2, ED = D4 - D3;
-  const float sB = sd_term<FAST>(EB), sC = sd_term<FAST>(EC), sD = sd_term<FAST>(ED);
-  // own cell (v3): stencils {5,4,3} {4,3,2} {3,2,1}   (inline-constant forms: see weno_face)
-  const float eR = 2.f * D3 - ED;   // 3 D3 - D4
-  const float t0 = smooth_t<FAST>(sD, eR), t1 = smooth_t<FAST>(sC, D3 + D2), t2 = smooth_t<FAST>(sB, 2.f * D2 + EB);
-  float w0, w1, w2;
-  if (FAST) {
-    const float u0 = t1 * t2, u1 = t0 * t2, u2 = t0 * t1;
-    w0 = u0 * u0; w1 = u1 * u1; w2 = u2 * u2;
-  } else {
-    w0 = inv_sq(t0); w1 = inv_sq(t1); w2 = inv_sq(t2);
-  }
-  {
-    const float a0 = 0.1f * w0, a1 = 0.6f * w1, a2 = 0.3f * w2;
-    const float num = a0 * (D3 - 2.f * eR) - a1 * (2.f * D2 + D3) + a2 * (D1 - 4.f * D2);
-    R = v3 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
-  }
-  { // cell v2 = the own cell of the lane below: its stencils {0,1,2} {1,2,3} {2,3,4} are that lane's {3,2,1} {4,3,2} {5,4,3}
-    const float a0 = 0.1f * lane_below(w2), a1 = 0.6f * lane_below(w1), a2 = 0.3f * lane_below(w0);
-    const float eL = 2.f * D1 + (D1 - D0);   // 3 D1 - D0
-    const float num = a0 * (2.f * eL - D1) + a1 * (2.f * D2 + D1) + a2 * (4.f * D2 - D3);
-    L = v2 + num * (rcp(a0 + a1 + a2) * (1.f / 6.f));
-  }
 }
 
 // cell-centred: m2,m1,c,p1,p2 around a cell -> Lhi = left state at its high face, Rlo = right state at its low face
@@ -310,7 +247,11 @@ template <bool FAST>
 __device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
   const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
   const float E0 = D1 - D0, E1 = D2 - D1, E2 = D3 - D2;
-  const float eL = 2.f * D1 + E0, eR = 2.f * D2 - E2;   // 3 D1 - D0, 3 D2 - D3 (inline-constant forms: see weno_face)
+  // The one-sided slopes 3 D_a - D_b and the candidates 5 D_a - 2 D_b are written on the SECOND differences and with the
+  // factors 2 and 4 only: 3.0 and 5.0 are not inline constants, a VOP3 v_fma cannot carry a literal on gfx950, so hipcc
+  // parks them in SGPRs — and an SGPR source halves the issue rate (profiles/r02/valu_calib.txt: 4.3 against 2.3 cycles).
+  // 3 D1 - D0 = 2 D1 + (D1 - D0);  5 D1 - 2 D0 = 2 (3 D1 - D0) - D1.
+  const float eL = 2.f * D1 + E0, eR = 2.f * D2 - E2;   // 3 D1 - D0, 3 D2 - D3
   float w0, w1, w2; // 0.1 i0, 0.6 i1, 0.3 i2 with i_k = 1 / t_k^2 up to a common factor
   weno_weights<FAST>(smooth_t<FAST>(sd_term<FAST>(E0), eL), smooth_t<FAST>(sd_term<FAST>(E1), D1 + D2),
                      smooth_t<FAST>(sd_term<FAST>(E2), eR), w0, w1, w2);
@@ -1087,9 +1028,6 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 #pragma unroll
     for (int m = 0; m < 6; m++) Fx[m] = F.c[m];
   }
-#ifdef TAU3D_XY_SCHED_BARRIER
-  __builtin_amdgcn_sched_barrier(0);   // do not start fetching the y face's operands while the x face is in flight
-#endif
   {
     Prim L, R;
     float lo[6], hi[6];
