@@ -1309,8 +1309,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   }
 }
 
-// W = waves per SIMD the register allocator is asked for (the launch picks one: TAU3D_Z_WAVES, default 4)
-template <int W> __global__ __launch_bounds__(ZNT, W) void k_update_z(const Args A) {
+__global__ __launch_bounds__(ZNT, 5) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
   __shared__ ZRing ring;
   if (fast_form(A.clk->fmax_in, A.in_fmax)) update_z_body<true>(A, ring);
   else update_z_body<false>(A, ring);
@@ -1921,11 +1920,7 @@ static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipS
   Z.nzc1 = (n1 + Z.zchunk - 1) / Z.zchunk;
   Z.nzc = Z.nzc1 + (n2 ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
   if (pack) { Z.send[0] = h->xbuf[0][0]; Z.send[1] = h->xbuf[0][1]; }
-  static const int zw = [] { const char *e = getenv("TAU3D_Z_WAVES"); return e ? atoi(e) : 4; }();
-  const dim3 g((unsigned)(tz * Z.nzc)), bl(h3d::ZNT);
-  if (zw <= 3) hipLaunchKernelGGL(h3d::k_update_z<3>, g, bl, 0, s, Z);
-  else if (zw == 4) hipLaunchKernelGGL(h3d::k_update_z<4>, g, bl, 0, s, Z);
-  else hipLaunchKernelGGL(h3d::k_update_z<5>, g, bl, 0, s, Z);
+  hipLaunchKernelGGL(h3d::k_update_z, dim3((unsigned)(tz * Z.nzc)), dim3(h3d::ZNT), 0, s, Z);
   TAU_LAUNCH_CHECK("k_update_z");
   return 0;
 }
