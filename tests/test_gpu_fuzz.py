@@ -6,6 +6,7 @@ import os
 import pytest
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -17,3 +18,14 @@ def test_random_shapes(eng, oracle_built, seed):
     msgs = []
     it, bad = m.sweep(seed=seed, seconds=90.0, max_iter=90, log=msgs.append)
     assert it == 90 and bad == 0, "\n".join(msgs)
+
+
+def test_split_3d_step_on_random_shapes():
+    """a short slice of scripts/fuzz_split3d.py: the two-kernel 3D step on ragged planes up to ~220^2 against the oracle
+    (a 150 s run of it compared 626 shapes without a failure)"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_split3d.py"), "7", "12"], capture_output=True,
+                       text=True, cwd=ROOT, env=dict(os.environ, TAU3D_SPLIT="1"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "0 failures" in r.stdout
