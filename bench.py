@@ -227,6 +227,9 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configs (2D Euler, Gray-Scott, SPH, CPU)")
     ap.add_argument("--force-slab", action="store_true",
                     help="run the Z-slab ring driver even on one GPU (self-neighbour halo copies): exercises the N>1 code path")
+    ap.add_argument("--self-p2p", action="store_true",
+                    help="with --force-slab on one GPU: exchange the halos with OURSELVES through RCCL send/recv and all-reduce the "
+                         "max words (a world-of-one process group) instead of device copies")
     args = ap.parse_args()
 
     import numpy as np
@@ -244,10 +247,14 @@ def main():
     dev = torch.device("cuda", local)
 
     n = args.n
-    if world > 1:
+    if world > 1 or (args.force_slab and args.self_p2p):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29581")
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     from importlib import import_module
     slab = import_module("fluid_sims_amd.slab")
 
@@ -273,7 +280,7 @@ def main():
         be = slab.EngineSlabBackend(f.taueng, params, z0, nzl, local)
         be.h.init(1)
         be.h.set_clock(0.02, 1e-4)
-        ring = slab.SlabRing(be, rank, world)
+        ring = slab.SlabRing(be, rank, world, self_p2p=args.self_p2p)
         ring.prime()
         step = lambda k: ring.step(k)               # noqa: E731
         sync = ring.finish
@@ -365,7 +372,7 @@ def main():
                 out["cpu_baseline_2d_simd"] = {"error": str(e)}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if world > 1 or (args.force_slab and args.self_p2p):
         dist.destroy_process_group()
 
 

@@ -110,8 +110,12 @@ class SlabRing:
         interior(E)  planes [E, nzl-E)
         end()        swap"""
 
-    def __init__(self, backend, rank, world, group=None):
+    def __init__(self, backend, rank, world, group=None, self_p2p=False):
+        # self_p2p: with world == 1, send / receive the halos to / from OURSELVES through torch.distributed (RCCL) instead of a
+        # device copy — the N > 1 communication path (batched isend / irecv on the packed buffers, their stream ordering
+        # against the step kernels) on a single GPU; the all-reduce of the max words runs too
         self.b, self.rank, self.world, self.group = backend, rank, world, group
+        self.self_p2p = bool(self_p2p) and world == 1
         self.lo = (rank - 1) % world
         self.hi = (rank + 1) % world
         self._pending = None
@@ -120,7 +124,7 @@ class SlabRing:
 
     def _post_exchange(self):
         b = self.b
-        if self.world == 1:  # periodic self-neighbour: my low planes are my own high halo and vice versa
+        if self.world == 1 and not self.self_p2p:  # periodic self-neighbour: my low planes are my own high halo and vice versa
             b.buf("recv", 1).copy_(b.buf("send", 0))
             b.buf("recv", 0).copy_(b.buf("send", 1))
             return []
@@ -148,7 +152,7 @@ class SlabRing:
         self._pending = self._post_exchange()
         self._wait()
         b.unpack(0)
-        if self.world > 1:                             # the field range init / upload measured, over all slabs
+        if self.world > 1 or self.self_p2p:                             # the field range init / upload measured, over all slabs
             dist.all_reduce(b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
         self._primed = True                            # (the first begin() unpacks the same buffers once more: idempotent)
 
@@ -170,7 +174,7 @@ class SlabRing:
             b.edges(E)
             self._pending = self._post_exchange()      # async; lands before the next begin()
             b.interior(E)                              # overlaps the exchange
-            if self.world > 1:
+            if self.world > 1 or self.self_p2p:
                 dist.all_reduce(b.max_tensor(), op=dist.ReduceOp.MAX, group=self.group)
             b.end()
         return self

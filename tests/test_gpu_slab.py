@@ -95,3 +95,39 @@ def test_multigpu_driver_script_world1(eng, tmp_path):
     for g, w in zip(got, e.download()):
         assert np.array_equal(g, w)
     e.close()
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("n", [(64, 48, 40), (160, 128, 24)])     # fused step / split step
+def test_ring_over_rccl_send_recv_to_self(eng, n):
+    """The N > 1 communication path on one GPU: a world-of-one RCCL group, the ring's batched isend / irecv of the packed halo
+    buffers addressed to OURSELVES (low planes -> own high halo and vice versa: what a periodic z means for one slab) and the
+    all-reduce of the max words — real ncclSend / ncclRecv kernels on the aliased engine memory, ordered against the step
+    kernels by torch's stream semantics.  Bit-identical to the single-domain entry point."""
+    import torch
+    import torch.distributed as dist
+    slab = import_module("fluid_sims_amd.slab")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29579"
+    ref = eng.Tau3D(*n)
+    ref.init(1)
+    ref.set_clock(0.02, 1e-4)
+    c_ref = ref.step(7)
+    want = ref.download()
+    ref.close()
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        be = slab.EngineSlabBackend(eng.taueng, _params(eng, n), 0, n[2], 0)
+        be.h.init(1)
+        be.h.set_clock(0.02, 1e-4)
+        ring = slab.SlabRing(be, 0, 1, self_p2p=True)
+        ring.step(7)                      # primes itself: pack, exchange, unpack, all-reduce of the field range
+        ring.finish()
+        got = be.h.download()
+        c = be.clock()
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+        assert (c.t, c.d_tau, c.maxs, c.step) == (c_ref.t, c_ref.d_tau, c_ref.maxs, c_ref.step)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
