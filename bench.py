@@ -296,6 +296,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     k_ms, k_launches, k_cells = h.timing_read()
+    xy_ms, z_ms, n_split = h.timing_read_split()
     h.timing_enable(False)
 
     if world > 1:
@@ -330,6 +331,8 @@ def main():
                 "avg_launch_ms": round(k_ms / max(args.steps, 1), 4),    # kernel time of ONE step on this GPU (rank 0)
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(args.steps, 1),
                 "per_gpu": world > 1,                                     # N > 1: rank 0's slab (its cells / its kernel time)
+                "kernels": ([{"name": "h3d::k_flux_xy", "avg_launch_ms": round(xy_ms / n_split, 4)},
+                             {"name": "h3d::k_update_z", "avg_launch_ms": round(z_ms / n_split, 4)}] if n_split else None),
                 "note": "the step is FP32-VALU bound (WENO5 + HLLC, ~2.25 k VALU instructions per cell at ~3.4 cycles each against a "
                         "~2.3-cycle full-rate issue, profiles/r02/valu_calib.txt); the HBM fraction is reported because "
                         "BASELINE.json's metric asks for it"}

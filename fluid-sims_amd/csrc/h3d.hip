@@ -1625,7 +1625,8 @@ struct tau3d {
   bool timing;
   int n_ev;
   double ev_cells;
-  hipEvent_t ev0[4096], ev1[4096];
+  hipEvent_t ev0[4096], ev1[4096], evm[4096];   // interval start / end, and (split step) the point between its two kernels
+  bool evm_set[4096];
   bool ev_made;
 };
 
@@ -1745,7 +1746,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   for (int k = 0; k < 2; k++)
     for (int sd = 0; sd < 2; sd++) hipFree(h->xbuf[k][sd]);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
-  if (h->ev_made) for (int i = 0; i < 4096; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); }
+  if (h->ev_made) for (int i = 0; i < 4096; i++) { hipEventDestroy(h->ev0[i]); hipEventDestroy(h->ev1[i]); hipEventDestroy(h->evm[i]); }
   delete h;
 }
 
@@ -1937,8 +1938,9 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
   if (h->split) {
     const bool tm = h->timing && h->n_ev < 4096;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
-    if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s));
+    if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s)); h->evm_set[h->n_ev] = false; }
     if (split_xy(h, zl_lo, zl_hi, zl_lo2, zl_hi2, s)) return 1;
+    if (tm) { TAU_HIP(hipEventRecord(h->evm[h->n_ev], s)); h->evm_set[h->n_ev] = true; }
     if (split_z(h, zl_lo, zl_hi, zl_lo2, zl_hi2, false, s)) return 1;
     if (tm) {
       TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
@@ -1972,7 +1974,7 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
   unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   hipStream_t s = stream ? (hipStream_t)stream : h->stream;
   const bool tm = h->timing && h->n_ev < 4096;
-  if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s));
+  if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s)); h->evm_set[h->n_ev] = false; }
   hipLaunchKernelGGL(h3d::k_step, dim3(nb), dim3(h3d::NT), 0, s, A);
   TAU_LAUNCH_CHECK("k_step");
   if (tm) {
@@ -2000,7 +2002,7 @@ extern "C" int tau3d_slab_begin_async(tau3d_t *h) {
 // event timing of a slab piece (tau3d_timing_*): the interval covers every launch of the piece
 static int slab_timed(tau3d_t *h, int planes, int (*body)(tau3d_t *, int), int depth) {
   const bool tm = h->timing && h->n_ev < 4096;
-  if (tm) TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream));
+  if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream)); h->evm_set[h->n_ev] = false; }
   if (body(h, depth)) return 1;
   if (tm) {
     TAU_HIP(hipEventRecord(h->ev1[h->n_ev], h->stream));
@@ -2162,7 +2164,7 @@ extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {
 extern "C" int tau3d_timing_enable(tau3d_t *h, int on) {
   TAU_HIP(hipSetDevice(h->device));
   if (on && !h->ev_made) {
-    for (int i = 0; i < 4096; i++) { TAU_HIP(hipEventCreate(&h->ev0[i])); TAU_HIP(hipEventCreate(&h->ev1[i])); }
+    for (int i = 0; i < 4096; i++) { TAU_HIP(hipEventCreate(&h->ev0[i])); TAU_HIP(hipEventCreate(&h->ev1[i])); TAU_HIP(hipEventCreate(&h->evm[i])); }
     h->ev_made = true;
   }
   h->timing = on != 0; h->n_ev = 0; h->ev_cells = 0.0;
@@ -2180,6 +2182,23 @@ extern "C" int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, do
   if (total_ms) *total_ms = tot;
   if (launches) *launches = h->n_ev;
   if (cells) *cells = h->ev_cells;
+  return 0;
+}
+extern "C" int tau3d_timing_read_split(tau3d_t *h, double *xy_ms, double *z_ms, int *intervals) {
+  TAU_HIP(hipSetDevice(h->device));
+  double a = 0.0, b = 0.0;
+  int n = 0;
+  for (int i = 0; i < h->n_ev; i++) {
+    if (!h->evm_set[i]) continue;
+    float m0 = 0.f, m1 = 0.f;
+    TAU_HIP(hipEventSynchronize(h->ev1[i]));
+    TAU_HIP(hipEventElapsedTime(&m0, h->ev0[i], h->evm[i]));
+    TAU_HIP(hipEventElapsedTime(&m1, h->evm[i], h->ev1[i]));
+    a += m0; b += m1; n++;
+  }
+  if (xy_ms) *xy_ms = a;
+  if (z_ms) *z_ms = b;
+  if (intervals) *intervals = n;
   return 0;
 }
 // ---- visualisation (tau_hypersonic_3d_cuda.cu:1715-1739) ----
