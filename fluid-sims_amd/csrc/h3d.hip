@@ -1161,19 +1161,20 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   }
 
   float smax = 0.f, fmx = 0.f;
-  // plane z+3 of the first iteration; afterwards every iteration fetches the plane the NEXT one slides in
+  // Plane z+3 of the first iteration takes over slot 0 (plane zc_lo-2 is done).  From then on every iteration issues the loads
+  // of the plane the NEXT one needs right at its top and consumes them (writes them into the ring) at its very END, after its
+  // own stores are issued: consumed at the top of the next trip, the wait across the back-edge was a vmcnt(0) that also covered
+  // the twelve stores of the trip before (measured: no difference either way — the stores have long completed by then).
   float Nx[6];
   unsigned nsol = load_own(zc_lo + 3, Nx);
-  int base = 0;      // ring slot that plane z+3 takes over (it held plane z-2); plane z-1+k sits in slot (base+1+k) % 5
+#pragma unroll
+  for (int m = 0; m < 6; m++) ring[0][m][tid] = Nx[m];
+  ws = (ws >> 1) | (nsol << 5);
+  int s0 = 1, s1 = 2, s2 = 3, s3 = 4, s4 = 0;   // slots of planes z-1 .. z+3
 
   for (int z = zc_lo; z < zc_hi; z++) {
-#pragma unroll
-    for (int m = 0; m < 6; m++) ring[base][m][tid] = Nx[m];
-    ws = (ws >> 1) | (nsol << 5);
-    if (z + 1 < zc_hi) nsol = load_own(z + 4, Nx);
-    const int s0 = base + 1 >= 5 ? base - 4 : base + 1, s1 = base + 2 >= 5 ? base - 3 : base + 2,
-              s2 = base + 3 >= 5 ? base - 2 : base + 3, s3 = base + 4 >= 5 ? base - 1 : base + 4, s4 = base;
-    base = s0;
+    const bool more = z + 1 < zc_hi;
+    if (more) nsol = load_own(z + 4, Nx);
 
     const size_t gi = (size_t)(z + HALO) * plane_n + col;
     const size_t di = (size_t)z * plane_n + col;
@@ -1296,6 +1297,12 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     }
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+    if (more) {   // plane z+4 replaces plane z-1; the window slides
+#pragma unroll
+      for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
+      ws = (ws >> 1) | (nsol << 5);
+      const int t = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = t;
+    }
   }
 
 #pragma unroll
