@@ -58,7 +58,8 @@ def _worker(rank, world, port, kind, nx, ny, H, nsteps, outdir):
 
 
 @pytest.mark.parametrize("kind,world,shape,H,nsteps", [("gs", 2, (48, 40), 4, 11), ("gs", 3, (32, 50), 2, 7),
-                                                       ("sw", 2, (40, 36), 4, 8), ("burgers", 4, (24, 41), 3, 6)])
+                                                       ("sw", 2, (40, 36), 4, 8), ("burgers", 4, (24, 41), 3, 6),
+                                                       ("gs", 8, (32, 64), 4, 9)])   # 8 ranks, 8 rows each
 def test_row_ring_equals_single_domain(oracle_built, tmp_path, kind, world, shape, H, nsteps):
     nx, ny = shape
     mp.spawn(_worker, args=(world, _free_port(), kind, nx, ny, H, nsteps, str(tmp_path)), nprocs=world, join=True)
