@@ -95,6 +95,11 @@ struct Args {
   float *qo[6];
   float *dxy[6];
   float *send[2];            // Z-slab ring: packed send buffers the step writes its new boundary planes into (or null)
+  // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
+  const float *in0, *q0;
+  float *out0, *qo0;
+  const float *d0;
+  unsigned fstride, dstride; // floats
   int nx, ny, nz;            // global
   int nzl, z0;               // local planes, global index of local plane 0
   int zl_lo, zl_hi;          // local plane range to update
@@ -1125,7 +1130,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   auto load_own = [&](int zl, float (&dst)[6]) -> unsigned {
     const size_t gi = (size_t)(zl + HALO) * plane_n + col;
 #pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = A.q[m][gi];
+    for (int m = 0; m < 6; m++) dst[m] = A.q0[(size_t)m * A.fstride + gi];
     return A.solid[gi] != 0 ? 1u : 0u;
   };
 
@@ -1205,7 +1210,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 
     float D[6];
 #pragma unroll
-    for (int m = 0; m < 6; m++) D[m] = (in_xy && !own_solid) ? A.dxy[m][di] : 0.f;
+    for (int m = 0; m < 6; m++) D[m] = (in_xy && !own_solid) ? A.d0[(size_t)m * A.dstride + di] : 0.f;
 
     if (in_xy) {
       // Z-slab ring: the first / last three local planes of the NEW state go straight into the packed send buffers
@@ -1219,8 +1224,8 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       if (own_solid) { // :1063-1072 copy-through
 #pragma unroll
         for (int m = 0; m < 6; m++) {
-          const float e = A.in[m][gi];
-          A.out[m][gi] = e; A.qo[m][gi] = own[m];
+          const float e = A.in0[(size_t)m * A.fstride + gi];
+          A.out0[(size_t)m * A.fstride + gi] = e; A.qo0[(size_t)m * A.fstride + gi] = own[m];
           if (snd) snd[m * n3] = e;
         }
       } else {
@@ -1290,7 +1295,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
 #pragma unroll
         for (int m = 0; m < 6; m++) {
-          A.out[m][gi] = E[m]; A.qo[m][gi] = decode_field(A.u_ref, m, E[m]);
+          A.out0[(size_t)m * A.fstride + gi] = E[m]; A.qo0[(size_t)m * A.fstride + gi] = decode_field(A.u_ref, m, E[m]);
           if (snd) snd[m * n3] = E[m];
         }
       }
@@ -1613,6 +1618,7 @@ struct tau3d {
   hipStream_t stream;
   bool own_stream;
   size_t plane_n, field_n;  // floats per plane, floats per field incl. halo
+  size_t field_stride, dxy_stride;   // floats between consecutive fields of one allocation (state / cache; x/y divergence)
   float *buf[2][6];         // ping-pong, halo layout
   float *qbuf[2][6];        // split step: primitive cache of buf (same layout), bitwise decode() of it
   float *dxy[6];            // split step: x/y flux divergence of the local planes
@@ -1705,17 +1711,25 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   // the latency between dependent dispatches and keep the one-kernel step.  TAU3D_SPLIT=0/1 overrides.
   h->split = (long)p->nx * p->ny >= 128L * 128L;
   if (const char *e = getenv("TAU3D_SPLIT")) h->split = atoi(e) != 0;
-  for (int s = 0; s < 2; s++)
-    for (int f = 0; f < 6; f++) {
-      TAU_HIP(hipMalloc(&h->buf[s][f], h->field_n * sizeof(float)));
-      TAU_HIP(hipMemsetAsync(h->buf[s][f], 0, h->field_n * sizeof(float), h->stream));
-      if (h->split) {
-        TAU_HIP(hipMalloc(&h->qbuf[s][f], h->field_n * sizeof(float)));
-        TAU_HIP(hipMemsetAsync(h->qbuf[s][f], 0, h->field_n * sizeof(float), h->stream));
-      }
+  // The six fields of an array group are ONE allocation, field f at f * field_n: the per-field pointers the API hands out
+  // are as before, but a kernel can address all six through one base pointer and a stride — k_update_z touches five such
+  // groups, and thirty separate pointers (60 SGPRs) had it spilling scalars to VGPR lanes (478 v_readlane per plane).
+  h->field_stride = (h->field_n + 63) & ~(size_t)63;          // keeps every field 256-byte aligned
+  h->dxy_stride = (h->plane_n * (size_t)nzl + 63) & ~(size_t)63;
+  for (int s = 0; s < 2; s++) {
+    TAU_HIP(hipMalloc(&h->buf[s][0], 6 * h->field_stride * sizeof(float)));
+    TAU_HIP(hipMemsetAsync(h->buf[s][0], 0, 6 * h->field_stride * sizeof(float), h->stream));
+    for (int f = 1; f < 6; f++) h->buf[s][f] = h->buf[s][0] + f * h->field_stride;
+    if (h->split) {
+      TAU_HIP(hipMalloc(&h->qbuf[s][0], 6 * h->field_stride * sizeof(float)));
+      TAU_HIP(hipMemsetAsync(h->qbuf[s][0], 0, 6 * h->field_stride * sizeof(float), h->stream));
+      for (int f = 1; f < 6; f++) h->qbuf[s][f] = h->qbuf[s][0] + f * h->field_stride;
     }
-  if (h->split)
-    for (int f = 0; f < 6; f++) TAU_HIP(hipMalloc(&h->dxy[f], h->plane_n * (size_t)nzl * sizeof(float)));
+  }
+  if (h->split) {
+    TAU_HIP(hipMalloc(&h->dxy[0], 6 * h->dxy_stride * sizeof(float)));
+    for (int f = 1; f < 6; f++) h->dxy[f] = h->dxy[0] + f * h->dxy_stride;
+  }
   TAU_HIP(hipMalloc(&h->solid, h->field_n));
   TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
   for (int k = 0; k < 2; k++)
@@ -1745,8 +1759,8 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   for (int s = 0; s < 2; s++)
-    for (int f = 0; f < 6; f++) { hipFree(h->buf[s][f]); hipFree(h->qbuf[s][f]); }
-  for (int f = 0; f < 6; f++) hipFree(h->dxy[f]);
+    { hipFree(h->buf[s][0]); hipFree(h->qbuf[s][0]); }
+  hipFree(h->dxy[0]);
   hipFree(h->solid);
   hipFree(h->clk);
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
@@ -1901,6 +1915,8 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   }
   A.zl_lo = lo; A.zl_hi = hi; A.zl_lo2 = lo2; A.zl_hi2 = hi2;
   A.send[0] = A.send[1] = nullptr;
+  A.in0 = h->buf[h->cur][0]; A.out0 = h->buf[h->cur ^ 1][0]; A.q0 = h->qbuf[h->cur][0]; A.qo0 = h->qbuf[h->cur ^ 1][0];
+  A.d0 = h->dxy[0]; A.fstride = (unsigned)h->field_stride; A.dstride = (unsigned)h->dxy_stride;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s) {   // x/y faces: one plane per workgroup
   h3d::Args X;
