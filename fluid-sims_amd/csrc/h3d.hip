@@ -1103,6 +1103,16 @@ __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
 // (ring of five, no barrier: a thread only ever reads what it wrote): in registers it costs 30 VGPRs and 24 moves
 // per plane to slide, and pushed the kernel to 148 VGPRs / three waves.
 constexpr int ZT_X = 64, ZT_Y = 4, ZNT = ZT_X * ZT_Y;
+typedef __attribute__((address_space(1))) char GChar;     // global address space spelled out: the asm below would otherwise
+typedef __attribute__((address_space(1))) float GFloat;   // hide the pointer's provenance and turn the access into flat_load / flat_store
+__device__ __forceinline__ float gld(const GChar *sbase, unsigned voff) {
+  asm volatile("" : "+s"(sbase));
+  return *(const GFloat *)(sbase + voff);
+}
+__device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
+  asm volatile("" : "+s"(sbase));
+  *(GFloat *)(sbase + voff) = v;
+}
 typedef float ZRing[5][6][ZNT];
 template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring) {
   const int tid = threadIdx.x;
@@ -1126,12 +1136,24 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const float gain = A.clk->gain;
   const Gas G = gas_vgpr(A);
 
+  // Addressing: every global access of the march is  <scalar base of the field at the chunk's first plane> + <one 32-bit
+  // byte offset per lane>, the form global_load / global_store take directly (saddr + voffset).  64-bit per-lane
+  // addresses cost a half-rate v_lshl_add_u64 per access (61 per plane) and a VGPR pair each; the host keeps
+  // zchunk * plane bytes below 2^31.
+  const unsigned plane4 = (unsigned)plane_n << 2;
+  const unsigned col4 = (unsigned)col << 2;
+  const size_t fs4 = (size_t)A.fstride << 2, ds4 = (size_t)A.dstride << 2;
+  const GChar *const qP = (const GChar *)(A.q0 + (size_t)zc_lo * plane_n);               // halo-layout plane zc_lo-3
+  const uint8_t *const solP = A.solid + (size_t)zc_lo * plane_n;
+  // (hipcc would rather add the lane offset to the group's base once and then the field stride per access in 64-bit
+  // VALU ops: gld / gst pin each field's base in an SGPR pair, and the stride is made opaque once per plane so that
+  // the 24 bases are recomputed by the scalar unit instead of living in SGPRs across the loop — those spilled)
   unsigned ws = 0;
-  auto load_own = [&](int zl, float (&dst)[6]) -> unsigned {
-    const size_t gi = (size_t)(zl + HALO) * plane_n + col;
+  auto load_own = [&](int k, float (&dst)[6]) -> unsigned {   // plane zc_lo-3+k
+    const unsigned vo = col4 + (unsigned)k * plane4;
 #pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = A.q0[(size_t)m * A.fstride + gi];
-    return A.solid[gi] != 0 ? 1u : 0u;
+    for (int m = 0; m < 6; m++) dst[m] = *(const GFloat *)(qP + m * fs4 + vo);
+    return solP[vo >> 2] != 0 ? 1u : 0u;
   };
 
   // prologue: planes zc_lo-2 .. zc_lo+2 into slots 0 .. 4 (plane zc_lo-3 is only needed here); flux through the low
@@ -1139,10 +1161,10 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   float Fz_lo[6], Lz[6];
   {
     float T[6], P[6];
-    ws |= load_own(zc_lo - 3, T) << 0;
+    ws |= load_own(0, T) << 0;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-      ws |= load_own(zc_lo - 2 + k, P) << (k + 1);
+      ws |= load_own(1 + k, P) << (k + 1);
 #pragma unroll
       for (int m = 0; m < 6; m++) ring[k][m][tid] = P[m];
     }
@@ -1171,18 +1193,29 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   // own stores are issued: consumed at the top of the next trip, the wait across the back-edge was a vmcnt(0) that also covered
   // the twelve stores of the trip before (measured: no difference either way — the stores have long completed by then).
   float Nx[6];
-  unsigned nsol = load_own(zc_lo + 3, Nx);
+  unsigned nsol = load_own(6, Nx);
 #pragma unroll
   for (int m = 0; m < 6; m++) ring[0][m][tid] = Nx[m];
   ws = (ws >> 1) | (nsol << 5);
   int s0 = 1, s1 = 2, s2 = 3, s3 = 4, s4 = 0;   // slots of planes z-1 .. z+3
+  // scalar bases at the chunk's first plane; vo = (z - zc_lo) * plane bytes + column bytes
+  const GChar *const qN = qP + 7 * (size_t)plane4;                                         // plane z+4
+  const uint8_t *const solN = solP + 7 * plane_n;
+  const GChar *const inB = (const GChar *)(A.in0 + (size_t)(zc_lo + HALO) * plane_n);      // plane z, halo layout
+  GChar *const outB = (GChar *)(A.out0 + (size_t)(zc_lo + HALO) * plane_n);
+  GChar *const qoB = (GChar *)(A.qo0 + (size_t)(zc_lo + HALO) * plane_n);
+  const GChar *const dB = (const GChar *)(A.d0 + (size_t)zc_lo * plane_n);                 // plane z, no halo
+  unsigned vo = col4;
 
   for (int z = zc_lo; z < zc_hi; z++) {
     const bool more = z + 1 < zc_hi;
-    if (more) nsol = load_own(z + 4, Nx);
-
-    const size_t gi = (size_t)(z + HALO) * plane_n + col;
-    const size_t di = (size_t)z * plane_n + col;
+    size_t f4 = fs4, d4 = ds4;
+    asm volatile("" : "+s"(f4), "+s"(d4));
+    if (more) {
+#pragma unroll
+      for (int m = 0; m < 6; m++) Nx[m] = gld(qN + m * f4, vo);
+      nsol = solN[vo >> 2] != 0 ? 1u : 0u;
+    }
     const bool own_solid = (ws >> 2) & 1u;
 
     float Fz_hi[6];
@@ -1192,13 +1225,20 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       float hi[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) L.q[m] = Lz[m];
-      int ts = tid;   // one variable at a time (see k_flux_xy): the empty asm orders the next variable's LDS reads behind this one
+      // one variable at a time (see k_flux_xy): the empty asm orders the next variable's LDS reads behind this one.  The
+      // five slot addresses are formed once per plane and ride through the asm (tied to one lane index instead, they
+      // were re-formed for every variable: 30 half-rate adds)
+      const char *const rb = (const char *)&ring[0][0][0];   // byte offsets: what ds_read takes, the variable's part as its immediate
+      auto rd = [&](int a, int m) { return *(const float *)(rb + a + m * (ZNT * 4)); };
+      const int t4 = tid * 4;
+      int a0 = s0 * (24 * ZNT) + t4, a1 = s1 * (24 * ZNT) + t4, a2 = s2 * (24 * ZNT) + t4, a3 = s3 * (24 * ZNT) + t4,
+          a4 = s4 * (24 * ZNT) + t4;
 #pragma unroll
       for (int m = 0; m < 6; m++) {
-        const float w0 = ring[s0][m][ts], w1 = ring[s1][m][ts], w2 = ring[s2][m][ts], w3 = ring[s3][m][ts], w4 = ring[s4][m][ts];
+        const float w0 = rd(a0, m), w1 = rd(a1, m), w2 = rd(a2, m), w3 = rd(a3, m), w4 = rd(a4, m);
         weno_cell<FAST>(w0, w1, w2, w3, w4, Lz[m], R.q[m]);
         own[m] = w1; hi[m] = w2;
-        asm volatile("" : "+v"(ts), "+v"(Lz[m]), "+v"(R.q[m]));
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(Lz[m]), "+v"(R.q[m]));
       }
       solid_override(L, R, own, hi, ws, 2);
       prim_floor(L);
@@ -1208,26 +1248,21 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
     }
 
-    float D[6];
+    // (instruction selection works one basic block at a time and folds the zero-extension of the lane offset into the
+    // access only if it sees it there: each block gets its own copy of the offset)
+    float D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (in_xy && !own_solid) {
+      unsigned vb = vo;
+      asm volatile("" : "+v"(vb));
 #pragma unroll
-    for (int m = 0; m < 6; m++) D[m] = (in_xy && !own_solid) ? A.d0[(size_t)m * A.dstride + di] : 0.f;
+      for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
+    }
 
     if (in_xy) {
-      // Z-slab ring: the first / last three local planes of the NEW state go straight into the packed send buffers
-      // (what k_halo_pack would copy afterwards): wave-uniform branch, one dispatch less per step
-      const size_t n3 = (size_t)HALO * plane_n;
-      float *snd = nullptr;
-      if (A.send[0]) {
-        if (z < HALO) snd = A.send[0] + (size_t)z * plane_n + col;
-        else if (z >= A.nzl - HALO) snd = A.send[1] + (size_t)(z - (A.nzl - HALO)) * plane_n + col;
-      }
+      float E[6], Qn[6];   // the cell's new encoded state and its decoded primitives
       if (own_solid) { // :1063-1072 copy-through
 #pragma unroll
-        for (int m = 0; m < 6; m++) {
-          const float e = A.in0[(size_t)m * A.fstride + gi];
-          A.out0[(size_t)m * A.fstride + gi] = e; A.qo0[(size_t)m * A.fstride + gi] = own[m];
-          if (snd) snd[m * n3] = e;
-        }
+        for (int m = 0; m < 6; m++) { E[m] = *(const GFloat *)(inB + m * fs4 + vo); Qn[m] = own[m]; }   // (rare path: plain addressing)
       } else {
         const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
         float U0[6];
@@ -1286,7 +1321,6 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
         fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
 
-        float E[6];
         E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
         E[1] = fasinh(u1 * A.inv_u_ref);
         E[2] = fasinh(v1 * A.inv_u_ref);
@@ -1294,14 +1328,32 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
         E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
 #pragma unroll
-        for (int m = 0; m < 6; m++) {
-          A.out0[(size_t)m * A.fstride + gi] = E[m]; A.qo0[(size_t)m * A.fstride + gi] = decode_field(A.u_ref, m, E[m]);
-          if (snd) snd[m * n3] = E[m];
-        }
+        for (int m = 0; m < 6; m++) Qn[m] = decode_field(A.u_ref, m, E[m]);
+      }
+      {
+        unsigned vb = vo;
+        asm volatile("" : "+v"(vb));
+#pragma unroll
+        for (int m = 0; m < 6; m++) { gst(outB + m * f4, vb, E[m]); gst(qoB + m * f4, vb, Qn[m]); }
+      }
+      // Z-slab ring: the first / last three local planes of the NEW state go straight into the packed send buffers
+      // (what k_halo_pack would copy afterwards): wave-uniform branch, one dispatch less per step
+      auto send_plane = [&](float *buf, int zrel) {
+        GChar *const sB = (GChar *)(buf + (size_t)zrel * plane_n);
+        const size_t n34 = (size_t)HALO * plane4;
+        unsigned vb = col4;
+        asm volatile("" : "+v"(vb));
+#pragma unroll
+        for (int m = 0; m < 6; m++) gst(sB + m * n34, vb, E[m]);
+      };
+      if (A.send[0]) {
+        if (z < HALO) send_plane(A.send[0], z);
+        else if (z >= A.nzl - HALO) send_plane(A.send[1], z - (A.nzl - HALO));
       }
     }
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+    vo += plane4;
     if (more) {   // plane z+4 replaces plane z-1; the window slides
 #pragma unroll
       for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
