@@ -546,23 +546,44 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 __device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
   return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
 }
-// fetch_cell on the primitive cache (no transcendental work)
-__device__ __forceinline__ void fetch_cell_q(const Args &A, int gx, int gyw, int zh, int zg, float (&q)[6], bool &sol) {
+// Addressing of the split step's kernels: every global access is  <scalar base of the field at the workgroup's first
+// plane> + <one 32-bit byte offset per lane>, the form global_load / global_store take directly (saddr + voffset).
+// 64-bit per-lane addresses cost a half-rate v_lshl_add_u64 per access and a VGPR pair each.  hipcc would rather add
+// the lane offset to the group's base once and then the field stride per access in 64-bit VALU ops: the empty asm pins
+// each field's base in an SGPR pair.  Instruction selection works one basic block at a time and folds the
+// zero-extension of the lane offset into the access only if it sees it there, so each block takes its own copy
+// (lane_off) of the offset.
+typedef __attribute__((address_space(1))) char GChar;     // global address space spelled out: the asm below would otherwise
+typedef __attribute__((address_space(1))) float GFloat;   // hide the pointer's provenance and turn the access into flat_load / flat_store
+__device__ __forceinline__ float gld(const GChar *sbase, unsigned voff) {
+  asm volatile("" : "+s"(sbase));
+  return *(const GFloat *)(sbase + voff);
+}
+__device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
+  asm volatile("" : "+s"(sbase));
+  *(GFloat *)(sbase + voff) = v;
+}
+__device__ __forceinline__ unsigned lane_off(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+
+// fetch_cell on the primitive cache (no transcendental work).  qpl: field 0 of the cache at plane zh; fs4: bytes between
+// fields; spl: the solid mask at plane zh
+__device__ __forceinline__ void fetch_cell_q(const Args &A, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
+                                             int zg, float (&q)[6], bool &sol) {
   Prim p;
   if (gx < 0) {
     p = inflow_prim(A);
     sol = sdf_solid(A, gx, gyw, zg);
   } else if (gx >= A.nx) {
-    const size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + (A.nx - 1);
+    const unsigned vo = lane_off((unsigned)(gyw * A.nx + (A.nx - 1)) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = A.q[m][gi];
+    for (int m = 0; m < 6; m++) p.q[m] = gld(qpl + m * fs4, vo);
     p = outflow_prim(A, p);
     sol = sdf_solid(A, gx, gyw, zg);
   } else {
-    const size_t gi = ((size_t)zh * A.ny + gyw) * A.nx + gx;
+    const unsigned vo = lane_off((unsigned)(gyw * A.nx + gx) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = A.q[m][gi];
-    sol = A.solid[gi] != 0;
+    for (int m = 0; m < 6; m++) p.q[m] = gld(qpl + m * fs4, vo);
+    sol = spl[vo >> 2] != 0;
   }
 #pragma unroll
   for (int m = 0; m < 6; m++) q[m] = p.q[m];
@@ -934,10 +955,14 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   const int zg = wrapi(A.z0 + z, A.nz);
   const int lc = (ty + HALO) * PXS + (tx + HALO);
 
+  const size_t plane_n = (size_t)A.nx * A.ny;
+  const GChar *const qpl = (const GChar *)(A.q0 + (size_t)zh * plane_n);
+  const uint8_t *const spl = A.solid + (size_t)zh * plane_n;
+  const size_t fs4 = (size_t)A.fstride << 2;
   bool own_solid;
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
-    fetch_cell_q(A, x, yw, zh, zg, q, own_solid);
+    fetch_cell_q(A, qpl, fs4, spl, x, yw, zg, q, own_solid);
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     sS[lc] = own_solid ? 1 : 0;
@@ -959,7 +984,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
       const int gx = bx0 + lx - HALO;
       const int gy = wrapi(by0 + ly - HALO, A.ny);
       bool sol;
-      fetch_cell_q(A, gx, gy, zh, zg, q, sol);
+      fetch_cell_q(A, qpl, fs4, spl, gx, gy, zg, q, sol);
       const int li = ly * PXS + lx;
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
@@ -1079,13 +1104,19 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   __syncthreads();
 
   // ---- x/y flux divergence of the own cell
-  const size_t di = (size_t)z * ((size_t)A.nx * A.ny) + (size_t)yw * A.nx + min(x, A.nx - 1);
+  GChar *const dpl = (GChar *)(A.d0 + (size_t)z * plane_n);
+  const size_t ds4 = (size_t)A.dstride << 2;
+  float d[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     const float up = lane_above(Fx[m]);
     const float fxh = (tx == XT - 1) ? S.sFxT[m][ty] : up;
-    const float d = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
-    if (in_xy && !own_solid) A.dxy[m][di] = d;
+    d[m] = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
+  }
+  if (in_xy && !own_solid) {
+    const unsigned vo = lane_off((unsigned)(yw * A.nx + x) << 2);
+#pragma unroll
+    for (int m = 0; m < 6; m++) gst(dpl + m * ds4, vo, d[m]);
   }
 }
 
@@ -1103,16 +1134,6 @@ __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
 // (ring of five, no barrier: a thread only ever reads what it wrote): in registers it costs 30 VGPRs and 24 moves
 // per plane to slide, and pushed the kernel to 148 VGPRs / three waves.
 constexpr int ZT_X = 64, ZT_Y = 4, ZNT = ZT_X * ZT_Y;
-typedef __attribute__((address_space(1))) char GChar;     // global address space spelled out: the asm below would otherwise
-typedef __attribute__((address_space(1))) float GFloat;   // hide the pointer's provenance and turn the access into flat_load / flat_store
-__device__ __forceinline__ float gld(const GChar *sbase, unsigned voff) {
-  asm volatile("" : "+s"(sbase));
-  return *(const GFloat *)(sbase + voff);
-}
-__device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
-  asm volatile("" : "+s"(sbase));
-  *(GFloat *)(sbase + voff) = v;
-}
 typedef float ZRing[5][6][ZNT];
 template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring) {
   const int tid = threadIdx.x;
@@ -1132,22 +1153,20 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const size_t plane_n = (size_t)A.nx * A.ny;
   const size_t col = (size_t)min(y, A.ny - 1) * A.nx + min(x, A.nx - 1);
 
-  const float dt = A.clk->dt;
+  const float dt = vreg(A.clk->dt);        // six uses per plane each: an SGPR operand makes a VALU op half rate
+  const float inv_dz = vreg(A.inv_dz);
   const float gain = A.clk->gain;
   const Gas G = gas_vgpr(A);
 
-  // Addressing: every global access of the march is  <scalar base of the field at the chunk's first plane> + <one 32-bit
-  // byte offset per lane>, the form global_load / global_store take directly (saddr + voffset).  64-bit per-lane
-  // addresses cost a half-rate v_lshl_add_u64 per access (61 per plane) and a VGPR pair each; the host keeps
-  // zchunk * plane bytes below 2^31.
+  // Addressing (see gld / gst): scalar field bases at the chunk's first plane + one 32-bit byte offset per lane (with
+  // 64-bit lane addresses: 61 half-rate adds per plane); the host keeps zchunk * plane bytes below 2^32.  The field
+  // stride is made opaque once per plane so that the 24 field bases are recomputed by the scalar unit instead of living
+  // in SGPRs across the loop — those spilled.
   const unsigned plane4 = (unsigned)plane_n << 2;
   const unsigned col4 = (unsigned)col << 2;
   const size_t fs4 = (size_t)A.fstride << 2, ds4 = (size_t)A.dstride << 2;
   const GChar *const qP = (const GChar *)(A.q0 + (size_t)zc_lo * plane_n);               // halo-layout plane zc_lo-3
   const uint8_t *const solP = A.solid + (size_t)zc_lo * plane_n;
-  // (hipcc would rather add the lane offset to the group's base once and then the field stride per access in 64-bit
-  // VALU ops: gld / gst pin each field's base in an SGPR pair, and the stride is made opaque once per plane so that
-  // the 24 bases are recomputed by the scalar unit instead of living in SGPRs across the loop — those spilled)
   unsigned ws = 0;
   auto load_own = [&](int k, float (&dst)[6]) -> unsigned {   // plane zc_lo-3+k
     const unsigned vo = col4 + (unsigned)k * plane4;
@@ -1248,12 +1267,9 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
     }
 
-    // (instruction selection works one basic block at a time and folds the zero-extension of the lane offset into the
-    // access only if it sees it there: each block gets its own copy of the offset)
     float D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (in_xy && !own_solid) {
-      unsigned vb = vo;
-      asm volatile("" : "+v"(vb));
+      const unsigned vb = lane_off(vo);
 #pragma unroll
       for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
     }
@@ -1276,7 +1292,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         float U1[6];
 #pragma unroll
         for (int m = 0; m < 6; m++) {
-          float dU = -(D[m] + (Fz_hi[m] - Fz_lo[m]) * A.inv_dz);
+          float dU = -(D[m] + (Fz_hi[m] - Fz_lo[m]) * inv_dz);
           U1[m] = U0[m] + dU * dt;
         }
         float r1 = fmaxf(U1[0], RHO_P_FLOOR);
@@ -1331,8 +1347,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         for (int m = 0; m < 6; m++) Qn[m] = decode_field(A.u_ref, m, E[m]);
       }
       {
-        unsigned vb = vo;
-        asm volatile("" : "+v"(vb));
+        const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) { gst(outB + m * f4, vb, E[m]); gst(qoB + m * f4, vb, Qn[m]); }
       }
@@ -1341,8 +1356,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       auto send_plane = [&](float *buf, int zrel) {
         GChar *const sB = (GChar *)(buf + (size_t)zrel * plane_n);
         const size_t n34 = (size_t)HALO * plane4;
-        unsigned vb = col4;
-        asm volatile("" : "+v"(vb));
+        const unsigned vb = lane_off(col4);
 #pragma unroll
         for (int m = 0; m < 6; m++) gst(sB + m * n34, vb, E[m]);
       };
@@ -1763,6 +1777,8 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   // the latency between dependent dispatches and keep the one-kernel step.  TAU3D_SPLIT=0/1 overrides.
   h->split = (long)p->nx * p->ny >= 128L * 128L;
   if (const char *e = getenv("TAU3D_SPLIT")) h->split = atoi(e) != 0;
+  if (h->split && h->plane_n * sizeof(float) * 8 > 0xFFFFFFFFull)   // k_update_z: 32-bit byte offsets within a chunk of planes
+    return tau::fail("tau3d_create: %d x %d planes are beyond the split step's 32-bit in-chunk offsets", p->nx, p->ny);
   // The six fields of an array group are ONE allocation, field f at f * field_n: the per-field pointers the API hands out
   // are as before, but a kernel can address all six through one base pointer and a stride — k_update_z touches five such
   // groups, and thirty separate pointers (60 SGPRs) had it spilling scalars to VGPR lanes (478 v_readlane per plane).
@@ -1992,6 +2008,10 @@ static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipS
   // reconstructions and a face).  Fewer, longer chunks were measured: 256^3 in 4 layers of 64 planes 1117 us against 997.
   int zc = h->zchunk;
   if (zc <= 0) { zc = (int)((long)(n1 + n2) * tz / 4096); zc = zc < 16 ? 16 : (zc > 64 ? 64 : zc); }
+  {   // the kernel addresses a chunk with 32-bit byte offsets from its first plane (tau3d_create checked that 8 planes fit)
+    const long zmax = (long)(0xFFFFFFFFull / (h->plane_n * sizeof(float)));
+    if (zc > zmax) zc = (int)zmax;
+  }
   Z.zchunk = zc < n1 ? zc : n1;
   Z.nzc1 = (n1 + Z.zchunk - 1) / Z.zchunk;
   Z.nzc = Z.nzc1 + (n2 ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
