@@ -124,14 +124,22 @@ __device__ __forceinline__ C4 neigh(const Args &A, const Tile &T, P4 center, int
 // known-answer check of tau_hypersonic_cuda_tests.cu:567-640 (k_unit_neighbors below):
 struct MCell { C4 c; bool m, in; };   // staged conserved state, body mask, "a cell of the domain" (for has-state tests)
 
+// Loads: scalar field base + 32-bit lane offset (tau_common.h; tauh2_create checks W * H * 4 < 2^32).  The inflow state is
+// taken into registers FIRST: written as `q.c = loaded; if (..) q.c = A.in_c;` hipcc selected between the two ADDRESSES
+// (global memory / a stack copy of the kernel argument) and issued flat_load through a generic pointer.
 __device__ __forceinline__ MCell march_load(const Args &A, int gx, int row) {
   MCell q;
+  float ir = A.in_c.r, imx = A.in_c.mx, imy = A.in_c.my, iE = A.in_c.E;
+  asm volatile("" : "+s"(ir), "+s"(imx), "+s"(imy), "+s"(iE));
   const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(row, A.H - 1));
-  const size_t gi = (size_t)sy * A.W + sx;
+  const unsigned gi = (unsigned)(sy * A.W + sx);
+  const unsigned g4 = tau::lane_off(gi << 2);
   const bool mk = A.mask[gi] != 0;
   q.m = (gx < 0 || gx >= A.W) ? false : mk;
-  q.c = C4{A.in[0][gi], A.in[1][gi], A.in[2][gi], A.in[3][gi]};
-  if ((sx == 0 && !mk) || gx < 0) q.c = A.in_c;
+  const float c0 = tau::gld((const tau::GChar *)A.in[0], g4), c1 = tau::gld((const tau::GChar *)A.in[1], g4),
+              c2 = tau::gld((const tau::GChar *)A.in[2], g4), c3 = tau::gld((const tau::GChar *)A.in[3], g4);
+  const bool inflow = (sx == 0 && !mk) || gx < 0;
+  q.c = C4{inflow ? ir : c0, inflow ? imx : c1, inflow ? imy : c2, inflow ? iE : c3};
   q.in = gx >= 0 && gx < A.W && row >= 0 && row < A.H;
   return q;
 }
@@ -516,8 +524,8 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
     const P4 qc = q3;
     const MCell l1 = lane_shift(w3, 1), r1 = lane_shift(w3, -1);
     // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried
-    P4 pl{__shfl_up(qc.r, 1, 64), __shfl_up(qc.u, 1, 64), __shfl_up(qc.v, 1, 64), __shfl_up(qc.p, 1, 64)};
-    P4 pr{__shfl_down(qc.r, 1, 64), __shfl_down(qc.u, 1, 64), __shfl_down(qc.v, 1, 64), __shfl_down(qc.p, 1, 64)};
+    P4 pl{tau::lane_dn(qc.r), tau::lane_dn(qc.u), tau::lane_dn(qc.v), tau::lane_dn(qc.p)};
+    P4 pr{tau::lane_up(qc.r), tau::lane_up(qc.u), tau::lane_up(qc.v), tau::lane_up(qc.p)};
     P4 pd = q2, pu = q4;
     if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | w4.m) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
       const C4 wg = wall_ghost(A, qc);
@@ -540,10 +548,9 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
 #endif
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     P4 xhi_l;
-    xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
+    xhi_l.r = tau::lane_dn(xhi.r); xhi_l.u = tau::lane_dn(xhi.u); xhi_l.v = tau::lane_dn(xhi.v); xhi_l.p = tau::lane_dn(xhi.p);
     const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
-    const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my,
-                   __shfl_down(Fx.E, 1, 64) - Fx.E};
+    const C4 dFx_p{tau::lane_up(Fx.r) - Fx.r, tau::lane_up(Fx.mx) - Fx.mx, tau::lane_up(Fx.my) - Fx.my, tau::lane_up(Fx.E) - Fx.E};
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
 #ifdef TAU_H2_SERIAL
     { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
@@ -586,8 +593,9 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
         sp = (gx == 0) ? in_sp : (isfinite(cv) ? cv : 1e-12f);
       }
       if (own) {
-        const size_t gi = (size_t)j * A.W + gx;
-        A.out[0][gi] = Un.r; A.out[1][gi] = Un.mx; A.out[2][gi] = Un.my; A.out[3][gi] = Un.E;
+        const unsigned g4 = tau::lane_off((unsigned)(j * A.W + gx) << 2);
+        tau::gst((tau::GChar *)A.out[0], g4, Un.r); tau::gst((tau::GChar *)A.out[1], g4, Un.mx);
+        tau::gst((tau::GChar *)A.out[2], g4, Un.my); tau::gst((tau::GChar *)A.out[3], g4, Un.E);
         smax = fmaxf(smax, sp);
       }
     }
@@ -622,11 +630,12 @@ struct MRing {
   __device__ __forceinline__ bool flag(int slot, int d) const { return __float_as_int(w[slot][4][min(max(lane - d, 0), 63)]) & 1; }
   __device__ __forceinline__ float fld(int slot, int f, int ln, int d) const { return w[slot][f][min(max(ln - d, 0), 63)]; }
 };
-__global__ __launch_bounds__(256, TAU_H2_LDS_WAVES) void k_march_lds(const Args A, int rows, int nstrips, int nchunks) {
-  __shared__ float sW[4][5][5][64];
+template <int WPB>   // waves per workgroup: the waves of a workgroup share nothing, WPB only sets the granularity of dispatch
+__global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const Args A, int rows, int nstrips, int nchunks) {
+  __shared__ float sW[WPB][5][5][64];
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(nstrips * nchunks);
-  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
+  const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * WPB + (threadIdx.x >> 6);
   float dt;
   if (A.dt_explicit > 0.f) dt = A.dt_explicit;
   else {
@@ -673,8 +682,8 @@ __global__ __launch_bounds__(256, TAU_H2_LDS_WAVES) void k_march_lds(const Args 
     const MCell w3 = R.get(s3, 0), l1 = R.get(s3, 1), r1 = R.get(s3, -1);
     const MCell w2 = R.get(s2, 0);
     // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried
-    P4 pl{__shfl_up(qc.r, 1, 64), __shfl_up(qc.u, 1, 64), __shfl_up(qc.v, 1, 64), __shfl_up(qc.p, 1, 64)};
-    P4 pr{__shfl_down(qc.r, 1, 64), __shfl_down(qc.u, 1, 64), __shfl_down(qc.v, 1, 64), __shfl_down(qc.p, 1, 64)};
+    P4 pl{tau::lane_dn(qc.r), tau::lane_dn(qc.u), tau::lane_dn(qc.v), tau::lane_dn(qc.p)};
+    P4 pr{tau::lane_up(qc.r), tau::lane_up(qc.u), tau::lane_up(qc.v), tau::lane_up(qc.p)};
     P4 pd = q2, pu = q4;
     if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | m4) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
       const C4 wg = wall_ghost(A, qc);
@@ -683,29 +692,38 @@ __global__ __launch_bounds__(256, TAU_H2_LDS_WAVES) void k_march_lds(const Args 
       if (w2.m) pd = c2p(A, wg);
       if (m4) pu = c2p(A, wg);
     }
-    P4 xlo, xhi, ylo, yhi;
-    predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
+    // The chunk's first trip predicts row j0-1 and its last one row j1: of those rows only the y states are read (by the
+    // y faces below row j0 / above row j1-1) — their x predictor and x faces, and the y face below row j0-1, are skipped
+    // (wave-uniform branches; with ~16-row chunks the two warm-up trips were 11 % of the kernel).
+    const bool row_x = a > j0 && a <= j1;
+    P4 xlo{1.f, 0.f, 0.f, 1.f}, xhi{1.f, 0.f, 0.f, 1.f}, ylo, yhi;
+    if (row_x) {
+      predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
 #ifdef TAU_H2_SERIAL
-    // phase by phase: hipcc otherwise interleaves the two predictors and the two faces for ILP and needs 164 VGPRs (three
-    // waves per SIMD); a wave issues at most every ~6 cycles whatever its ILP (profiles/r02/valu_calib.txt), so occupancy
-    // is worth more.  The empty asm makes the next phase's inputs wait for this phase's results.
-    asm volatile("" : "+v"(xlo.r), "+v"(xlo.p), "+v"(xhi.r), "+v"(xhi.p), "+v"(pd.r), "+v"(pu.r));
+      // phase by phase: hipcc otherwise interleaves the two predictors and the two faces for ILP and needs 164 VGPRs (three
+      // waves per SIMD); a wave issues at most every ~6 cycles whatever its ILP (profiles/r02/valu_calib.txt), so occupancy
+      // is worth more.  The empty asm makes the next phase's inputs wait for this phase's results.
+      asm volatile("" : "+v"(xlo.r), "+v"(xlo.p), "+v"(xhi.r), "+v"(xhi.p), "+v"(pd.r), "+v"(pu.r));
 #endif
+    }
     predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
 #ifdef TAU_H2_SERIAL
     asm volatile("" : "+v"(ylo.r), "+v"(ylo.p), "+v"(yhi.r), "+v"(yhi.p), "+v"(xhi.u), "+v"(xlo.u));
 #endif
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
-    P4 xhi_l;
-    xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
-    const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
-    const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my,
-                   __shfl_down(Fx.E, 1, 64) - Fx.E};
+    C4 dFx_p{0.f, 0.f, 0.f, 0.f};
+    if (row_x) {
+      P4 xhi_l;
+      xhi_l.r = tau::lane_dn(xhi.r); xhi_l.u = tau::lane_dn(xhi.u); xhi_l.v = tau::lane_dn(xhi.v); xhi_l.p = tau::lane_dn(xhi.p);
+      const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
+      dFx_p = C4{tau::lane_up(Fx.r) - Fx.r, tau::lane_up(Fx.mx) - Fx.mx, tau::lane_up(Fx.my) - Fx.my, tau::lane_up(Fx.E) - Fx.E};
+    }
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
 #ifdef TAU_H2_SERIAL
     { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
 #endif
-    const C4 Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
+    C4 Gy{0.f, 0.f, 0.f, 0.f};
+    if (a > j0) Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
     // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175
     const int j = a - 2;
     if (j >= j0 && j < j1) {   // wave-uniform
@@ -752,8 +770,9 @@ __global__ __launch_bounds__(256, TAU_H2_LDS_WAVES) void k_march_lds(const Args 
         sp = (gx == 0) ? in_sp : (isfinite(cv) ? cv : 1e-12f);
       }
       if (own) {
-        const size_t gi = (size_t)j * A.W + gx;
-        A.out[0][gi] = Un.r; A.out[1][gi] = Un.mx; A.out[2][gi] = Un.my; A.out[3][gi] = Un.E;
+        const unsigned g4 = tau::lane_off((unsigned)(j * A.W + gx) << 2);
+        tau::gst((tau::GChar *)A.out[0], g4, Un.r); tau::gst((tau::GChar *)A.out[1], g4, Un.mx);
+        tau::gst((tau::GChar *)A.out[2], g4, Un.my); tau::gst((tau::GChar *)A.out[3], g4, Un.E);
         smax = fmaxf(smax, sp);
       }
     }
@@ -970,6 +989,8 @@ static void h2_consts(tauh2 *h) {
 extern "C" int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, void *stream) {
   if (!out || !p) return tau::fail("tauh2_create: null argument");
   if (p->W < 8 || p->H < 8) return tau::fail("tauh2_create: grid must be at least 8x8");
+  if ((size_t)p->W * p->H * sizeof(float) > 0x7FFFFFFFull)   // the kernels address a field with 32-bit byte offsets
+    return tau::fail("tauh2_create: %d x %d cells are beyond the kernels' 32-bit field offsets", p->W, p->H);
   if (!(p->gamma > 1.0)) return tau::fail("tauh2_create: gamma must be > 1");
   TAU_HIP(hipSetDevice(device));
   tauh2 *h = new (std::nothrow) tauh2();
@@ -1075,7 +1096,11 @@ static int h2_launch_step(tauh2 *h, float dt_explicit) {
     if (rows_env >= 1) rows = rows_env;
     const int nchunks = (A.H + rows - 1) / rows;
     static const int lds_win = [] { const char *e = getenv("TAU_H2_LDSWIN"); return e ? atoi(e) : 1; }();   // the window in LDS (default) or in registers
-    if (lds_win) hipLaunchKernelGGL(h2d::k_march_lds, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    static const int wpb = [] { const char *e = getenv("TAU_H2_WPB"); return e ? atoi(e) : 1; }();   // one wave per workgroup: 49.2 against 48.2 Gcell/s with four (4096^2)
+    const unsigned nwork = (unsigned)(nstrips * nchunks);
+    if (lds_win && wpb == 1) hipLaunchKernelGGL(h2d::k_march_lds<1>, dim3(nwork), dim3(64), 0, h->stream, A, rows, nstrips, nchunks);
+    else if (lds_win && wpb == 2) hipLaunchKernelGGL(h2d::k_march_lds<2>, dim3((nwork + 1) / 2), dim3(128), 0, h->stream, A, rows, nstrips, nchunks);
+    else if (lds_win) hipLaunchKernelGGL(h2d::k_march_lds<4>, dim3((nwork + 3) / 4), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
     else hipLaunchKernelGGL(h2d::k_march, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
   } else {
     hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);

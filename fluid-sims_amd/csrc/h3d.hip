@@ -546,24 +546,7 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 __device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
   return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
 }
-// Addressing of the split step's kernels: every global access is  <scalar base of the field at the workgroup's first
-// plane> + <one 32-bit byte offset per lane>, the form global_load / global_store take directly (saddr + voffset).
-// 64-bit per-lane addresses cost a half-rate v_lshl_add_u64 per access and a VGPR pair each.  hipcc would rather add
-// the lane offset to the group's base once and then the field stride per access in 64-bit VALU ops: the empty asm pins
-// each field's base in an SGPR pair.  Instruction selection works one basic block at a time and folds the
-// zero-extension of the lane offset into the access only if it sees it there, so each block takes its own copy
-// (lane_off) of the offset.
-typedef __attribute__((address_space(1))) char GChar;     // global address space spelled out: the asm below would otherwise
-typedef __attribute__((address_space(1))) float GFloat;   // hide the pointer's provenance and turn the access into flat_load / flat_store
-__device__ __forceinline__ float gld(const GChar *sbase, unsigned voff) {
-  asm volatile("" : "+s"(sbase));
-  return *(const GFloat *)(sbase + voff);
-}
-__device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
-  asm volatile("" : "+s"(sbase));
-  *(GFloat *)(sbase + voff) = v;
-}
-__device__ __forceinline__ unsigned lane_off(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::lane_off;   // tau_common.h: scalar base + 32-bit lane offset
 
 // fetch_cell on the primitive cache (no transcendental work).  qpl: field 0 of the cache at plane zh; fs4: bytes between
 // fields; spl: the solid mask at plane zh

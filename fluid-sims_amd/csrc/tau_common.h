@@ -62,4 +62,29 @@ __device__ __forceinline__ void atomic_max_float_bits(unsigned *word, float v) {
 int st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,
                      float u0, int oneD, const float *dt_dev, float frac, hipStream_t stream);
 
+// Addressing of the marching / plane kernels: every global access is  <scalar base pointer> + <one 32-bit byte offset per
+// lane>, the form global_load / global_store take directly (saddr + voffset).  64-bit per-lane addresses cost a half-rate
+// v_lshl_add_u64 per access and a VGPR pair each.  hipcc would rather add the lane offset to a group's base once and then
+// the field stride per access in 64-bit VALU ops: the empty asm pins each base in an SGPR pair.  Instruction selection
+// works one basic block at a time and folds the zero-extension of the lane offset into the access only if it sees it
+// there, so each block takes its own copy (lane_off) of the offset.
+typedef __attribute__((address_space(1))) char GChar;     // global address space spelled out: the asm below would otherwise
+typedef __attribute__((address_space(1))) float GFloat;   // hide the pointer's provenance and turn the access into flat_load / flat_store
+__device__ __forceinline__ float gld(const GChar *sbase, unsigned voff) {
+  asm volatile("" : "+s"(sbase));
+  return *(const GFloat *)(sbase + voff);
+}
+__device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
+  asm volatile("" : "+s"(sbase));
+  *(GFloat *)(sbase + voff) = v;
+}
+__device__ __forceinline__ unsigned lane_off(unsigned v) { asm volatile("" : "+v"(v)); return v; }
+// the value of the lane below / above (lane 0 / 63: its own): one DPP move instead of the ds_bpermute __shfl_up / __shfl_down cost
+__device__ __forceinline__ float lane_dn(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float lane_up(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
+}
+
 } // namespace tau

@@ -74,6 +74,23 @@ OP(mix_alu5_sgpr, asm volatile("v_mul_f32 %0, %2, %0\n v_add_f32 %1, %3, %1\n v_
 OP(mix_fma4_dsr1, asm volatile("v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n v_fma_f32 %0, %0, %2, %3\n"
                                "ds_read_b32 %1, %4\n s_waitcnt lgkmcnt(8)"
                                : "+v"(x), "+v"(y) : "v"(a), "v"(b), "v"((int)(threadIdx.x * 4))))
+// packed fp32 (two floats per lane and instruction, operands in aligned VGPR pairs): does one instruction cost one issue slot?
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define PK(NAME, INSTR)                                                                                  \
+  struct NAME {                                                                                          \
+    static constexpr const char *name = #NAME;                                                           \
+    static __device__ __forceinline__ void go(float &x, float &y, float a, float b) {                    \
+      v2f X, A2, B2;                                                                                     \
+      X.x = x; X.y = y; A2.x = a; A2.y = a; B2.x = b; B2.y = b;                                          \
+      asm volatile(INSTR : "+v"(X) : "v"(A2), "v"(B2));                                                  \
+      x = X.x; y = X.y;                                                                                  \
+    }                                                                                                    \
+  };
+PK(pk_fma, "v_pk_fma_f32 %0, %0, %1, %2")
+PK(pk_mul, "v_pk_mul_f32 %0, %0, %1")
+PK(pk_add, "v_pk_add_f32 %0, %0, %2")
+PK(pk_fma_neg, "v_pk_fma_f32 %0, %0, %1, %2 neg_lo:[0,1,0] neg_hi:[0,1,0]")
+PK(pk_fma_sel, "v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]")
 }  // namespace op
 using namespace op;
 
@@ -188,6 +205,11 @@ int main(int argc, char **argv) {
   sweep<fma_vcc>(iters);
   sweep<fma_mods>(iters);
   sweep<fmac_vv>(iters);
+  sweep<pk_fma>(iters);
+  sweep<pk_mul>(iters);
+  sweep<pk_add>(iters);
+  sweep<pk_fma_neg>(iters);
+  sweep<pk_fma_sel>(iters);
   sweep<mul_vv>(iters);
   sweep<mul_sv>(iters);
   sweep<mul_lv>(iters);
