@@ -124,20 +124,23 @@ __device__ __forceinline__ C4 neigh(const Args &A, const Tile &T, P4 center, int
 // known-answer check of tau_hypersonic_cuda_tests.cu:567-640 (k_unit_neighbors below):
 struct MCell { C4 c; bool m, in; };   // staged conserved state, body mask, "a cell of the domain" (for has-state tests)
 
-// Loads: scalar field base + 32-bit lane offset (tau_common.h; tauh2_create checks W * H * 4 < 2^32).  The inflow state is
-// taken into registers FIRST: written as `q.c = loaded; if (..) q.c = A.in_c;` hipcc selected between the two ADDRESSES
-// (global memory / a stack copy of the kernel argument) and issued flat_load through a generic pointer.
-__device__ __forceinline__ MCell march_load(const Args &A, int gx, int row) {
+// Loads: scalar base of the field at row `row0` (wave-uniform, <= every row the caller asks for) + 32-bit lane offset
+// (tau_common.h): a caller touches a band of at most ~60 rows, so the offsets fit whatever the grid (tauh2_create bounds
+// W).  The inflow state is taken into registers FIRST: written as `q.c = loaded; if (..) q.c = A.in_c;` hipcc selected
+// between the two ADDRESSES (global memory / a stack copy of the kernel argument) and issued flat_load through a generic
+// pointer.
+__device__ __forceinline__ MCell march_load(const Args &A, int gx, int row, int row0) {
   MCell q;
   float ir = A.in_c.r, imx = A.in_c.mx, imy = A.in_c.my, iE = A.in_c.E;
   asm volatile("" : "+s"(ir), "+s"(imx), "+s"(imy), "+s"(iE));
   const int sx = max(0, min(gx, A.W - 1)), sy = max(0, min(row, A.H - 1));
-  const unsigned gi = (unsigned)(sy * A.W + sx);
+  const size_t rb = (size_t)row0 * A.W;
+  const unsigned gi = (unsigned)((sy - row0) * A.W + sx);
   const unsigned g4 = tau::lane_off(gi << 2);
-  const bool mk = A.mask[gi] != 0;
+  const bool mk = (A.mask + rb)[gi] != 0;
   q.m = (gx < 0 || gx >= A.W) ? false : mk;
-  const float c0 = tau::gld((const tau::GChar *)A.in[0], g4), c1 = tau::gld((const tau::GChar *)A.in[1], g4),
-              c2 = tau::gld((const tau::GChar *)A.in[2], g4), c3 = tau::gld((const tau::GChar *)A.in[3], g4);
+  const float c0 = tau::gld((const tau::GChar *)(A.in[0] + rb), g4), c1 = tau::gld((const tau::GChar *)(A.in[1] + rb), g4),
+              c2 = tau::gld((const tau::GChar *)(A.in[2] + rb), g4), c3 = tau::gld((const tau::GChar *)(A.in[3] + rb), g4);
   const bool inflow = (sx == 0 && !mk) || gx < 0;
   q.c = C4{inflow ? ir : c0, inflow ? imx : c1, inflow ? imy : c2, inflow ? iE : c3};
   q.in = gx >= 0 && gx < A.W && row >= 0 && row < A.H;
@@ -318,7 +321,7 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
     const int ly = t / UW, lx = t - ly * UW;
     // columns outside the domain: left = the inflow state, right = a copy of cell W-1; neither is ever "wall"
     // (neighbor_or_wall tests x before the mask, :266-290); rows clamp: march_load is that rule
-    const MCell q = march_load(A, bx0 - 2 + lx, by0 - 2 + ly);
+    const MCell q = march_load(A, bx0 - 2 + lx, by0 - 2 + ly, max(by0 - 2, 0));
     sU[0][t] = q.c.r; sU[1][t] = q.c.mx; sU[2][t] = q.c.my; sU[3][t] = q.c.E;
     sM[t] = q.m ? 1 : 0;
   }
@@ -505,21 +508,22 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
   const int j0 = chunk * rows, j1 = min(j0 + rows, A.H);
 
   MCell w0, w1, w2, w3, w4;                       // input rows a-4 .. a
-  w2 = march_load(A, gx, j0 - 2);                 // (the loop's first slide makes these rows a-4, a-3 = j0-3?, see below)
-  w3 = march_load(A, gx, j0 - 2);
-  w4 = march_load(A, gx, j0 - 1);
+  const int row0 = __builtin_amdgcn_readfirstlane(max(j0 - 2, 0));   // the band's first row: base of every load / store offset
+  w2 = march_load(A, gx, j0 - 2, row0);           // (the loop's first slide makes these rows a-4, a-3 = j0-3?, see below)
+  w3 = march_load(A, gx, j0 - 2, row0);
+  w4 = march_load(A, gx, j0 - 1, row0);
   w0 = w2; w1 = w2;
   P4 yhi_prev{1.f, 0.f, 0.f, 1.f};                // predicted high-y state of row a-2
   C4 Gy_lo{0.f, 0.f, 0.f, 0.f};                   // y-face flux below row a-2 (between a-3 and a-2)
   C4 dFx{0.f, 0.f, 0.f, 0.f};                     // x flux difference of row a-2
   float smax = 0.f;
   const float in_sp = cell_speed(A, A.in_c);      // the inflow column's speed (its state is overwritten on load)
-  MCell nxt = march_load(A, gx, j0);
+  MCell nxt = march_load(A, gx, j0, row0);
   P4 q3 = c2p(A, w3.c), q4 = c2p(A, w4.c), q2 = q3;   // primitives of rows a-2, a-1, a (after the slide): each row is converted once
   for (int a = j0; a <= j1 + 1; a++) {
     w0 = w1; w1 = w2; w2 = w3; w3 = w4; w4 = nxt; // window = rows a-4 .. a
     q2 = q3; q3 = q4; q4 = c2p(A, w4.c);
-    if (a < j1 + 1) nxt = march_load(A, gx, a + 1);
+    if (a < j1 + 1) nxt = march_load(A, gx, a + 1, row0);
     // ---- predict row p = a-1 (centre w3) along x and y
     const P4 qc = q3;
     const MCell l1 = lane_shift(w3, 1), r1 = lane_shift(w3, -1);
@@ -593,9 +597,10 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
         sp = (gx == 0) ? in_sp : (isfinite(cv) ? cv : 1e-12f);
       }
       if (own) {
-        const unsigned g4 = tau::lane_off((unsigned)(j * A.W + gx) << 2);
-        tau::gst((tau::GChar *)A.out[0], g4, Un.r); tau::gst((tau::GChar *)A.out[1], g4, Un.mx);
-        tau::gst((tau::GChar *)A.out[2], g4, Un.my); tau::gst((tau::GChar *)A.out[3], g4, Un.E);
+        const size_t rb = (size_t)row0 * A.W;
+        const unsigned g4 = tau::lane_off((unsigned)((j - row0) * A.W + gx) << 2);
+        tau::gst((tau::GChar *)(A.out[0] + rb), g4, Un.r); tau::gst((tau::GChar *)(A.out[1] + rb), g4, Un.mx);
+        tau::gst((tau::GChar *)(A.out[2] + rb), g4, Un.my); tau::gst((tau::GChar *)(A.out[3] + rb), g4, Un.E);
         smax = fmaxf(smax, sp);
       }
     }
@@ -656,12 +661,13 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
   const bool own = lane >= 2 && lane < 2 + MCOLS && gx < A.W;
   const int j0 = chunk * rows, j1 = min(j0 + rows, A.H);
 
+  const int row0 = __builtin_amdgcn_readfirstlane(max(j0 - 2, 0));   // the band's first row: base of every load / store offset
   const MRing R{sW[threadIdx.x >> 6], lane};
   // slots: row a sits in slot s4, rows a-1 .. a-4 in s3 .. s0 (a ring of five, rotated once per trip).  Before the first
   // trip rows j0-2, j0-2, j0-1 stand in for a-3 .. a-1 as in k_march (the first two rows a trip completes are j0, j0+1).
   int s0 = 0, s1 = 1, s2 = 2, s3 = 3, s4 = 4;
   {
-    const MCell a2 = march_load(A, gx, j0 - 2), a1 = march_load(A, gx, j0 - 1);
+    const MCell a2 = march_load(A, gx, j0 - 2, row0), a1 = march_load(A, gx, j0 - 1, row0);
     R.put(s1, a2); R.put(s2, a2); R.put(s3, a2); R.put(s4, a1);
   }
   P4 yhi_prev{1.f, 0.f, 0.f, 1.f};                // predicted high-y state of row a-2
@@ -669,14 +675,14 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
   C4 dFx{0.f, 0.f, 0.f, 0.f};                     // x flux difference of row a-2
   float smax = 0.f;
   const float in_sp = cell_speed(A, A.in_c);      // the inflow column's speed (its state is overwritten on load)
-  MCell nxt = march_load(A, gx, j0);
+  MCell nxt = march_load(A, gx, j0, row0);
   P4 q3 = c2p(A, R.cons(s3)), q4 = c2p(A, R.cons(s4)), q2 = q3;   // primitives of rows a-2, a-1, a (after the slide): each row is converted once
   for (int a = j0; a <= j1 + 1; a++) {
     { const int t = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = t; }   // window = rows a-4 .. a in slots s0 .. s4
     R.put(s4, nxt);
     q2 = q3; q3 = q4; q4 = c2p(A, nxt.c);
     const bool m4 = nxt.m;
-    if (a < j1 + 1) nxt = march_load(A, gx, a + 1);
+    if (a < j1 + 1) nxt = march_load(A, gx, a + 1, row0);
     // ---- predict row p = a-1 (centre w3) along x and y
     const P4 qc = q3;
     const MCell w3 = R.get(s3, 0), l1 = R.get(s3, 1), r1 = R.get(s3, -1);
@@ -770,9 +776,10 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
         sp = (gx == 0) ? in_sp : (isfinite(cv) ? cv : 1e-12f);
       }
       if (own) {
-        const unsigned g4 = tau::lane_off((unsigned)(j * A.W + gx) << 2);
-        tau::gst((tau::GChar *)A.out[0], g4, Un.r); tau::gst((tau::GChar *)A.out[1], g4, Un.mx);
-        tau::gst((tau::GChar *)A.out[2], g4, Un.my); tau::gst((tau::GChar *)A.out[3], g4, Un.E);
+        const size_t rb = (size_t)row0 * A.W;
+        const unsigned g4 = tau::lane_off((unsigned)((j - row0) * A.W + gx) << 2);
+        tau::gst((tau::GChar *)(A.out[0] + rb), g4, Un.r); tau::gst((tau::GChar *)(A.out[1] + rb), g4, Un.mx);
+        tau::gst((tau::GChar *)(A.out[2] + rb), g4, Un.my); tau::gst((tau::GChar *)(A.out[3] + rb), g4, Un.E);
         smax = fmaxf(smax, sp);
       }
     }
@@ -832,8 +839,8 @@ __global__ void k_unit(const Args A, float *out) {
 __global__ void k_unit_neighbors(const Args A, int x, int y, float *out) {
   const size_t ic = (size_t)y * A.W + x;
   const C4 wg = wall_ghost(A, c2p(A, C4{A.in[0][ic], A.in[1][ic], A.in[2][ic], A.in[3][ic]}));
-  const C4 left = ghost_sel(wg, march_load(A, x - 1, y)), right = ghost_sel(wg, march_load(A, x + 1, y)),
-           up = ghost_sel(wg, march_load(A, x, y + 1)), top = ghost_sel(wg, march_load(A, x, A.H + 20));
+  const C4 left = ghost_sel(wg, march_load(A, x - 1, y, 0)), right = ghost_sel(wg, march_load(A, x + 1, y, 0)),
+           up = ghost_sel(wg, march_load(A, x, y + 1, 0)), top = ghost_sel(wg, march_load(A, x, A.H + 20, 0));
   out[0] = left.r; out[1] = left.mx; out[2] = right.r; out[3] = right.mx; out[4] = up.mx;     // k_test_neighbors
   out[5] = left.r; out[6] = left.mx; out[7] = up.mx; out[8] = top.r;                          // k_test_neighbor_for_diff
 }
@@ -989,8 +996,8 @@ static void h2_consts(tauh2 *h) {
 extern "C" int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, void *stream) {
   if (!out || !p) return tau::fail("tauh2_create: null argument");
   if (p->W < 8 || p->H < 8) return tau::fail("tauh2_create: grid must be at least 8x8");
-  if ((size_t)p->W * p->H * sizeof(float) > 0x7FFFFFFFull)   // the kernels address a field with 32-bit byte offsets
-    return tau::fail("tauh2_create: %d x %d cells are beyond the kernels' 32-bit field offsets", p->W, p->H);
+  if (p->W > (1 << 24))   // the kernels address their band of rows (<= 60) with 32-bit byte offsets
+    return tau::fail("tauh2_create: W = %d is beyond the kernels' 32-bit in-band offsets (2^24 columns)", p->W);
   if (!(p->gamma > 1.0)) return tau::fail("tauh2_create: gamma must be > 1");
   TAU_HIP(hipSetDevice(device));
   tauh2 *h = new (std::nothrow) tauh2();
@@ -1092,8 +1099,14 @@ static int h2_launch_step(tauh2 *h, float dt_explicit) {
     // 16 rows 46.7, 20: 46.3, 24: 45.8, 32: 45.2, 48: 42.8, 64: 38.8 Gcell/s (shorter chunks re-do 4 warm-up rows more often)
     int rows = (int)((long)A.H * nstrips / 16384);
     rows = rows < 8 ? 8 : (rows > 32 ? 32 : rows);
+    // a wave count just above a whole number of rounds of the 4096 resident waves leaves the chip nearly empty for a
+    // chunk's duration: 17-row chunks at 4096^2 are 4.06 rounds (48.5 Gcell/s), 16-row chunks 4.31 (49.7)
+    for (int k = 0; k < 2 && rows > 8; k++) {
+      const double rounds = (double)nstrips * ((A.H + rows - 1) / rows) / 4096.0;
+      if (rounds > 1.0 && rounds - (long)rounds < 0.2) rows--; else break;
+    }
     static const int rows_env = [] { const char *e = getenv("TAU_H2_ROWS"); return e ? atoi(e) : 0; }();
-    if (rows_env >= 1) rows = rows_env;
+    if (rows_env >= 1) rows = rows_env < 56 ? rows_env : 56;
     const int nchunks = (A.H + rows - 1) / rows;
     static const int lds_win = [] { const char *e = getenv("TAU_H2_LDSWIN"); return e ? atoi(e) : 1; }();   // the window in LDS (default) or in registers
     static const int wpb = [] { const char *e = getenv("TAU_H2_WPB"); return e ? atoi(e) : 1; }();   // one wave per workgroup: 49.2 against 48.2 Gcell/s with four (4096^2)
