@@ -192,6 +192,13 @@ __device__ __forceinline__ bool sdf_solid(const Args &A, int x, int y, int zg) {
 }
 
 __device__ __forceinline__ int wrapi(int i, int n) { i %= n; return (i < 0) ? i + n : i; }
+// the same for -n <= i < 2n without the integer division (~22 VALU instructions): k_flux_xy's rows, which overhang the
+// grid by at most a tile + the halo; `nearby` is a kernel-uniform flag (the row count covers that overhang)
+__device__ __forceinline__ int wrap_near(int i, int n, bool nearby) {
+  if (!nearby) return wrapi(i, n);
+  i = (i < 0) ? i + n : i;
+  return (i >= n) ? i - n : i;
+}
 
 // ---------------------------------------------------------------- WENO5, :534-558
 // The reference evaluates weno5_left(v0..v4) for the left state and weno5_left(v5..v1) for the
@@ -933,7 +940,8 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 
   const int x = bx0 + tx, y = by0 + ty;
   const bool in_xy = (x < A.nx) && (y < A.ny);
-  const int yw = wrapi(y, A.ny);
+  const bool ynear = A.ny >= YT + HALO;   // y in [-HALO, ny + YT + HALO): one conditional add / subtract wraps it
+  const int yw = wrap_near(y, A.ny, ynear);
   const int zh = z + HALO;
   const int zg = wrapi(A.z0 + z, A.nz);
   const int lc = (ty + HALO) * PXS + (tx + HALO);
@@ -965,7 +973,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
         lx = (c < HALO) ? c : c + XT;
       }
       const int gx = bx0 + lx - HALO;
-      const int gy = wrapi(by0 + ly - HALO, A.ny);
+      const int gy = wrap_near(by0 + ly - HALO, A.ny, ynear);
       bool sol;
       fetch_cell_q(A, qpl, fs4, spl, gx, gy, zg, q, sol);
       const int li = ly * PXS + lx;
