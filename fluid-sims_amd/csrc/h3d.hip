@@ -1229,28 +1229,44 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     const bool own_solid = (ws >> 2) & 1u;
 
     float Fz_hi[6];
-    float own[6];
+    float D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const char *const rb = (const char *)&ring[0][0][0];   // byte offsets: what ds_read takes, the variable's part as its immediate
+    auto rd = [&](int a, int m) { return *(const float *)(rb + a + m * (ZNT * 4)); };
+    const int t4 = tid * 4;
     {
       Prim L, R;
-      float hi[6];
 #pragma unroll
       for (int m = 0; m < 6; m++) L.q[m] = Lz[m];
       // one variable at a time (see k_flux_xy): the empty asm orders the next variable's LDS reads behind this one.  The
       // five slot addresses are formed once per plane and ride through the asm (tied to one lane index instead, they
       // were re-formed for every variable: 30 half-rate adds)
-      const char *const rb = (const char *)&ring[0][0][0];   // byte offsets: what ds_read takes, the variable's part as its immediate
-      auto rd = [&](int a, int m) { return *(const float *)(rb + a + m * (ZNT * 4)); };
-      const int t4 = tid * 4;
       int a0 = s0 * (24 * ZNT) + t4, a1 = s1 * (24 * ZNT) + t4, a2 = s2 * (24 * ZNT) + t4, a3 = s3 * (24 * ZNT) + t4,
           a4 = s4 * (24 * ZNT) + t4;
 #pragma unroll
       for (int m = 0; m < 6; m++) {
         const float w0 = rd(a0, m), w1 = rd(a1, m), w2 = rd(a2, m), w3 = rd(a3, m), w4 = rd(a4, m);
         weno_cell<FAST>(w0, w1, w2, w3, w4, Lz[m], R.q[m]);
-        own[m] = w1; hi[m] = w2;
         asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(Lz[m]), "+v"(R.q[m]));
       }
-      solid_override(L, R, own, hi, ws, 2);
+      // Latencies behind work: the next plane (loads issued at the top of the trip) has had the reconstruction to arrive
+      // and takes over slot s0, which nothing reads any more; its six registers then carry the x/y divergence of THIS
+      // plane, fetched behind the z face.  (Loaded right where the update needs it, every trip stalled a full HBM round
+      // trip: 3.9 cycles per instruction against 3.1 for the mix.)
+      if (more) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
+      }
+      if (in_xy && !own_solid) {
+        const unsigned vb = lane_off(vo);
+#pragma unroll
+        for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
+      }
+      if (ws != 0u) {   // rare: the cells either side of the face, from the ring
+        float lo[6], hi[6];
+#pragma unroll
+        for (int m = 0; m < 6; m++) { lo[m] = rd(s1 * (24 * ZNT) + t4, m); hi[m] = rd(s2 * (24 * ZNT) + t4, m); }
+        solid_override(L, R, lo, hi, ws, 2);
+      }
       prim_floor(L);
       prim_floor(R);
       Cons F = hllc(G, L, R, 2);
@@ -1258,15 +1274,11 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
     }
 
-    float D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (in_xy && !own_solid) {
-      const unsigned vb = lane_off(vo);
-#pragma unroll
-      for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
-    }
-
     if (in_xy) {
       float E[6], Qn[6];   // the cell's new encoded state and its decoded primitives
+      float own[6];        // the cell itself, back from the ring (carried from the reconstruction it cost six registers across the face)
+#pragma unroll
+      for (int m = 0; m < 6; m++) own[m] = rd(s1 * (24 * ZNT) + t4, m);
       if (own_solid) { // :1063-1072 copy-through
 #pragma unroll
         for (int m = 0; m < 6; m++) { E[m] = *(const GFloat *)(inB + m * fs4 + vo); Qn[m] = own[m]; }   // (rare path: plain addressing)
@@ -1359,9 +1371,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
     vo += plane4;
-    if (more) {   // plane z+4 replaces plane z-1; the window slides
-#pragma unroll
-      for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
+    if (more) {   // plane z+4 has replaced plane z-1; the window slides
       ws = (ws >> 1) | (nsol << 5);
       const int t = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = t;
     }
