@@ -1002,29 +1002,29 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 #pragma unroll
     for (int m = 0; m < 6; m++) S.sLxT[m][ty] = Lxo[m];
   }
-  const int wA = (int)((unsigned)z % (unsigned)XNW), wB = (wA + 1) % XNW, wC = (wA + 2) % XNW;
-  if (wave == wA && lane < XT + YT) { // low ring: left states of the cells at x = -1 and y = -1
-    const bool isx = lane < YT;
-    const int c0 = isx ? (lane + HALO) * PXS + (HALO - 1) : (HALO - 1) * PXS + (lane - YT + HALO);
+  const int wA = (int)((unsigned)z % (unsigned)XNW), wC = (wA + 2) % XNW;
+  // The ring: the cells at x = -1 and y = -1 give their LEFT states (of the tile's low faces), those at x = XT and y = YT
+  // their RIGHT states (of the far faces).  One lane per (ring cell, variable) — 2 x 48 cells x 6 variables = 576 tasks,
+  // one round of all eight waves and a 64-task remainder on one wave (rotating with the plane).  With one lane per ring
+  // cell and the six variables in sequence, two waves ran ~270 instructions each while the other six sat at the barrier.
+  constexpr int RING = XT + YT, RTASKS = 2 * 6 * RING;
+  static_assert(RTASKS > XNT && RTASKS - XNT <= 64, "ring tasks: one round of the workgroup + one wave");
+  auto ring_task = [&](int t) {
+    const int side = t >= 6 * RING ? 1 : 0;   // 0: low ring (left states), 1: high ring (right states)
+    const int r = t - side * (6 * RING);
+    const int m = r / RING, ln = r - m * RING;
+    const bool isx = ln < YT;
+    const int c0 = isx ? (ln + HALO) * PXS + (side ? XT + HALO : HALO - 1) : (side ? YT + HALO : HALO - 1) * PXS + (ln - YT + HALO);
     const int st = isx ? 1 : PXS;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      const float *p = &sP[m][c0];
-      const float v = weno_cell_side<FAST, true>(p[-2 * st], p[-st], p[0], p[st], p[2 * st]);
-      if (isx) S.sLx0[m][lane] = v; else S.sLy[m][0][lane - YT] = v;
-    }
-  }
-  if (wave == wB && lane < XT + YT) { // high ring: right states of the cells at x = XT and y = YT
-    const bool isx = lane < YT;
-    const int c0 = isx ? (lane + HALO) * PXS + (XT + HALO) : (YT + HALO) * PXS + (lane - YT + HALO);
-    const int st = isx ? 1 : PXS;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      const float *p = &sP[m][c0];
-      const float v = weno_cell_side<FAST, false>(p[-2 * st], p[-st], p[0], p[st], p[2 * st]);
-      if (isx) S.sRxT[m][lane] = v; else S.sRyT[m][lane - YT] = v;
-    }
-  }
+    const float *p = &sP[0][0] + m * XPLANE + c0;
+    float Lhi, Rlo;
+    weno_cell<FAST>(p[-2 * st], p[-st], p[0], p[st], p[2 * st], Lhi, Rlo);
+    float *dst = side ? (isx ? &S.sRxT[0][0] + m * YT + ln : &S.sRyT[0][0] + m * XT + (ln - YT))
+                      : (isx ? &S.sLx0[0][0] + m * YT + ln : &S.sLy[0][0][0] + m * ((YT + 1) * XT) + (ln - YT));
+    *dst = side ? Rlo : Lhi;
+  };
+  ring_task(tid);
+  if (wave == wA) ring_task(XNT + lane);
   __syncthreads();
 
   // ---- faces: low-x and low-y of the own cell; the tile's far faces
