@@ -528,8 +528,8 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
     const P4 qc = q3;
     const MCell l1 = lane_shift(w3, 1), r1 = lane_shift(w3, -1);
     // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried
-    P4 pl{tau::lane_dn(qc.r), tau::lane_dn(qc.u), tau::lane_dn(qc.v), tau::lane_dn(qc.p)};
-    P4 pr{tau::lane_up(qc.r), tau::lane_up(qc.u), tau::lane_up(qc.v), tau::lane_up(qc.p)};
+    P4 pl{__shfl_up(qc.r, 1, 64), __shfl_up(qc.u, 1, 64), __shfl_up(qc.v, 1, 64), __shfl_up(qc.p, 1, 64)};
+    P4 pr{__shfl_down(qc.r, 1, 64), __shfl_down(qc.u, 1, 64), __shfl_down(qc.v, 1, 64), __shfl_down(qc.p, 1, 64)};
     P4 pd = q2, pu = q4;
     if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | w4.m) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
       const C4 wg = wall_ghost(A, qc);
@@ -552,9 +552,9 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
 #endif
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     P4 xhi_l;
-    xhi_l.r = tau::lane_dn(xhi.r); xhi_l.u = tau::lane_dn(xhi.u); xhi_l.v = tau::lane_dn(xhi.v); xhi_l.p = tau::lane_dn(xhi.p);
+    xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
     const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
-    const C4 dFx_p{tau::lane_up(Fx.r) - Fx.r, tau::lane_up(Fx.mx) - Fx.mx, tau::lane_up(Fx.my) - Fx.my, tau::lane_up(Fx.E) - Fx.E};
+    const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my, __shfl_down(Fx.E, 1, 64) - Fx.E};
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
 #ifdef TAU_H2_SERIAL
     { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
@@ -687,9 +687,11 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
     const P4 qc = q3;
     const MCell w3 = R.get(s3, 0), l1 = R.get(s3, 1), r1 = R.get(s3, -1);
     const MCell w2 = R.get(s2, 0);
-    // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried
-    P4 pl{tau::lane_dn(qc.r), tau::lane_dn(qc.u), tau::lane_dn(qc.v), tau::lane_dn(qc.p)};
-    P4 pr{tau::lane_up(qc.r), tau::lane_up(qc.u), tau::lane_up(qc.v), tau::lane_up(qc.p)};
+    // the x neighbours' primitives come by lane shift too (they are the neighbours' own qc), the y neighbours' are carried.
+    // (ds_bpermute shuffles, not DPP moves: a DPP move is a half-rate VALU instruction and the kernel is short of VALU issue,
+    // not of LDS issue — 50.0 against 49.4 Gcell/s, and the same sign in the Burgers / LBM marches)
+    P4 pl{__shfl_up(qc.r, 1, 64), __shfl_up(qc.u, 1, 64), __shfl_up(qc.v, 1, 64), __shfl_up(qc.p, 1, 64)};
+    P4 pr{__shfl_down(qc.r, 1, 64), __shfl_down(qc.u, 1, 64), __shfl_down(qc.v, 1, 64), __shfl_down(qc.p, 1, 64)};
     P4 pd = q2, pu = q4;
     if (__builtin_amdgcn_ballot_w64(l1.m | r1.m | w2.m | m4) != 0ull) {   // a masked neighbour is seen as the wall ghost of the centre (rare: wave-uniform branch)
       const C4 wg = wall_ghost(A, qc);
@@ -720,9 +722,9 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
     C4 dFx_p{0.f, 0.f, 0.f, 0.f};
     if (row_x) {
       P4 xhi_l;
-      xhi_l.r = tau::lane_dn(xhi.r); xhi_l.u = tau::lane_dn(xhi.u); xhi_l.v = tau::lane_dn(xhi.v); xhi_l.p = tau::lane_dn(xhi.p);
+      xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
       const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
-      dFx_p = C4{tau::lane_up(Fx.r) - Fx.r, tau::lane_up(Fx.mx) - Fx.mx, tau::lane_up(Fx.my) - Fx.my, tau::lane_up(Fx.E) - Fx.E};
+      dFx_p = C4{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my, __shfl_down(Fx.E, 1, 64) - Fx.E};
     }
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
 #ifdef TAU_H2_SERIAL

@@ -249,7 +249,8 @@ __device__ __forceinline__ void weno_weights(float t0, float t1, float t2, float
 }
 
 // x faces of the own cells share weights across lanes (weno_face_xshare_r01 below, the fused kernel) and the split step's
-// k_flux_xy takes the left state of a face from the lane below: a DPP wave shift
+// k_flux_xy takes the left state of a face from the lane below: a DPP wave shift (k_flux_xy with ds_bpermute shuffles instead:
+// 4.04 against 3.85 ms — its LDS pipe is busy; the VALU-bound 2D marches with an idle LDS pipe prefer the shuffle)
 __device__ __forceinline__ float lane_below(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }

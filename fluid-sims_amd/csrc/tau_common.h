@@ -79,12 +79,5 @@ __device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
   *(GFloat *)(sbase + voff) = v;
 }
 __device__ __forceinline__ unsigned lane_off(unsigned v) { asm volatile("" : "+v"(v)); return v; }
-// the value of the lane below / above (lane 0 / 63: its own): one DPP move instead of the ds_bpermute __shfl_up / __shfl_down cost
-__device__ __forceinline__ float lane_dn(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
-}
-__device__ __forceinline__ float lane_up(float x) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
-}
 
 } // namespace tau
