@@ -373,6 +373,11 @@ def main():
                 out["cpu_baseline_2d_simd_all_cores"] = cpu_baseline_2d_all_cores()
             except Exception as e:  # the 2D CPU program is an extra, never fatal for the headline
                 out["cpu_baseline_2d_simd"] = {"error": str(e)}
+        try:   # RCCL's version banner (NCCL_DEBUG=VERSION on the GPU boxes) sits in the C stdio buffer until exit: push it out
+            import ctypes as _ct   # first, so that the JSON line is the LAST line of stdout
+            _ct.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
 
     if world > 1 or (args.force_slab and args.self_p2p):
