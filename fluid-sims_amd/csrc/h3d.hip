@@ -89,15 +89,12 @@ struct Args {
   float *out[6];
   const uint8_t *solid;      // halo layout, plane -3 first
   DevClock *clk;
-  // split step (k_flux_xy + k_update_z): decoded-primitive cache of the in / out state (same halo layout; always
-  // bitwise decode() of the encoded arrays) and the x/y flux divergence of the local planes (no halo)
-  const float *q[6];
-  float *qo[6];
+  // split step (k_flux_xy + k_update_z): the x/y flux divergence of the local planes (no halo)
   float *dxy[6];
   float *send[2];            // Z-slab ring: packed send buffers the step writes its new boundary planes into (or null)
   // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
-  const float *in0, *q0;
-  float *out0, *qo0;
+  const float *in0;
+  float *out0;
   const float *d0;
   unsigned fstride, dstride; // floats
   int nx, ny, nz;            // global
@@ -550,15 +547,15 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
   for (int m = 0; m < 6; m++) q[m] = p.q[m];
 }
 
-// one field of decode(): what the primitive cache holds for encoded value e of field m
+// one field of decode(): the primitive the encoded value e of field m stands for
 __device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
   return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
 }
 using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::lane_off;   // tau_common.h: scalar base + 32-bit lane offset
 
-// fetch_cell on the primitive cache (no transcendental work).  qpl: field 0 of the cache at plane zh; fs4: bytes between
-// fields; spl: the solid mask at plane zh
-__device__ __forceinline__ void fetch_cell_q(const Args &A, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
+// fetch_cell through a scalar plane base.  epl: field 0 of the encoded state at plane zh; fs4: bytes between fields; spl:
+// the solid mask at plane zh
+__device__ __forceinline__ void fetch_cell_e(const Args &A, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
                                              int zg, float (&q)[6], bool &sol) {
   Prim p;
   if (gx < 0) {
@@ -567,13 +564,13 @@ __device__ __forceinline__ void fetch_cell_q(const Args &A, const GChar *qpl, si
   } else if (gx >= A.nx) {
     const unsigned vo = lane_off((unsigned)(gyw * A.nx + (A.nx - 1)) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = gld(qpl + m * fs4, vo);
+    for (int m = 0; m < 6; m++) p.q[m] = decode_field(A.u_ref, m, gld(qpl + m * fs4, vo));
     p = outflow_prim(A, p);
     sol = sdf_solid(A, gx, gyw, zg);
   } else {
     const unsigned vo = lane_off((unsigned)(gyw * A.nx + gx) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = gld(qpl + m * fs4, vo);
+    for (int m = 0; m < 6; m++) p.q[m] = decode_field(A.u_ref, m, gld(qpl + m * fs4, vo));
     sol = spl[vo >> 2] != 0;
   }
 #pragma unroll
@@ -890,13 +887,13 @@ __global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
 // cycles (profiles/r02/valu_calib.txt), so three resident waves only just cover a ~2.3-cycle pipe and every stall of
 // one of them is lost issue time (measured: 4.0 cycles per instruction against ~3.1 for the instruction mix).
 // The split trades HBM traffic, of which this VALU-bound step uses a tenth, for occupancy:
-//   k_flux_xy   one plane per workgroup, no z dependence at all (so it needs no z halo): stage the tile + x/y halo of
-//               the PRIMITIVE CACHE in LDS, every x / y face once, write the x/y flux divergence (6 floats per cell);
-//   k_update_z  one column per lane, no LDS, no barrier: the z window in registers, every z face once, add the x/y
-//               divergence, update, re-encode, and write the new state AND its decoded primitives.
-// The primitive cache q is bitwise decode() of the encoded state wherever a kernel reads it (k_update_z decodes what
-// it has just encoded; uploads, init and halo refreshes run decode_field on what they wrote), so results are the
-// fused kernel's; what disappears is the exp / sinh work of decoding every cell ~2.7 times per step.
+//   k_flux_xy   one plane per workgroup, no z dependence at all (so it needs no z halo): stage the tile + x/y halo,
+//               decoded on load, in LDS, every x / y face once, write the x/y flux divergence (6 floats per cell);
+//   k_update_z  one column per lane, no barrier: the z window (decoded on load) in a private LDS ring, every z face
+//               once, add the x/y divergence, update, re-encode, write the new state.
+// Both decode the encoded state where they load it (1.6 + 1 decodes per cell and step; the fused kernel: 2.7).  A cache
+// of the decoded primitives beside the state (written by k_update_z, read by both) was measured: it saves k_flux_xy
+// 4 % but costs k_update_z, which is HBM-bound at ~5 TB/s, 24 of its 97 bytes per cell — 2.67 against 2.35 ms.
 #ifndef TAU3D_XY_TY
 #define TAU3D_XY_TY 16
 #endif
@@ -948,13 +945,13 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   const int lc = (ty + HALO) * PXS + (tx + HALO);
 
   const size_t plane_n = (size_t)A.nx * A.ny;
-  const GChar *const qpl = (const GChar *)(A.q0 + (size_t)zh * plane_n);
+  const GChar *const qpl = (const GChar *)(A.in0 + (size_t)zh * plane_n);
   const uint8_t *const spl = A.solid + (size_t)zh * plane_n;
   const size_t fs4 = (size_t)A.fstride << 2;
   bool own_solid;
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
-    fetch_cell_q(A, qpl, fs4, spl, x, yw, zg, q, own_solid);
+    fetch_cell_e(A, qpl, fs4, spl, x, yw, zg, q, own_solid);
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     sS[lc] = own_solid ? 1 : 0;
@@ -976,7 +973,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
       const int gx = bx0 + lx - HALO;
       const int gy = wrap_near(by0 + ly - HALO, A.ny, ynear);
       bool sol;
-      fetch_cell_q(A, qpl, fs4, spl, gx, gy, zg, q, sol);
+      fetch_cell_e(A, qpl, fs4, spl, gx, gy, zg, q, sol);
       const int li = ly * PXS + lx;
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
@@ -1157,13 +1154,13 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const unsigned plane4 = (unsigned)plane_n << 2;
   const unsigned col4 = (unsigned)col << 2;
   const size_t fs4 = (size_t)A.fstride << 2, ds4 = (size_t)A.dstride << 2;
-  const GChar *const qP = (const GChar *)(A.q0 + (size_t)zc_lo * plane_n);               // halo-layout plane zc_lo-3
+  const GChar *const qP = (const GChar *)(A.in0 + (size_t)zc_lo * plane_n);              // halo-layout plane zc_lo-3
   const uint8_t *const solP = A.solid + (size_t)zc_lo * plane_n;
   unsigned ws = 0;
   auto load_own = [&](int k, float (&dst)[6]) -> unsigned {   // plane zc_lo-3+k
     const unsigned vo = col4 + (unsigned)k * plane4;
 #pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = *(const GFloat *)(qP + m * fs4 + vo);
+    for (int m = 0; m < 6; m++) dst[m] = decode_field(A.u_ref, m, *(const GFloat *)(qP + m * fs4 + vo));
     return solP[vo >> 2] != 0 ? 1u : 0u;
   };
 
@@ -1214,7 +1211,6 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const uint8_t *const solN = solP + 7 * plane_n;
   const GChar *const inB = (const GChar *)(A.in0 + (size_t)(zc_lo + HALO) * plane_n);      // plane z, halo layout
   GChar *const outB = (GChar *)(A.out0 + (size_t)(zc_lo + HALO) * plane_n);
-  GChar *const qoB = (GChar *)(A.qo0 + (size_t)(zc_lo + HALO) * plane_n);
   const GChar *const dB = (const GChar *)(A.d0 + (size_t)zc_lo * plane_n);                 // plane z, no halo
   unsigned vo = col4;
 
@@ -1224,7 +1220,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     asm volatile("" : "+s"(f4), "+s"(d4));
     if (more) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) Nx[m] = gld(qN + m * f4, vo);
+      for (int m = 0; m < 6; m++) Nx[m] = decode_field(A.u_ref, m, gld(qN + m * f4, vo));
       nsol = solN[vo >> 2] != 0 ? 1u : 0u;
     }
     const bool own_solid = (ws >> 2) & 1u;
@@ -1276,13 +1272,13 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     }
 
     if (in_xy) {
-      float E[6], Qn[6];   // the cell's new encoded state and its decoded primitives
+      float E[6];          // the cell's new encoded state
       float own[6];        // the cell itself, back from the ring (carried from the reconstruction it cost six registers across the face)
 #pragma unroll
       for (int m = 0; m < 6; m++) own[m] = rd(s1 * (24 * ZNT) + t4, m);
       if (own_solid) { // :1063-1072 copy-through
 #pragma unroll
-        for (int m = 0; m < 6; m++) { E[m] = *(const GFloat *)(inB + m * fs4 + vo); Qn[m] = own[m]; }   // (rare path: plain addressing)
+        for (int m = 0; m < 6; m++) E[m] = *(const GFloat *)(inB + m * fs4 + vo);   // (rare path: plain addressing)
       } else {
         const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
         float U0[6];
@@ -1347,13 +1343,11 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         E[3] = fasinh(w1 * A.inv_u_ref);
         E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
         E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
-#pragma unroll
-        for (int m = 0; m < 6; m++) Qn[m] = decode_field(A.u_ref, m, E[m]);
       }
       {
         const unsigned vb = lane_off(vo);
 #pragma unroll
-        for (int m = 0; m < 6; m++) { gst(outB + m * f4, vb, E[m]); gst(qoB + m * f4, vb, Qn[m]); }
+        for (int m = 0; m < 6; m++) gst(outB + m * f4, vb, E[m]);
       }
       // Z-slab ring: the first / last three local planes of the NEW state go straight into the packed send buffers
       // (what k_halo_pack would copy afterwards): wave-uniform branch, one dispatch less per step
@@ -1393,15 +1387,6 @@ __global__ __launch_bounds__(ZNT, 5) void k_update_z(const Args A) {   // 5 wave
   __shared__ ZRing ring;
   if (fast_form(A.clk->fmax_in, A.in_fmax)) update_z_body<true>(A, ring);
   else update_z_body<false>(A, ring);
-}
-
-// primitive cache of planes [zh_lo, zh_hi) of the halo layout from the encoded arrays (after init / upload / a halo refresh)
-__global__ __launch_bounds__(256) void k_decode_planes(Args A, int zh_lo, int zh_hi) {
-  const size_t n0 = (size_t)A.nx * A.ny * zh_lo, n1 = (size_t)A.nx * A.ny * zh_hi;
-  for (size_t i = n0 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n1; i += (size_t)gridDim.x * blockDim.x) {
-#pragma unroll
-    for (int m = 0; m < 6; m++) A.qo[m][i] = decode_field(A.u_ref, m, A.in[m][i]);
-  }
 }
 
 // ---------------------------------------------------------------- small kernels
@@ -1453,7 +1438,7 @@ __device__ __forceinline__ void clock_end(DevClock *c) { // d_tau controller, :1
 // The single-domain step loop folds the two 1-thread clock kernels into the halo copy that precedes every k_step
 // (controller of the step before, then the clock of this one): two dependent dispatches per step instead of four,
 // which is what a 64^3 run is made of (clk == nullptr: plain halo copy).
-struct HaloArgs { float *f[12]; size_t plane_n; int nzl; DevClock *clk; int do_end; };   // 6 encoded fields (+ 6 of the primitive cache)
+struct HaloArgs { float *f[6]; size_t plane_n; int nzl; DevClock *clk; int do_end; };
 __global__ void k_halo_periodic(HaloArgs H) {
   if (H.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (H.do_end) clock_end(H.clk);
@@ -1469,7 +1454,7 @@ __global__ void k_halo_periodic(HaloArgs H) {
 }
 
 // packed halo exchange: boundary planes of 6 fields <-> one contiguous buffer per side
-struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; float *q[6]; float u_ref; DevClock *clk; int do_end; };   // q: primitive cache to refresh on unpack (or null); clk: also run the controller / clock (tau3d_slab_begin_async)
+struct PackArgs { float *f[6]; float *buf[2]; size_t plane_n; int nzl; DevClock *clk; int do_end; };   // clk: also run the controller / clock (tau3d_slab_begin_async)
 // dir 0: pack (send side s <- first / last 3 interior planes); dir 1: unpack (recv side s -> halo planes)
 __global__ void k_halo_pack(PackArgs P, int dir) {
   if (P.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {   // as k_halo_periodic does for the single domain
@@ -1482,21 +1467,14 @@ __global__ void k_halo_pack(PackArgs P, int dir) {
   float *b = P.buf[side] + (size_t)f * n3;
   float *planes = dir == 0 ? (side == 0 ? fld + (size_t)HALO * P.plane_n : fld + (size_t)P.nzl * P.plane_n)
                            : (side == 0 ? fld : fld + (size_t)(P.nzl + HALO) * P.plane_n);
-  float *qpl = (dir == 1 && P.q[f]) ? (side == 0 ? P.q[f] : P.q[f] + (size_t)(P.nzl + HALO) * P.plane_n) : nullptr;
   for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n3; i += (size_t)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n3) {
       if (dir == 0) *reinterpret_cast<float4 *>(b + i) = *reinterpret_cast<const float4 *>(planes + i);
-      else {
-        const float4 v = *reinterpret_cast<const float4 *>(b + i);
-        *reinterpret_cast<float4 *>(planes + i) = v;
-        if (qpl)
-          *reinterpret_cast<float4 *>(qpl + i) = make_float4(decode_field(P.u_ref, f, v.x), decode_field(P.u_ref, f, v.y),
-                                                             decode_field(P.u_ref, f, v.z), decode_field(P.u_ref, f, v.w));
-      }
+      else *reinterpret_cast<float4 *>(planes + i) = *reinterpret_cast<const float4 *>(b + i);
     } else {
       for (size_t k = i; k < n3; k++) {
         if (dir == 0) b[k] = planes[k];
-        else { planes[k] = b[k]; if (qpl) qpl[k] = decode_field(P.u_ref, f, b[k]); }
+        else planes[k] = b[k];
       }
     }
   }
@@ -1688,7 +1666,6 @@ struct tau3d {
   size_t plane_n, field_n;  // floats per plane, floats per field incl. halo
   size_t field_stride, dxy_stride;   // floats between consecutive fields of one allocation (state / cache; x/y divergence)
   float *buf[2][6];         // ping-pong, halo layout
-  float *qbuf[2][6];        // split step: primitive cache of buf (same layout), bitwise decode() of it
   float *dxy[6];            // split step: x/y flux divergence of the local planes
   bool split;               // step = k_flux_xy + k_update_z (else the fused k_step)
   uint8_t *solid;
@@ -1790,11 +1767,6 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     TAU_HIP(hipMalloc(&h->buf[s][0], 6 * h->field_stride * sizeof(float)));
     TAU_HIP(hipMemsetAsync(h->buf[s][0], 0, 6 * h->field_stride * sizeof(float), h->stream));
     for (int f = 1; f < 6; f++) h->buf[s][f] = h->buf[s][0] + f * h->field_stride;
-    if (h->split) {
-      TAU_HIP(hipMalloc(&h->qbuf[s][0], 6 * h->field_stride * sizeof(float)));
-      TAU_HIP(hipMemsetAsync(h->qbuf[s][0], 0, 6 * h->field_stride * sizeof(float), h->stream));
-      for (int f = 1; f < 6; f++) h->qbuf[s][f] = h->qbuf[s][0] + f * h->field_stride;
-    }
   }
   if (h->split) {
     TAU_HIP(hipMalloc(&h->dxy[0], 6 * h->dxy_stride * sizeof(float)));
@@ -1829,7 +1801,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipSetDevice(h->device);
   hipStreamSynchronize(h->stream);
   for (int s = 0; s < 2; s++)
-    { hipFree(h->buf[s][0]); hipFree(h->qbuf[s][0]); }
+    hipFree(h->buf[s][0]);
   hipFree(h->dxy[0]);
   hipFree(h->solid);
   hipFree(h->clk);
@@ -1868,11 +1840,6 @@ static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
   for (int f = 0; f < 6; f++) a.in[f] = h->buf[h->cur][f];
   hipLaunchKernelGGL(h3d::k_field_max, dim3(1024), dim3(256), 0, h->stream, a, zl_lo + h3d::HALO, zl_hi + h3d::HALO);
   TAU_LAUNCH_CHECK("k_field_max");
-  if (h->split) { // ... and their primitive cache
-    for (int f = 0; f < 6; f++) a.qo[f] = h->qbuf[h->cur][f];
-    hipLaunchKernelGGL(h3d::k_decode_planes, dim3(2048), dim3(256), 0, h->stream, a, zl_lo + h3d::HALO, zl_hi + h3d::HALO);
-    TAU_LAUNCH_CHECK("k_decode_planes");
-  }
   return 0;
 }
 
@@ -1967,9 +1934,9 @@ static int flush_clock(tau3d_t *h) { // the deferred k_clock_end of tau3d_step_a
 static int fill_halo(tau3d_t *h, bool with_clock) {
   h3d::HaloArgs H;
   H.clk = with_clock ? h->clk : nullptr; H.do_end = h->end_pending ? 1 : 0;
-  for (int f = 0; f < 6; f++) { H.f[f] = h->buf[h->cur][f]; H.f[6 + f] = h->split ? h->qbuf[h->cur][f] : nullptr; }
+  for (int f = 0; f < 6; f++) H.f[f] = h->buf[h->cur][f];
   H.plane_n = h->plane_n; H.nzl = h->nzl;
-  hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, h->split ? 24 : 12), dim3(256), 0, h->stream, H);
+  hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, 12), dim3(256), 0, h->stream, H);
   TAU_LAUNCH_CHECK("k_halo_periodic");
   if (with_clock) h->end_pending = false;
   return 0;
@@ -1980,12 +1947,11 @@ extern "C" int tau3d_fill_halo_periodic_async(tau3d_t *h) { return fill_halo(h, 
 static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi2) {
   A = h->base;
   for (int f = 0; f < 6; f++) {
-    A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f];
-    A.q[f] = h->qbuf[h->cur][f]; A.qo[f] = h->qbuf[h->cur ^ 1][f]; A.dxy[f] = h->dxy[f];
+    A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; A.dxy[f] = h->dxy[f];
   }
   A.zl_lo = lo; A.zl_hi = hi; A.zl_lo2 = lo2; A.zl_hi2 = hi2;
   A.send[0] = A.send[1] = nullptr;
-  A.in0 = h->buf[h->cur][0]; A.out0 = h->buf[h->cur ^ 1][0]; A.q0 = h->qbuf[h->cur][0]; A.qo0 = h->qbuf[h->cur ^ 1][0];
+  A.in0 = h->buf[h->cur][0]; A.out0 = h->buf[h->cur ^ 1][0];
   A.d0 = h->dxy[0]; A.fstride = (unsigned)h->field_stride; A.dstride = (unsigned)h->dxy_stride;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s) {   // x/y faces: one plane per workgroup
@@ -2224,8 +2190,7 @@ static int halo_pack(tau3d_t *h, int which, int dir, bool with_clock) {
   if (with_clock) h->end_pending = false;
   for (int f = 0; f < 6; f++) P.f[f] = h->buf[h->cur ^ (which & 1)][f];
   P.buf[0] = h->xbuf[dir][0]; P.buf[1] = h->xbuf[dir][1];
-  P.plane_n = h->plane_n; P.nzl = h->nzl; P.u_ref = h->p.u_ref;
-  for (int f = 0; f < 6; f++) P.q[f] = (h->split && dir == 1) ? h->qbuf[h->cur ^ (which & 1)][f] : nullptr;
+  P.plane_n = h->plane_n; P.nzl = h->nzl;
   hipLaunchKernelGGL(h3d::k_halo_pack, dim3(32, 12), dim3(256), 0, h->stream, P, dir);
   TAU_LAUNCH_CHECK("k_halo_pack");
   return 0;

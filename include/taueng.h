@@ -118,8 +118,8 @@ int tau3d_fill_halo_periodic_async(tau3d_t *h);
 /* side 0 = low-z, 1 = high-z; which = 0 current (input) state, 1 = next (output) state.
  * send: first/last 3 INTERIOR planes; recv: the halo planes.  Each is 3*ny*nx floats. */
 /* (A caller that fills halo planes through tau3d_halo_recv_ptr itself — instead of the packed buffers and
- * tau3d_unpack_halos_async / tau3d_slab_begin_async, which also refresh the handle's decoded-primitive cache of those
- * planes — must call tau3d_state_written before the next step.) */
+ * tau3d_unpack_halos_async / tau3d_slab_begin_async — must call tau3d_state_written before the next step, so that the
+ * field range the WENO weight form depends on covers what it wrote.) */
 int tau3d_halo_send_ptr(tau3d_t *h, int which, int field, int side, float **p);
 int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p);
 /* Packed exchange buffers: 6 fields x 3 planes contiguous, one send and one recv buffer per side, so
