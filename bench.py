@@ -333,9 +333,9 @@ def main():
                 "per_gpu": world > 1,                                     # N > 1: rank 0's slab (its cells / its kernel time)
                 "kernels": ([{"name": "h3d::k_flux_xy", "avg_launch_ms": round(xy_ms / n_split, 4)},
                              {"name": "h3d::k_update_z", "avg_launch_ms": round(z_ms / n_split, 4)}] if n_split else None),
-                "note": "the step is FP32-VALU bound (WENO5 + HLLC, ~2.25 k VALU instructions per cell at ~3.4 cycles each against a "
-                        "~2.3-cycle full-rate issue, profiles/r02/valu_calib.txt); the HBM fraction is reported because "
-                        "BASELINE.json's metric asks for it"}
+                "note": "the step is FP32-VALU bound (WENO5 + HLLC, ~2.16 k VALU instructions per 64 cells at ~3.3 cycles each against "
+                        "a ~2.3-cycle full-rate issue and a ~3.0-cycle floor for the instruction mix, profiles/r02/valu_calib.txt, "
+                        "pmc_sq.txt); the HBM fraction is reported because BASELINE.json's metric asks for it"}
         out = {"metric": "Gcell-updates/s, 3D hypersonic 512^3 fp32", "value": round(value, 4),
                "unit": "Gcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
