@@ -921,7 +921,10 @@ __device__ __forceinline__ float lane_above(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
 }
 
-template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S) {
+// what k_flux_xy knows about its cell when the x / y faces are done (core / store split: the core also served the
+// small-grid experiment of DESIGN §4.1's tried-list)
+struct XyCell { float d[6]; bool in_xy, own_solid; int x, yw, z, lc; };
+template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A, XyLds &S, XyCell &C) {
   auto &sP = S.sP; auto &sS = S.sS;
   const int tid = threadIdx.x;
   const int tx = tid & (XT - 1), ty = tid >> 5;
@@ -1093,19 +1096,23 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   __syncthreads();
 
   // ---- x/y flux divergence of the own cell
-  GChar *const dpl = (GChar *)(A.d0 + (size_t)z * plane_n);
-  const size_t ds4 = (size_t)A.dstride << 2;
-  float d[6];
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     const float up = lane_above(Fx[m]);
     const float fxh = (tx == XT - 1) ? S.sFxT[m][ty] : up;
-    d[m] = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
+    C.d[m] = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
   }
-  if (in_xy && !own_solid) {
-    const unsigned vo = lane_off((unsigned)(yw * A.nx + x) << 2);
+  C.in_xy = in_xy; C.own_solid = own_solid; C.x = x; C.yw = yw; C.z = z; C.lc = lc;
+}
+template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S) {
+  XyCell C;
+  flux_xy_core<FAST>(A, S, C);
+  if (C.in_xy && !C.own_solid) {
+    GChar *const dpl = (GChar *)(A.d0 + (size_t)C.z * ((size_t)A.nx * A.ny));
+    const size_t ds4 = (size_t)A.dstride << 2;
+    const unsigned vo = lane_off((unsigned)(C.yw * A.nx + C.x) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) gst(dpl + m * ds4, vo, d[m]);
+    for (int m = 0; m < 6; m++) gst(dpl + m * ds4, vo, C.d[m]);
   }
 }
 
@@ -1116,6 +1123,77 @@ __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyLds S;
   if (fast_form(A.clk->fmax_in, A.in_fmax)) flux_xy_body<true>(A, S);
   else flux_xy_body<false>(A, S);
+}
+
+// The update of one fluid cell, :1266-1358: conservative update from the x/y divergence D and the two z-face fluxes,
+// repairs, Landau-Teller relaxation, sponges, the max-wavespeed / max-|primitive| contributions, re-encoding.  One
+// function (k_update_z; a one-plane-per-workgroup kernel for small grids that shared it was measured and dropped).
+__device__ __forceinline__ void update_cell(const Args &A, const float (&own)[6], const float (&D)[6], const float (&Fz_lo)[6],
+                                            const float (&Fz_hi)[6], float dt, float inv_dz, float gain, int x, float (&E)[6],
+                                            float &smax, float &fmx) {
+  const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
+  float U0[6];
+  U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
+  {
+    float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
+    float eth = p0 * rcp(fmaxf(A.gm1 * r0, RHO_P_FLOOR));
+    U0[4] = r0 * (ke + eth + e0);
+    U0[5] = r0 * e0;
+  }
+  float U1[6];
+#pragma unroll
+  for (int m = 0; m < 6; m++) {
+    float dU = -(D[m] + (Fz_hi[m] - Fz_lo[m]) * inv_dz);
+    U1[m] = U0[m] + dU * dt;
+  }
+  float r1 = fmaxf(U1[0], RHO_P_FLOOR);
+  float ir1 = rcp(r1);
+  float u1 = U1[1] * ir1, v1 = U1[2] * ir1, w1 = U1[3] * ir1;
+  float ke = 0.5f * (u1 * u1 + v1 * v1 + w1 * w1);
+  float ev1 = fmaxf(U1[5] * ir1, 0.f);
+  float e_th = fmaxf(U1[4] * ir1 - ke - ev1, THERMAL_ENERGY_FLOOR);
+  float p1 = fmaxf(A.gm1 * r1 * e_th, RHO_P_FLOOR);
+  const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
+                     __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
+                   r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
+  if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; }
+  float T1 = p1 * rcp(r1 * A.R);
+  ev1 = fmaxf(ev1 + (evib_eq(A, T1) - ev1) * (dt * A.inv_tau_vib), 0.f);
+
+  if (A.sponge_n > 0 && x < A.sponge_n) {
+    float s = 1.0f - (float)x / (float)A.sponge_n;
+    s = fminf(fmaxf(s, 0.0f), 1.0f);
+    float k = A.sponge_strength * (s * s);
+    r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
+    p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
+    u1 = u1 + k * (gain * A.in_u - u1);
+    v1 = v1 + k * (gain * A.in_v - v1);
+    w1 = w1 + k * (gain * A.in_w - w1);
+    ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+  }
+  if (A.sponge_out_n > 0 && x >= (A.nx - A.sponge_out_n)) {
+    int xo2 = x - (A.nx - A.sponge_out_n);
+    float s = (float)xo2 / (float)A.sponge_out_n;
+    s = fminf(fmaxf(s, 0.0f), 1.0f);
+    float k = A.sponge_out_strength * (s * s);
+    r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
+    p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
+    u1 = u1 + k * (0.0f - u1);
+    v1 = v1 + k * (0.0f - v1);
+    w1 = w1 + k * (0.0f - w1);
+    ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+  }
+  float a = soundspeed(A, p1, r1);
+  float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
+  if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
+  fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
+
+  E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
+  E[1] = fasinh(u1 * A.inv_u_ref);
+  E[2] = fasinh(v1 * A.inv_u_ref);
+  E[3] = fasinh(w1 * A.inv_u_ref);
+  E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
+  E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
 }
 
 // k_update_z: a wave owns 64 consecutive x of one row and marches a chunk of planes; ZT_Y rows per workgroup.
@@ -1280,69 +1358,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #pragma unroll
         for (int m = 0; m < 6; m++) E[m] = *(const GFloat *)(inB + m * fs4 + vo);   // (rare path: plain addressing)
       } else {
-        const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
-        float U0[6];
-        U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
-        {
-          float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
-          float eth = p0 * rcp(fmaxf(A.gm1 * r0, RHO_P_FLOOR));
-          U0[4] = r0 * (ke + eth + e0);
-          U0[5] = r0 * e0;
-        }
-        float U1[6];
-#pragma unroll
-        for (int m = 0; m < 6; m++) {
-          float dU = -(D[m] + (Fz_hi[m] - Fz_lo[m]) * inv_dz);
-          U1[m] = U0[m] + dU * dt;
-        }
-        float r1 = fmaxf(U1[0], RHO_P_FLOOR);
-        float ir1 = rcp(r1);
-        float u1 = U1[1] * ir1, v1 = U1[2] * ir1, w1 = U1[3] * ir1;
-        float ke = 0.5f * (u1 * u1 + v1 * v1 + w1 * w1);
-        float ev1 = fmaxf(U1[5] * ir1, 0.f);
-        float e_th = fmaxf(U1[4] * ir1 - ke - ev1, THERMAL_ENERGY_FLOOR);
-        float p1 = fmaxf(A.gm1 * r1 * e_th, RHO_P_FLOOR);
-        const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
-                           __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
-                         r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
-        if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; }
-        float T1 = p1 * rcp(r1 * A.R);
-        ev1 = fmaxf(ev1 + (evib_eq(A, T1) - ev1) * (dt * A.inv_tau_vib), 0.f);
-
-        if (A.sponge_n > 0 && x < A.sponge_n) {
-          float s = 1.0f - (float)x / (float)A.sponge_n;
-          s = fminf(fmaxf(s, 0.0f), 1.0f);
-          float k = A.sponge_strength * (s * s);
-          r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
-          p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
-          u1 = u1 + k * (gain * A.in_u - u1);
-          v1 = v1 + k * (gain * A.in_v - v1);
-          w1 = w1 + k * (gain * A.in_w - w1);
-          ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
-        }
-        if (A.sponge_out_n > 0 && x >= (A.nx - A.sponge_out_n)) {
-          int xo2 = x - (A.nx - A.sponge_out_n);
-          float s = (float)xo2 / (float)A.sponge_out_n;
-          s = fminf(fmaxf(s, 0.0f), 1.0f);
-          float k = A.sponge_out_strength * (s * s);
-          r1 = fmaxf(r1 + k * (A.in_r - r1), RHO_P_FLOOR);
-          p1 = fmaxf(p1 + k * (A.in_p - p1), RHO_P_FLOOR);
-          u1 = u1 + k * (0.0f - u1);
-          v1 = v1 + k * (0.0f - v1);
-          w1 = w1 + k * (0.0f - w1);
-          ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
-        }
-        float a = soundspeed(A, p1, r1);
-        float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
-        if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
-        fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
-
-        E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
-        E[1] = fasinh(u1 * A.inv_u_ref);
-        E[2] = fasinh(v1 * A.inv_u_ref);
-        E[3] = fasinh(w1 * A.inv_u_ref);
-        E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
-        E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
+        update_cell(A, own, D, Fz_lo, Fz_hi, dt, inv_dz, gain, x, E, smax, fmx);
       }
       {
         const unsigned vb = lane_off(vo);
