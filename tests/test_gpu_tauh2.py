@@ -165,6 +165,27 @@ def test_marching_step_agrees_with_the_tile_step(eng, tmp_path, W, H, steps):
         assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= 2e-5 * scale, k
 
 
+def test_march_is_the_same_for_every_workgroup_size(eng, tmp_path):
+    """the waves of the marching kernel share nothing, so its workgroup size (TAU_H2_WPB = 1 / 2 / 4 waves, a dispatch
+    granularity knob) must not change a bit; 2100 x 1100 runs the march by default, with chunks whose first rows are far
+    from row 0 (the loads / stores are 32-bit offsets from each chunk's first row)"""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import fluid_sims_amd as f, numpy as np\n"
+            "h = f.Hypersonic2D(2100, 1100); h.init(); t = h.step(25)\n"
+            "st = h.download(); np.savez(sys.argv[1], *st, t=np.float64(t if t is not None else 0.0))\n" % root)
+    outs = []
+    for wpb in ("1", "2", "4"):
+        out = tmp_path / f"w{wpb}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], capture_output=True, text=True, env=dict(os.environ, TAU_H2_WPB=wpb))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.load(out))
+    for o in outs[1:]:
+        assert float(o["t"]) == float(outs[0]["t"])
+        for k in ("arr_0", "arr_1", "arr_2", "arr_3"):
+            assert np.array_equal(o[k], outs[0][k]), k
+
+
 def test_neighbor_lookups_on_the_reference_field(eng):
     """The nine known answers of the reference's neighbour tests (tau_hypersonic_cuda_tests.cu:348-371, 567-640: inflow at
     x < 0, fluid neighbour, NO-SLIP reflection mx 3 -> -3 at a body cell, clamped y) evaluated by the engine's own staging
