@@ -356,3 +356,30 @@ np.save(sys.argv[1], np.stack(e.download()))
     print("split vs fused after 12 steps:", {k: f"{v:.1e}" for k, v in r.items()})
     for k in ("xi", "phix", "phiy", "phiz", "rho", "mx", "E"):
         assert r[k] <= 2e-5, (k, r[k])          # 12 steps of accumulated rounding between two legal groupings
+
+
+def test_split_step_is_the_same_for_every_chunk_length():
+    """k_update_z's chunk length (TAU3D_ZCHUNK planes per workgroup) only decides which workgroup computes a plane: every
+    chunk addresses its planes as 32-bit offsets from its own first plane and primes its own ring, so the state after
+    several steps must not change by a bit — odd lengths, a length that does not divide nz, one chunk for everything."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.getcwd())
+import fluid_sims_amd as f
+e = f.Tau3D(160, 136, 40); e.init(1); e.set_clock(0.02, 1e-4); e.step(6)
+np.save(sys.argv[1], np.stack(e.download()))
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for zc in ("0", "1", "7", "16", "40"):
+        path = os.path.join("/tmp", f"tau3d_zc{zc}.npy")
+        env = dict(os.environ, TAU3D_SPLIT="1", TAU3D_ZCHUNK=zc)
+        subprocess.run([sys.executable, "-c", code, path], check=True, cwd=root, env=env)
+        outs.append(np.load(path))
+    assert np.isfinite(outs[0]).all()
+    for o in outs[1:]:
+        assert np.array_equal(o, outs[0])
