@@ -1096,11 +1096,12 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   __syncthreads();
 
   // ---- x/y flux divergence of the own cell
+  const float inv_dx = vreg(A.inv_dx), inv_dy = vreg(A.inv_dy);   // twelve uses: SGPR operands would make them half rate
 #pragma unroll
   for (int m = 0; m < 6; m++) {
     const float up = lane_above(Fx[m]);
     const float fxh = (tx == XT - 1) ? S.sFxT[m][ty] : up;
-    C.d[m] = (fxh - Fx[m]) * A.inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * A.inv_dy;
+    C.d[m] = (fxh - Fx[m]) * inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * inv_dy;
   }
   C.in_xy = in_xy; C.own_solid = own_solid; C.x = x; C.yw = yw; C.z = z; C.lc = lc;
 }
