@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py — headline benchmark: Gcell-updates/s of the 3D hypersonic step on a 512^3 fp32 grid.
 
-  python bench.py --gpus N --steps K --warmup W          (N = 1)
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (N > 1)
+  python bench.py --gpus N --steps K --warmup W          (any N: for N > 1 it re-launches itself under
+                                                           torch.distributed.run, one rank per GPU)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the same, launched from outside)
 
 A "step" is one full time step of the reference loop (tau_hypersonic_3d_cuda.cu:1680-1711: log-time
 clock, k_step over the whole grid, d_tau controller, swap) on synthetic input already resident in
@@ -13,7 +14,10 @@ controller has settled, then exactly K timed steps bracketed by barrier + device
 N > 1: the SAME 512^3 grid is Z-slab partitioned over the ranks (strong scaling, as BASELINE.json's
 metric states: "512^3 at 1/2/4/8 MI355X"); per step each rank exchanges 3 boundary planes x 6 fields
 with both ring neighbours (RCCL send/recv over xGMI, overlapped with the interior planes) and one
-8-byte all-reduce(max) (max wavespeed + max |primitive|) feeds the device-side d_tau controller.
+8-byte all-reduce(max) (max wavespeed + max |primitive|) feeds the device-side d_tau controller.  The ring
+is the library's (tau3d_ring_*, csrc/ring.hip: librccl called from C on a private stream); torch.distributed
+only provides the launch, the barrier and the max-over-ranks of the contract.  --ring-driver python selects the
+older torch.distributed ring of fluid-sims_amd/slab.py instead.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` and `cpu_baseline`; at N = 1 the
 line also carries `configs`: the other four BASELINE.json configurations (2D Euler 4096^2, Gray-Scott 8192^2,
@@ -101,26 +105,26 @@ def cpu_baseline_2d_all_cores(steps=60, n=300):
                       f"{steps} steps each, {el:.2f} s"}
 
 
-def input_variants(f, n, steps=6):
+def input_variants(f, torch, dev, n, steps=20):
     """SURVEY §8d asks for two more inputs beside the headline one: (i) the reference's own quiescent k_init
-    start after 50 controller warm-up steps, and a no-body variant that bounds the branch-free throughput."""
+    start after 50 controller warm-up steps, and a no-body variant that bounds the branch-free throughput.
+    Event-timed on the handle's stream, `steps` steps each."""
     out = {}
+    stream = torch.cuda.Stream(dev)
+    sp = ctypes.c_void_p(stream.cuda_stream)
     for name, mode, warm, body in (("reference_ic_50_warmup", 0, 50, True), ("developed_no_body", 1, 10, False)):
         p = f.Tau3DParams()
         f.load().tau3d_params_default(ctypes.byref(p), n, n, n)
         if not body:
             p.sdf_r = -1.0
-        e = f.Tau3D(n, n, n, params=p)
+        e = f.Tau3D(n, n, n, params=p, stream=sp)
         e.init(mode)
         if mode:
             e.set_clock(0.02, 1e-4)
         e.step_async(warm)
-        e.sync()
-        t0 = time.perf_counter()
-        e.step_async(steps)
-        e.sync()
-        el = time.perf_counter() - t0
-        out[name] = {"value": round(float(n) ** 3 * steps / el / 1e9, 3), "unit": "Gcell-updates/s", "steps": steps, "warmup": warm}
+        ms = _event_timed(torch, stream, lambda: e.step_async(steps), e.sync)
+        out[name] = {"value": round(float(n) ** 3 * steps / ms / 1e6, 3), "unit": "Gcell-updates/s", "steps": steps, "warmup": warm,
+                     "timing": "HIP events on the handle's stream"}
         e.close()
     return out
 
@@ -174,15 +178,13 @@ def other_configs(f, torch, dev):
     ms = _event_timed(torch, stream, lambda: g.step_async(1000), g.sync)
     out.append({"config": f"tau_gray_scott {n}x{n}, 4 time levels per pass (default)", "steps": 1000, "warmup": 40,
                 "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
-                "roofline": _roof("st2::k_fused<GS,4> (one launch = 4 steps)", ms / 250, 4 * n * n, 16, "valu + hbm",
-                                  "16 B per update is the single-step algorithmic figure; a 4-level pass moves ~4.6 B per "
-                                  "update (profiles/r01i), so frac > 1 is traffic removed, not bandwidth exceeded")})
-
-    def single():
-        for _ in range(1000):
-            g.step_async(1)
-    ms = _event_timed(torch, stream, single, g.sync)
-    out.append({"config": f"tau_gray_scott {n}x{n}, one step per launch", "steps": 1000, "warmup": 0,
+                "roofline": _roof("st2::k_fused<GS,4> (one launch = 4 steps)", ms / 250, n * n, 16, "valu + hbm",
+                                  "per LAUNCH: the compulsory traffic of a pass is one read and one write of u, v (16 B per cell) "
+                                  "whatever the number of time levels it advances; per cell-update the pass moves a quarter of that")})
+    g.set_levels(1)                                  # the reference's structure: one launch per step (bit-identical results)
+    g.step_async(8)
+    ms = _event_timed(torch, stream, lambda: g.step_async(1000), g.sync)   # ONE call: 1000 launches enqueued back to back
+    out.append({"config": f"tau_gray_scott {n}x{n}, one step per launch", "steps": 1000, "warmup": 8,
                 "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
                 "roofline": _roof("st2::k_march<GS>", ms / 1000, n * n, 16, "hbm")})
     g.close()
@@ -216,6 +218,27 @@ def other_configs(f, torch, dev):
     return out
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _self_spawn(n):
+    """--gpus N without a launcher: run this very command under torch.distributed.run, one rank per GPU.  Whether the node
+    has N devices is checked INSIDE the ranks (each says what it sees), not here."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL's intra-node transport needs it on these hosts
+    env.setdefault("NCCL_DEBUG", "VERSION")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,11 +249,18 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the two extra SURVEY 8d inputs (reference IC, no body)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configs (2D Euler, Gray-Scott, SPH, CPU)")
     ap.add_argument("--force-slab", action="store_true",
-                    help="run the Z-slab ring driver even on one GPU (self-neighbour halo copies): exercises the N>1 code path")
+                    help="run the Z-slab ring even on one GPU (self-neighbour halo copies): exercises the N>1 code path")
     ap.add_argument("--self-p2p", action="store_true",
                     help="with --force-slab on one GPU: exchange the halos with OURSELVES through RCCL send/recv and all-reduce the "
-                         "max words (a world-of-one process group) instead of device copies")
+                         "max words (a communicator of one) instead of device copies")
+    ap.add_argument("--ring-driver", choices=("c", "python"), default="c",
+                    help="c: the library's ring (tau3d_ring_*, librccl called from C); python: fluid-sims_amd/slab.py over torch.distributed")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(_self_spawn(args.gpus))
 
     import numpy as np
     import torch
@@ -240,14 +270,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: drop the launcher (bench.py spawns its own ranks) or make them agree")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (libtaueng has no CPU path)")
+    ndev = torch.cuda.device_count()
+    if ndev < world:
+        raise SystemExit(f"bench.py --gpus {world}: rank {rank} sees {ndev} device(s); the Z-slab ring needs {world} devices, "
+                         f"one MI355X per rank")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     n = args.n
-    if world > 1 or (args.force_slab and args.self_p2p):
+    use_ring = world > 1 or args.force_slab
+    py_ring = use_ring and args.ring_driver == "python"
+    need_pg = world > 1 or (py_ring and args.self_p2p)
+    if need_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29581")
@@ -255,13 +292,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    from importlib import import_module
-    slab = import_module("fluid_sims_amd.slab")
 
     L = f.load()
     params = f.Tau3DParams()
     L.tau3d_params_default(ctypes.byref(params), n, n, n)
-    z0, nzl = slab.slab_bounds(n, world, rank)
+    z0, nzl = f.slab_bounds(n, world, rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -269,14 +304,18 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if world == 1 and not args.force_slab:
+    ring_info = None
+    if not use_ring:
         eng = f.Tau3D(n, n, n, params=params, device=local)
         eng.init(1)
         eng.set_clock(0.02, 1e-4)
         step = lambda k: eng.step_async(k)          # noqa: E731
         sync = eng.sync
+        get_clock = eng.clock
         h = eng
-    else:
+    elif py_ring:
+        from importlib import import_module
+        slab = import_module("fluid_sims_amd.slab")
         be = slab.EngineSlabBackend(f.taueng, params, z0, nzl, local)
         be.h.init(1)
         be.h.set_clock(0.02, 1e-4)
@@ -284,7 +323,28 @@ def main():
         ring.prime()
         step = lambda k: ring.step(k)               # noqa: E731
         sync = ring.finish
+        get_clock = be.h.clock
         h = be.h
+        ring_info = {"driver": "python (torch.distributed batch_isend_irecv + all_reduce)"}
+    else:
+        # the library's ring: every rank passes the same rendezvous path and job key (agreed through torch.distributed)
+        key = torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.broadcast(key, 0)
+        key = int(key.item())
+        eng = f.Tau3D(n, n, n, params=params, z0=z0, nzl=nzl, device=local)
+        eng.init(1)
+        eng.set_clock(0.02, 1e-4)
+        transport = f.RING_RCCL if (world > 1 or args.self_p2p) else f.RING_LOCAL
+        ring = f.Tau3DRing(eng, rank, world, transport, rendezvous=f"/dev/shm/tau3d_bench_{key & 0xffffffffff:x}" if world > 1 else None,
+                           job_key=key)
+        ring.prime()
+        step = lambda k: ring.step(k)               # noqa: E731
+        sync = ring.finish
+        get_clock = ring.clock
+        h = eng
+        ring_info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)",
+                         transport={f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies"}[transport])
 
     step(args.warmup)
     sync()
@@ -298,13 +358,19 @@ def main():
     k_ms, k_launches, k_cells = h.timing_read()
     xy_ms, z_ms, n_split = h.timing_read_split()
     h.timing_enable(False)
+    is_split = h.is_split()
 
+    per_rank_ms = None
     if world > 1:
         tmax = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
+        km = torch.zeros(world, dtype=torch.float64, device=dev)
+        km[rank] = k_ms / max(args.steps, 1)
+        dist.all_reduce(km, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 4) for x in km.tolist()]
 
-    clk = h.clock()
+    clk = get_clock()
     cells_total = float(n) ** 3 * args.steps
     value = cells_total / el / 1e9
 
@@ -314,43 +380,61 @@ def main():
         # it is the PMC figure of the committed profile (profiles/k_step_traffic.json names the passes it came from).
         k_s = k_ms * 1e-3
         achieved = ALGO_BYTES_PER_CELL * k_cells / k_s / 1e9 if k_s > 0 else 0.0
-        traffic, tsrc = None, None
+        traffic, tsrc, valu = None, None, None
         tpath = os.path.join(ROOT, "profiles", "k_step_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic, tsrc = tj.get("hbm_bytes_per_launch"), tj.get("source")
+                valu = tj.get("valu")
             except Exception:
                 traffic = None
-        split = n * n >= 128 * 128 and os.environ.get("TAU3D_SPLIT", "1") != "0"
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "traffic_source": f"profile-derived, not this run: {tsrc}" if traffic else None,
-                "kernel": "h3d::k_flux_xy + h3d::k_update_z (one step = the pair)" if split else "h3d::k_step",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic if n == 512 and world == 1 else None,
+                "traffic_source": f"profile-derived, not this run: {tsrc}" if traffic and n == 512 and world == 1 else None,
+                "kernel": "h3d::k_flux_xy + h3d::k_update_z (one step = the pair)" if is_split else "h3d::k_step",
                 "launches": args.steps, "event_intervals": k_launches,   # a Z-slab step is two timed intervals (edges, interior)
                 "avg_launch_ms": round(k_ms / max(args.steps, 1), 4),    # kernel time of ONE step on this GPU (rank 0)
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(args.steps, 1),
                 "per_gpu": world > 1,                                     # N > 1: rank 0's slab (its cells / its kernel time)
                 "kernels": ([{"name": "h3d::k_flux_xy", "avg_launch_ms": round(xy_ms / n_split, 4)},
                              {"name": "h3d::k_update_z", "avg_launch_ms": round(z_ms / n_split, 4)}] if n_split else None),
-                "note": "the step is FP32-VALU bound (WENO5 + HLLC, ~2.16 k VALU instructions per 64 cells at ~3.3 cycles each against "
-                        "a ~2.3-cycle full-rate issue and a ~3.0-cycle floor for the instruction mix, profiles/r02/valu_calib.txt, "
-                        "pmc_sq.txt); the HBM fraction is reported because BASELINE.json's metric asks for it"}
+                "note": "the step is FP32-VALU bound (WENO5 + HLLC); the HBM fraction is reported because BASELINE.json's metric asks "
+                        "for it, the VALU block beside it says how close the step is to the bound that binds"}
+        if per_rank_ms:
+            roof["per_rank_kernel_ms_per_step"] = per_rank_ms
+        if valu and n == 512 and k_s > 0:
+            # second bound: wave-instructions issued per step (SQ_INSTS_VALU of the committed PMC pass) against what the chip
+            # issues in the measured kernel time: 256 CUs x 4 SIMDs, one wave64 FMA-pipe instruction per 2 cycles
+            insts = float(valu["sq_insts_valu_per_step"]) * (k_cells / max(args.steps, 1)) / float(n) ** 3
+            clock_ghz = float(valu.get("clock_ghz", 2.4))
+            peak = 256 * 4 * clock_ghz * 1e9 / 2.0
+            ach = insts / (k_s / max(args.steps, 1))
+            out_valu = {"bound": "valu", "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
+                        "frac": round(ach / peak, 4), "cycles_per_instr": round(256 * 4 * clock_ghz * 1e9 / ach, 3),
+                        "source": f"instruction count profile-derived ({valu.get('source')}), time from this run's events; "
+                                  f"peak = 1024 SIMDs x {clock_ghz} GHz / 2 cycles per wave64 instruction"}
+        else:
+            out_valu = None
         out = {"metric": "Gcell-updates/s, 3D hypersonic 512^3 fp32", "value": round(value, 4),
                "unit": "Gcell-updates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"tau_hypersonic_3d {n}^3 fp32, sphere r=0.25, Mach-100 inflow, "
                                       f"developed-flow start (SURVEY 8d input ii)",
-                          "grid": [n, n, n], "decomposition": f"z-slab x{world}" if world > 1 else "single domain",
+                          "grid": [n, n, n], "decomposition": f"z-slab x{world}" if use_ring else "single domain",
                           "halo_planes": 3, "t": clk.t, "d_tau": clk.d_tau, "maxs": clk.maxs},
                "roofline": roof}
-        if world == 1 and not args.no_variants and not args.force_slab:
+        if out_valu:
+            out["roofline_valu"] = out_valu
+        if ring_info:
+            out["ring"] = ring_info
+        if world == 1 and not args.no_variants and not use_ring:
             try:
-                out["other_inputs"] = input_variants(f, n)
+                out["other_inputs"] = input_variants(f, torch, dev, n)
             except Exception as e:  # extras never take the headline down
                 out["other_inputs"] = {"error": str(e)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not use_ring:
             planes = 8
             zc = n // 2 - 40 if n >= 128 else 0
             planes = min(planes, n)
@@ -358,21 +442,26 @@ def main():
             h.sync()
             st = h.download_planes(zc - 3, zc + planes + 3)
             cpu_sample = ([np.ascontiguousarray(a) for a in st], clk.dt, zc, planes)
-        if world == 1 and not args.no_configs and not args.force_slab:
-            h.close()                                      # the 512^3 state (20 GB with the primitive cache) is not needed below
+        if world == 1 and not args.no_configs and not use_ring:
+            h.close()                                      # the 512^3 state is not needed below
             h = None
             try:
                 out["configs"] = other_configs(f, torch, dev)
             except Exception as e:  # extras never take the headline down
                 out["configs"] = [{"error": str(e)}]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(n, *cpu_sample)
+        if world == 1 and not args.no_cpu_baseline and not use_ring:
+            # north_star names tau_hypersonic_simd.c as the CPU baseline: the restated program (fluid-sims_amd/cpu/), 300^2 as
+            # shipped, one thread.  The 3D oracle on a slab of the headline state — the same workload — is kept beside it.
             try:
-                out["cpu_baseline_2d_simd"] = cpu_baseline_2d()
+                out["cpu_baseline"] = cpu_baseline_2d()
                 out["cpu_baseline_2d_simd_256"] = cpu_baseline_2d(n=256)      # BASELINE config 1 size
                 out["cpu_baseline_2d_simd_all_cores"] = cpu_baseline_2d_all_cores()
-            except Exception as e:  # the 2D CPU program is an extra, never fatal for the headline
-                out["cpu_baseline_2d_simd"] = {"error": str(e)}
+            except Exception as e:
+                out["cpu_baseline"] = {"error": str(e)}
+            try:
+                out["cpu_baseline_3d_oracle"] = cpu_baseline(n, *cpu_sample)
+            except Exception as e:
+                out["cpu_baseline_3d_oracle"] = {"error": str(e)}
         try:   # RCCL's version banner (NCCL_DEBUG=VERSION on the GPU boxes) sits in the C stdio buffer until exit: push it out
             import ctypes as _ct   # first, so that the JSON line is the LAST line of stdout
             _ct.CDLL(None).fflush(None)
@@ -380,7 +469,9 @@ def main():
             pass
         print(json.dumps(out), flush=True)
 
-    if world > 1 or (args.force_slab and args.self_p2p):
+    if use_ring and not py_ring:
+        ring.close()
+    if need_pg:
         dist.destroy_process_group()
 
 

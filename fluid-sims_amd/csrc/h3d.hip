@@ -1892,11 +1892,10 @@ extern "C" int tau3d_upload_state(tau3d_t *h, const float *const host[6]) {
   for (int f = 0; f < 6; f++)
     TAU_HIP(hipMemcpyAsync(h->buf[h->cur][f] + h3d::HALO * h->plane_n, host[f], n * sizeof(float),
                            hipMemcpyHostToDevice, h->stream));
-  // The whole local state was replaced: its range is what these planes hold.  The halo planes are not measured — every
-  // step refreshes them before it reads them (periodic fill / unpack), from planes that were (a ring all-reduces the
-  // range) — so what they held before does not matter, and a create -> upload -> step caller gets the fast weight form
-  // like one that called tau3d_init first.
-  if (measure_field(h, 0, h->nzl, true)) return 1;
+  // The local planes were replaced: the range is re-measured over them AND the halo planes (defined since tau3d_create
+  // zeroed them; an earlier tau3d_upload_planes may have put values there that the next step reads before any exchange).
+  // A ring all-reduces the range when it primes.
+  if (measure_field(h, -h3d::HALO, h->nzl + h3d::HALO, true)) return 1;
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -2011,6 +2010,7 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
   if (zl_lo < 0 || zl_hi > h->nzl || zl_lo >= zl_hi) return tau::fail("tau3d_step_range: bad plane range [%d,%d)", zl_lo, zl_hi);
   const bool two = zl_lo2 < zl_hi2;
   if (two && (zl_lo2 < zl_hi || zl_hi2 > h->nzl)) return tau::fail("tau3d_step_edges: bad second range [%d,%d)", zl_lo2, zl_hi2);
+  TAU_HIP(hipSetDevice(h->device));
   h3d::Args A = h->base;
   for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
@@ -2134,6 +2134,7 @@ extern "C" int tau3d_slab_edges_async(tau3d_t *h, int depth) {
 }
 extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
   if (2 * depth >= h->nzl) return 0;
+  TAU_HIP(hipSetDevice(h->device));
   return slab_timed(h, h->nzl - 2 * depth, slab_interior_body, depth);
 }
 extern "C" int tau3d_slab_end_async(tau3d_t *h) {
@@ -2236,6 +2237,16 @@ extern "C" int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max
   if (fast_form) *fast_form = h3d::fast_form(c.fmax_in, h->base.in_fmax) ? 1 : 0;
   return 0;
 }
+extern "C" int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *device, void **stream) {
+  if (!h) return tau::fail("tau3d_slab_info: null handle");
+  if (z0) *z0 = h->z0;
+  if (nzl) *nzl = h->nzl;
+  if (nz) *nz = h->p.nz;
+  if (device) *device = h->device;
+  if (stream) *stream = (void *)h->stream;
+  return 0;
+}
+extern "C" int tau3d_is_split(tau3d_t *h) { return h && h->split ? 1 : 0; }
 extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {
   *p = reinterpret_cast<float *>(&h->clk->maxs_bits);
   return 0;

@@ -326,6 +326,7 @@ struct Pair {
   int nx, ny;
   float *buf[2][2];
   int cur;
+  int levels = 0;   // time levels per pass: 0 = the default (TAU_ST2_LEVELS, 4), 1 = one launch per step, 2..4
 };
 
 static int pair_create(Pair *h, int nx, int ny, int device, void *stream) {
@@ -370,7 +371,8 @@ template <int KIND>
 static int run_steps(Pair *pr, Args A, int nsteps) {
   static const bool fuse_env = !(getenv("TAU_ST2_FUSE") && atoi(getenv("TAU_ST2_FUSE")) == 0);
   static const int frows = getenv("TAU_ST2_FROWS") ? atoi(getenv("TAU_ST2_FROWS")) : 32;
-  static const int kmax = getenv("TAU_ST2_LEVELS") ? atoi(getenv("TAU_ST2_LEVELS")) : 4;
+  static const int kmax_env = getenv("TAU_ST2_LEVELS") ? atoi(getenv("TAU_ST2_LEVELS")) : 4;
+  const int kmax = pr->levels > 0 ? pr->levels : kmax_env;
   const bool fuse = fuse_env && kmax >= 2 && kmax <= 4 && (A.nx & 3) == 0 && A.nx >= 8 && A.ny >= 2;
   static const int bfast = getenv("TAU_ST2_BURGERS_FAST") ? atoi(getenv("TAU_ST2_BURGERS_FAST")) : 0;
   A.burgers_fast = bfast;
@@ -484,6 +486,11 @@ extern "C" int taugs_step_async(taugs_t *h, int nsteps) {
 extern "C" int taugs_sync(taugs_t *h) {
   TAU_HIP(hipSetDevice(h->pr.device));
   TAU_HIP(hipStreamSynchronize(h->pr.stream));
+  return 0;
+}
+extern "C" int taugs_set_levels(taugs_t *h, int levels) {
+  if (!h || levels < 0 || levels > 4) return tau::fail("taugs_set_levels: levels must be 0 (default), 1 (one launch per step) or 2..4");
+  h->pr.levels = levels;
   return 0;
 }
 extern "C" int taugs_step(taugs_t *h, int nsteps) {

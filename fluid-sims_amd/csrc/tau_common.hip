@@ -25,3 +25,9 @@ extern "C" int tau_device_available(void) {
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
+extern "C" int tau_device_count(int *n) {
+  if (!n) return tau::fail("tau_device_count: null argument");
+  *n = 0;
+  TAU_HIP(hipGetDeviceCount(n));
+  return 0;
+}

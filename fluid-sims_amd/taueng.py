@@ -147,6 +147,16 @@ def load():
         "tau3d_palette_indices": ([vp, f32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "tau3d_field_range": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)], i32),
         "tau3d_sync": ([vp], i32),
+        "tau_device_count": ([C.POINTER(i32)], i32),
+        "tau3d_slab_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)], i32),
+        "tau3d_is_split": ([vp], i32),
+        "tau3d_slab_bounds": ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
+        "tau3d_ring_create": ([C.POINTER(vp), vp, i32, i32, i32, C.c_char_p, C.c_uint64], i32),
+        "tau3d_ring_destroy": ([vp], None),
+        "tau3d_ring_prime": ([vp], i32), "tau3d_ring_invalidate": ([vp], i32),
+        "tau3d_ring_step_async": ([vp, i32], i32), "tau3d_ring_finish": ([vp], i32),
+        "tau3d_ring_get_clock": ([vp, C.POINTER(Tau3DClock)], i32), "tau3d_ring_barrier": ([vp], i32),
+        "tau3d_ring_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t], i32),
         "tau3d_vis": ([vp, i32, vp], i32),
         "tau3d_vis_async": ([vp, i32, vp], i32),
         "tau3d_slice_rgba": ([vp, i32, i32, f32, vp, C.POINTER(f32), C.POINTER(f32)], i32),
@@ -222,6 +232,7 @@ def load():
         "taugs_step": ([vp, i32], i32),
         "taugs_step_async": ([vp, i32], i32),
         "taugs_sync": ([vp], i32),
+        "taugs_set_levels": ([vp, i32], i32),
         "taulap_create": ([C.POINTER(vp), C.POINTER(LapParams), i32, i32, i32, vp], i32),
         "taulap_destroy": ([vp], None),
         "taulap_upload": ([vp, vp, vp], i32),
@@ -258,6 +269,63 @@ def _require_device():
 def _f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a
+
+
+RING_RCCL, RING_HOST, RING_LOCAL = 0, 1, 2
+
+
+def slab_bounds(nz, world, rank):
+    """tau3d_slab_bounds: (z0, nzl) of rank's contiguous Z-slab"""
+    z0, nzl = C.c_int(), C.c_int()
+    _ck(load().tau3d_slab_bounds(nz, world, rank, C.byref(z0), C.byref(nzl)))
+    return z0.value, nzl.value
+
+
+class Tau3DRing:
+    """tau3d_ring_*: the Z-slab ring inside the library (csrc/ring.hip) around one slab handle `eng` (a Tau3D created
+    with this rank's z0 / nzl).  transport: RING_RCCL (librccl, one device per rank), RING_HOST (staged through the
+    rendezvous file, ranks may share a device), RING_LOCAL (world 1, device copies)."""
+
+    def __init__(self, eng, rank, world, transport=RING_RCCL, rendezvous=None, job_key=0):
+        self._L = eng._L
+        self.eng = eng
+        self._r = C.c_void_p()
+        rv = rendezvous.encode() if rendezvous else None
+        _ck(self._L.tau3d_ring_create(C.byref(self._r), eng._h, rank, world, transport, rv, job_key))
+
+    def close(self):
+        if getattr(self, "_r", None):
+            self._L.tau3d_ring_destroy(self._r)
+            self._r = None
+
+    __del__ = close
+
+    def prime(self):
+        _ck(self._L.tau3d_ring_prime(self._r))
+
+    def invalidate(self):
+        _ck(self._L.tau3d_ring_invalidate(self._r))
+
+    def step(self, n=1):
+        _ck(self._L.tau3d_ring_step_async(self._r, n))
+        return self
+
+    def finish(self):
+        _ck(self._L.tau3d_ring_finish(self._r))
+
+    def barrier(self):
+        _ck(self._L.tau3d_ring_barrier(self._r))
+
+    def clock(self):
+        c = Tau3DClock()
+        _ck(self._L.tau3d_ring_get_clock(self._r, C.byref(c)))
+        return c
+
+    def info(self):
+        ver, ranks, edge = C.c_int(), C.c_int(), C.c_int()
+        lib = C.create_string_buffer(512)
+        _ck(self._L.tau3d_ring_info(self._r, C.byref(ver), C.byref(ranks), C.byref(edge), lib, 512))
+        return {"rccl_version": ver.value, "comm_ranks": ranks.value, "edge_planes": edge.value, "librccl": lib.value.decode()}
 
 
 class Tau3D:
@@ -412,6 +480,10 @@ class Tau3D:
 
     def sync(self):
         _ck(self._L.tau3d_sync(self._h))
+
+    def is_split(self):
+        """True if a step of this handle is the kernel pair k_flux_xy + k_update_z (else the fused k_step)"""
+        return bool(self._L.tau3d_is_split(self._h))
 
     VIS_MODES = ("schlieren_rho", "log_rho", "log_p", "speed", "mach", "vort_mag", "div", "q_criterion")
 
@@ -773,6 +845,10 @@ class GrayScott:
 
     def step_async(self, n=1):
         _ck(self._L.taugs_step_async(self._h, n))
+
+    def set_levels(self, levels):
+        """time levels per launch: 0 default (4 fused), 1 one launch per step, 2..4"""
+        _ck(self._L.taugs_set_levels(self._h, levels))
 
     def sync(self):
         _ck(self._L.taugs_sync(self._h))

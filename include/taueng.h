@@ -31,6 +31,8 @@ extern "C" {
 const char *tau_last_error(void);
 /* 1 if a gfx950 device is visible to the HIP runtime, else 0 (never fails) */
 int tau_device_available(void);
+/* number of devices the HIP runtime shows (0 with an error text when there is no runtime / no device) */
+int tau_device_count(int *n);
 int tau_version(void);
 
 /* =====================================================================
@@ -141,6 +143,38 @@ int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast
  * here before the next step (tau3d_init / tau3d_upload_* do it themselves). */
 int tau3d_state_written(tau3d_t *h);
 int tau3d_sync(tau3d_t *h);
+/* what the handle was created with: its slab [z0, z0+nzl) of the global nz, its device and the stream its work runs on */
+int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *device, void **stream);
+/* 1 if a step of this handle is the kernel pair k_flux_xy + k_update_z, 0 if the fused k_step */
+int tau3d_is_split(tau3d_t *h);
+
+/* ---- The Z-slab ring, in the library (csrc/ring.hip): one process per GPU, each owning one slab handle; the ring adds
+ * the halo exchange with both z neighbours and the all-reduce(max) of the two words of tau3d_max_ptr, issued from C on a
+ * private stream beside the handle's — replaces, for N GPUs, the loop body tau_hypersonic_3d_cuda.cu:1678-1713 (the
+ * reference is single-GPU: SURVEY §8e).  Per step: slab_begin, slab_edges(E), [exchange posted], slab_interior(E)
+ * overlapping it, [all-reduce], slab_end — enqueued without any host synchronisation.
+ *   transport  TAU3D_RING_RCCL  ncclSend / ncclRecv / ncclAllReduce (librccl bound at run time; world 1 talks to itself)
+ *              TAU3D_RING_HOST  staged through the rendezvous file by the host (ranks may share a device; tests, fallback)
+ *              TAU3D_RING_LOCAL world 1: device copies, no collective
+ *   rendezvous path of a file rank 0 creates and the others map (ncclUniqueId, barrier, staging); every rank of a job
+ *              passes the same path and job_key, a later job a different key.  May be NULL when world == 1. */
+enum { TAU3D_RING_RCCL = 0, TAU3D_RING_HOST = 1, TAU3D_RING_LOCAL = 2 };
+typedef struct tau3d_ring tau3d_ring_t;
+/* contiguous split of nz planes over `world` ranks (every slab needs >= 6 planes) */
+int tau3d_slab_bounds(int nz, int world, int rank, int *z0, int *nzl);
+int tau3d_ring_create(tau3d_ring_t **out, tau3d_t *h, int rank, int world, int transport, const char *rendezvous, uint64_t job_key);
+void tau3d_ring_destroy(tau3d_ring_t *r);          /* does not destroy the slab handle */
+/* exchange the halos of the current state and agree on its field range; tau3d_ring_step_async does it itself after
+ * create / tau3d_ring_invalidate (call that after tau3d_init / tau3d_upload_* on the handle) */
+int tau3d_ring_prime(tau3d_ring_t *r);
+int tau3d_ring_invalidate(tau3d_ring_t *r);
+int tau3d_ring_step_async(tau3d_ring_t *r, int nsteps);
+int tau3d_ring_finish(tau3d_ring_t *r);            /* waits for both streams */
+int tau3d_ring_get_clock(tau3d_ring_t *r, tau3d_clock *out);
+int tau3d_ring_barrier(tau3d_ring_t *r);           /* host barrier over the ranks (through the rendezvous file) */
+/* RCCL's version (ncclGetVersion), the rank count of the communicator (ncclCommCount), planes per edge launch, the
+ * librccl the ring bound to; any pointer may be NULL */
+int tau3d_ring_info(tau3d_ring_t *r, int *rccl_version, int *comm_ranks, int *edge_planes, char *lib_path, size_t lib_path_len);
 
 /* The export path of th3cs.cu (:1193-1222): the volume of the last tau3d_vis — th3cs uses mode 0, its
  * k_schlieren_export (:641-673) is that field — mapped to 8-bit palette indices,
@@ -251,6 +285,9 @@ int taugs_download(taugs_t *h, float *u, float *v);
 int taugs_state_ptrs(taugs_t *h, float **u, float **v);
 int taugs_step(taugs_t *h, int nsteps);                                    /* :321-329 */
 int taugs_step_async(taugs_t *h, int nsteps);
+/* time levels per launch: 0 = default (four levels fused per pass, the remainder as single steps), 1 = one launch per
+ * step (the reference's structure, :321-329), 2..4.  The results are bit-identical either way. */
+int taugs_set_levels(taugs_t *h, int levels);
 int taugs_sync(taugs_t *h);
 
 /* =====================================================================

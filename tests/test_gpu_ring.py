@@ -1,0 +1,109 @@
+"""GPU: the Z-slab ring INSIDE the library (csrc/ring.hip, tau3d_ring_*) and the plain-C driver `tau3d --gpus N`.
+
+The GPU box has one device.  What runs here:
+  * `bin/tau3d --gpus N --transport host`: N forked ranks sharing the device, halos staged through the shared rendezvous
+    file — the ring's ordering (prime, begin / edges / exchange / interior / all-reduce / end, events between the two
+    streams), the rendezvous and the per-rank dump are the production code; only the transport differs from RCCL;
+  * the RCCL transport with a communicator of one (ncclSend / ncclRecv to itself + ncclAllReduce), from C and from Python;
+  * `--gpus 2` over RCCL on this one-device box fails from INSIDE the ranks with a clear message.
+All results must be bit-identical to the single-domain run (same kernels, same inputs: SURVEY §8e fixture iv)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAU3D = os.path.join(ROOT, "bin", "tau3d")
+
+
+def run(*args, **kw):
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("TAU3D_RING_TIMEOUT", "60")
+    return subprocess.run(list(args), capture_output=True, text=True, cwd=ROOT, env=env, timeout=600, **kw)
+
+
+def dump_of(tmp_path, name, *flags):
+    path = str(tmp_path / name)
+    r = run(TAU3D, *flags, "--dump", path)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return open(path, "rb").read(), r.stdout
+
+
+SHAPES = [((32, 32, 64), 6), ((64, 48, 40), 5),
+          ((160, 128, 48), 3)]      # planes >= 128^2: the split step (k_flux_xy + k_update_z), with an interior piece at world 2
+
+
+@pytest.mark.parametrize("shape,frames", SHAPES)
+def test_tau3d_host_ring_is_bit_identical(eng, tmp_path, shape, frames):
+    nx, ny, nz = shape
+    grid = ["--nx", str(nx), "--ny", str(ny), "--nz", str(nz), "--frames", str(frames), "--start", "1"]
+    want, _ = dump_of(tmp_path, "single.bin", *grid)
+    assert len(want) > 6 * 4 * nx * ny * nz
+    for world in (2, 3, 4, 8):
+        if nz // world < 6:
+            continue
+        got, out = dump_of(tmp_path, f"w{world}.bin", *grid, "--gpus", str(world), "--transport", "host")
+        assert f"ring: {world} ranks, host-staged transport" in out
+        assert got == want, f"world {world}: dump differs from the single-domain run"
+
+
+def test_tau3d_rccl_self_ring_is_bit_identical(eng, tmp_path):
+    grid = ["--nx", "64", "--ny", "48", "--nz", "40", "--frames", "5", "--start", "1"]
+    want, _ = dump_of(tmp_path, "single.bin", *grid)
+    got, out = dump_of(tmp_path, "ring.bin", *grid, "--ring")
+    assert "RCCL" in out and "communicator of 1" in out
+    assert got == want
+
+
+def test_tau3d_rccl_needs_one_device_per_rank(eng, tmp_path):
+    import fluid_sims_amd as f
+    n = __import__("ctypes").c_int()
+    f.load().tau_device_count(__import__("ctypes").byref(n))
+    if n.value >= 2:
+        pytest.skip("this box has several devices")
+    r = run(TAU3D, "--n", "32", "--frames", "1", "--gpus", "2")
+    assert r.returncode != 0
+    assert "needs 2 devices" in r.stderr
+
+
+@pytest.mark.parametrize("transport", ["rccl", "local"])
+def test_python_binding_ring_world1(eng, transport):
+    """Tau3DRing (the ctypes mirror of tau3d_ring_*) with a world of one: RCCL to itself, and plain device copies"""
+    nx, ny, nz, steps = 48, 40, 36, 7
+    ref = eng.Tau3D(nx, ny, nz)
+    ref.init(1)
+    ref.set_clock(0.02, 1e-4)
+    ref.step(steps)
+    want, wc = ref.download(), ref.clock()
+    ref.close()
+    e = eng.Tau3D(nx, ny, nz)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    ring = eng.Tau3DRing(e, 0, 1, eng.RING_RCCL if transport == "rccl" else eng.RING_LOCAL)
+    ring.step(steps)
+    ring.finish()
+    c = ring.clock()
+    got = e.download()
+    info = ring.info()
+    ring.close()
+    e.close()
+    if transport == "rccl":
+        assert info["rccl_version"] > 0 and info["comm_ranks"] == 1 and "rccl" in info["librccl"]
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+    assert (c.t, c.d_tau, c.maxs, c.step) == (wc.t, wc.d_tau, wc.maxs, wc.step)
+
+
+def test_bench_force_slab_c_ring(eng):
+    """bench.py's N > 1 code path on one GPU: the C ring with RCCL to itself, one JSON line"""
+    import json
+    import sys
+    r = run(sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--n", "128", "--steps", "4", "--warmup", "2",
+            "--force-slab", "--self-p2p", "--no-cpu-baseline", "--no-configs", "--no-variants")
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 1 and j["ring"]["transport"] == "rccl" and j["ring"]["comm_ranks"] == 1 and j["value"] > 0
