@@ -120,16 +120,43 @@ __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x)
 __device__ __forceinline__ float clampf(float x, float a, float b) { return fminf(fmaxf(x, a), b); }
 __device__ __forceinline__ float denom_guard(float x) { return copysignf(fmaxf(fabsf(x), DENOM_EPS), x); } // :147-150
 
-// sinh with full relative accuracy for small arguments (the reference calls sinhf, :119)
-__device__ __forceinline__ float fsinh(float x) {
-  float ax = fabsf(x);
-  float x2 = x * x;
-  float series = x * (1.f + x2 * (1.f / 6.f) * (1.f + x2 * (1.f / 20.f) * (1.f + x2 * (1.f / 42.f))));
-  float e = fexp(ax);
-  float big = copysignf(0.5f * (e - rcp(e)), x);
-  return (ax < 0.5f) ? series : big;
+// Constants that a hot VALU expression multiplies by or masks with are kept out of SGPRs: an SGPR source halves the issue
+// rate on gfx950 (profiles/r02/valu_calib.txt), and a VOP3 instruction (fma, bfi, anything with |x|) cannot carry a literal,
+// so hipcc parks 1/6, 1/20, log2 e, 0x7fffffff ... in SGPRs.  VOP2 forms (mul / add with a 32-bit literal) and inline
+// constants (1.0, 0.5, 2.0) issue at full rate.
+// stops a mul from being contracted into an fma that would need the constant in an SGPR.  NOT volatile: a volatile asm keeps
+// its place among the other volatile asms (tau::gld's base pins), and inside a decode that serialises the six loads of a
+// cell — measured: k_flux_xy 3.96 -> 4.37 ms
+__device__ __forceinline__ float opaque(float v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ float vlit(unsigned bits) {
+  float v;
+  asm("v_mov_b32 %0, %1" : "=v"(v) : "i"(bits));
+  return v;
 }
-// asinh as the reference writes it, :121-125
+// magnitude of `mag`, sign of `sgn`; maskv = 0x7fffffff held in a VGPR (vlit)
+__device__ __forceinline__ float copysign_v(float mag, float sgn, float maskv) {
+  float r;
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(maskv), "v"(mag), "v"(sgn));
+  return r;
+}
+// sinh with full relative accuracy for small arguments (the reference calls sinhf, :119): the odd series to x^7 below 0.5
+// (truncation 2.7e-9 relative), (e^x - e^-x) / 2 above.  Signed exponential: no copysign; Horner on literal multiplies.
+__device__ __forceinline__ float fsinh(float x) {
+  const float x2 = x * x;
+  const float a = opaque(x2 * (1.f / 42.f)) + 1.f;
+  const float c = (x2 * (1.f / 20.f)) * a + 1.f;
+  const float s = (x2 * (1.f / 6.f)) * c + 1.f;
+  const float series = x * s;
+  const float e = fexp(x);
+  const float big = 0.5f * (e - rcp(e));
+  return (fabsf(x) < 0.5f) ? series : big;
+}
+// asinh as the reference writes it, :121-125.  maskv: 0x7fffffff in a VGPR (vlit), or use the two-argument form
+__device__ __forceinline__ float fasinh(float x, float maskv) {
+  float ax = fabsf(x);
+  float t = flog(ax + fsqrt(ax * ax + 1.0f));
+  return copysign_v(t, x, maskv);
+}
 __device__ __forceinline__ float fasinh(float x) {
   float ax = fabsf(x);
   float t = flog(ax + fsqrt(ax * ax + 1.0f));
@@ -381,19 +408,23 @@ __device__ __forceinline__ float vreg(float s) {
 }
 __device__ __forceinline__ Gas gas_sgpr(const Args &A) { return Gas{A.gamma, A.gm1, A.inv_gm1}; }
 __device__ __forceinline__ Gas gas_vgpr(const Args &A) { return Gas{vreg(A.gamma), vreg(A.gm1), vreg(A.inv_gm1)}; }
+__device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R, int axis) {
   const float rL = L.q[IR], rR = R.q[IR], pL = L.q[IP], pR = R.q[IP];
   const float irL = rcp(rL), irR = rcp(rR);
-  const float aL = fsqrt(fmaxf(A.gamma * pL * irL, DENOM_EPS));
-  const float aR = fsqrt(fmaxf(A.gamma * pR * irR, DENOM_EPS));
+  // a = sqrt(max(gamma p / r, eps)) and 1 / a from ONE transcendental: a = x rsq(x).  x >= 1e-12, so a >= 1e-6 and the
+  // reference's guards on aRef (max(aRef, 1e-12), 0.1 aRef > 1e-12; :366-374) never bind: 1 / aRef = min(1 / aL, 1 / aR).
+  const float xL = fmaxf(A.gamma * pL * irL, DENOM_EPS), xR = fmaxf(A.gamma * pR * irR, DENOM_EPS);
+  const float rsL = rsq(xL), rsR = rsq(xR);
+  const float aL = xL * rsL, aR = xR * rsR;
   const float unL = (axis == 0) ? L.q[IU] : (axis == 1) ? L.q[IV] : L.q[IW];
   const float unR = (axis == 0) ? R.q[IU] : (axis == 1) ? R.q[IV] : R.q[IW];
   float sL = fminf(unL - aL, unR - aR);
   float sR = fmaxf(unL + aL, unR + aR);
   const float aRef = fmaxf(aL, aR);
-  const float iaRef = rcp(fmaxf(aRef, DENOM_EPS));
-  { // entropy_fix_speed, :366-374  (1/max(0.1 a, eps) == 10/max(a, eps) for every a > 1e-11)
-    const float d = 0.1f * aRef, id = (d > DENOM_EPS) ? 10.f * iaRef : (1.f / DENOM_EPS);
+  const float iaRef = fminf(rsL, rsR);
+  { // entropy_fix_speed, :366-374  (1/max(0.1 a, eps) == 10/a)
+    const float d = 0.1f * aRef, id = 10.f * iaRef;
     float asl = fabsf(sL), asr = fabsf(sR);
     float fl = 0.5f * (asl * asl * id + d), fr = 0.5f * (asr * asr * id + d);
     sL = (asl >= d) ? sL : ((sL >= 0.f) ? fl : -fl);
@@ -460,16 +491,18 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   const float EK = left ? UL.c[4] : UR.c[4], EvK = left ? UL.c[5] : UR.c[5];
   US.c[4] = ((sK - unK) * EK - pK * unK + pStar * sM) * iden;
   US.c[5] = EvK * fac;
+  // The blend  F = (1 - alpha) [F_K + s_K (U* - U_K)] + alpha [s_R F_L - s_L F_R + s_L s_R (U_R - U_L)] / (s_R - s_L)  (:441-459)
+  // as ONE linear combination of F_L, F_R, U*, U_R, U_L: five coefficients picked once (four selects) instead of picking
+  // U_K and F_K per component (twelve half-rate selects and ten operations per component against five).
   const float wC = 1.f - alpha, wH = alpha * ihll;
+  const float aS = wC * sK, cU = wH * sLR;
+  const float lw = left ? wC : 0.f, la = left ? aS : 0.f;
+  const float cFL = wH * sR + lw, cFR = (wC - lw) - wH * sL;
+  const float cUR = cU - (aS - la), cUL = -(cU + la);
   Cons F;
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    float UK = left ? UL.c[k] : UR.c[k];
-    float FK = left ? FL.c[k] : FR.c[k];
-    float fhllc = FK + (US.c[k] - UK) * sK;
-    float fhll = FL.c[k] * sR - FR.c[k] * sL + (UR.c[k] - UL.c[k]) * sLR;
-    F.c[k] = fhllc * wC + fhll * wH;
-  }
+  for (int k = 0; k < 6; k++)
+    F.c[k] = cFL * FL.c[k] + cFR * FR.c[k] + aS * US.c[k] + cUR * UR.c[k] + cUL * UL.c[k];
   return F;
 }
 __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R, int axis) { return hllc(gas_sgpr(A), L, R, axis); }
@@ -555,7 +588,7 @@ using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::
 
 // fetch_cell through a scalar plane base.  epl: field 0 of the encoded state at plane zh; fs4: bytes between fields; spl:
 // the solid mask at plane zh
-__device__ __forceinline__ void fetch_cell_e(const Args &A, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
+__device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
                                              int zg, float (&q)[6], bool &sol) {
   Prim p;
   if (gx < 0) {
@@ -564,13 +597,13 @@ __device__ __forceinline__ void fetch_cell_e(const Args &A, const GChar *qpl, si
   } else if (gx >= A.nx) {
     const unsigned vo = lane_off((unsigned)(gyw * A.nx + (A.nx - 1)) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = decode_field(A.u_ref, m, gld(qpl + m * fs4, vo));
+    for (int m = 0; m < 6; m++) p.q[m] = decode_field(uref, m, gld(qpl + m * fs4, vo));
     p = outflow_prim(A, p);
     sol = sdf_solid(A, gx, gyw, zg);
   } else {
     const unsigned vo = lane_off((unsigned)(gyw * A.nx + gx) << 2);
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = decode_field(A.u_ref, m, gld(qpl + m * fs4, vo));
+    for (int m = 0; m < 6; m++) p.q[m] = decode_field(uref, m, gld(qpl + m * fs4, vo));
     sol = spl[vo >> 2] != 0;
   }
 #pragma unroll
@@ -930,6 +963,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   const int tx = tid & (XT - 1), ty = tid >> 5;
   const int lane = tid & 63, wave = tid >> 6;
   const Gas G = gas_vgpr(A);
+  const float uref = vreg(A.u_ref);   // three multiplies per decoded cell: an SGPR operand would halve their rate
 
   const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
@@ -954,7 +988,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   bool own_solid;
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
-    fetch_cell_e(A, qpl, fs4, spl, x, yw, zg, q, own_solid);
+    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, own_solid);
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     sS[lc] = own_solid ? 1 : 0;
@@ -976,7 +1010,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
       const int gx = bx0 + lx - HALO;
       const int gy = wrap_near(by0 + ly - HALO, A.ny, ynear);
       bool sol;
-      fetch_cell_e(A, qpl, fs4, spl, gx, gy, zg, q, sol);
+      fetch_cell_e(A, uref, qpl, fs4, spl, gx, gy, zg, q, sol);
       const int li = ly * PXS + lx;
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
@@ -1122,14 +1156,23 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 #endif
 __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyLds S;
+#ifdef TAU3D_FAST_ONLY   // ISA statistics only (scripts/isa_kernel_mix.py): the object then holds the one body that runs
+  flux_xy_body<true>(A, S);
+#else
   if (fast_form(A.clk->fmax_in, A.in_fmax)) flux_xy_body<true>(A, S);
   else flux_xy_body<false>(A, S);
+#endif
 }
 
 // The update of one fluid cell, :1266-1358: conservative update from the x/y divergence D and the two z-face fluxes,
 // repairs, Landau-Teller relaxation, sponges, the max-wavespeed / max-|primitive| contributions, re-encoding.  One
 // function (k_update_z; a one-plane-per-workgroup kernel for small grids that shared it was measured and dropped).
-__device__ __forceinline__ void update_cell(const Args &A, const float (&own)[6], const float (&D)[6], const float (&Fz_lo)[6],
+// the constants update_cell uses three times per cell, in VGPRs (an SGPR operand halves the issue rate); gamma and gamma - 1
+// come from the Gas copy the z face already holds.  k_update_z has three registers to spare under its five-wave limit (96):
+// the constants with one use per cell stay in SGPRs.
+struct UpdK { float gm1, gamma, inv_u_ref, absmask; };
+__device__ __forceinline__ UpdK updk_vgpr(const Args &A, const Gas &G) { return UpdK{G.gm1, G.gamma, vreg(A.inv_u_ref), vlit(0x7fffffffu)}; }
+__device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const float (&own)[6], const float (&D)[6], const float (&Fz_lo)[6],
                                             const float (&Fz_hi)[6], float dt, float inv_dz, float gain, int x, float (&E)[6],
                                             float &smax, float &fmx) {
   const float r0 = own[IR], u0 = own[IU], v0 = own[IV], w0 = own[IW], p0 = own[IP], e0 = own[IE];
@@ -1137,7 +1180,7 @@ __device__ __forceinline__ void update_cell(const Args &A, const float (&own)[6]
   U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
   {
     float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
-    float eth = p0 * rcp(fmaxf(A.gm1 * r0, RHO_P_FLOOR));
+    float eth = p0 * rcp(fmaxf(K.gm1 * r0, RHO_P_FLOOR));
     U0[4] = r0 * (ke + eth + e0);
     U0[5] = r0 * e0;
   }
@@ -1153,7 +1196,7 @@ __device__ __forceinline__ void update_cell(const Args &A, const float (&own)[6]
   float ke = 0.5f * (u1 * u1 + v1 * v1 + w1 * w1);
   float ev1 = fmaxf(U1[5] * ir1, 0.f);
   float e_th = fmaxf(U1[4] * ir1 - ke - ev1, THERMAL_ENERGY_FLOOR);
-  float p1 = fmaxf(A.gm1 * r1 * e_th, RHO_P_FLOOR);
+  float p1 = fmaxf(K.gm1 * r1 * e_th, RHO_P_FLOOR);
   const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
                      __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
                    r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
@@ -1184,15 +1227,15 @@ __device__ __forceinline__ void update_cell(const Args &A, const float (&own)[6]
     w1 = w1 + k * (0.0f - w1);
     ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
   }
-  float a = soundspeed(A, p1, r1);
-  float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
+  float a = fsqrt(fmaxf(K.gamma * p1 * rcp(r1), DENOM_EPS));   // soundspeed, :264-266
+  float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * inv_dz;
   if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
   fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
 
   E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
-  E[1] = fasinh(u1 * A.inv_u_ref);
-  E[2] = fasinh(v1 * A.inv_u_ref);
-  E[3] = fasinh(w1 * A.inv_u_ref);
+  E[1] = fasinh(u1 * K.inv_u_ref, K.absmask);
+  E[2] = fasinh(v1 * K.inv_u_ref, K.absmask);
+  E[3] = fasinh(w1 * K.inv_u_ref, K.absmask);
   E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
   E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
 }
@@ -1225,6 +1268,8 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const float inv_dz = vreg(A.inv_dz);
   const float gain = A.clk->gain;
   const Gas G = gas_vgpr(A);
+  const float uref = vreg(A.u_ref);
+  const UpdK K = updk_vgpr(A, G);
 
   // Addressing (see gld / gst): scalar field bases at the chunk's first plane + one 32-bit byte offset per lane (with
   // 64-bit lane addresses: 61 half-rate adds per plane); the host keeps zchunk * plane bytes below 2^32.  The field
@@ -1239,7 +1284,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   auto load_own = [&](int k, float (&dst)[6]) -> unsigned {   // plane zc_lo-3+k
     const unsigned vo = col4 + (unsigned)k * plane4;
 #pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = decode_field(A.u_ref, m, *(const GFloat *)(qP + m * fs4 + vo));
+    for (int m = 0; m < 6; m++) dst[m] = decode_field(uref, m, *(const GFloat *)(qP + m * fs4 + vo));
     return solP[vo >> 2] != 0 ? 1u : 0u;
   };
 
@@ -1299,7 +1344,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     asm volatile("" : "+s"(f4), "+s"(d4));
     if (more) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) Nx[m] = decode_field(A.u_ref, m, gld(qN + m * f4, vo));
+      for (int m = 0; m < 6; m++) Nx[m] = decode_field(uref, m, gld(qN + m * f4, vo));
       nsol = solN[vo >> 2] != 0 ? 1u : 0u;
     }
     const bool own_solid = (ws >> 2) & 1u;
@@ -1359,7 +1404,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #pragma unroll
         for (int m = 0; m < 6; m++) E[m] = *(const GFloat *)(inB + m * fs4 + vo);   // (rare path: plain addressing)
       } else {
-        update_cell(A, own, D, Fz_lo, Fz_hi, dt, inv_dz, gain, x, E, smax, fmx);
+        update_cell(A, K, own, D, Fz_lo, Fz_hi, dt, inv_dz, gain, x, E, smax, fmx);
       }
       {
         const unsigned vb = lane_off(vo);
@@ -1402,8 +1447,12 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 
 __global__ __launch_bounds__(ZNT, 5) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
   __shared__ ZRing ring;
+#ifdef TAU3D_FAST_ONLY
+  update_z_body<true>(A, ring);
+#else
   if (fast_form(A.clk->fmax_in, A.in_fmax)) update_z_body<true>(A, ring);
   else update_z_body<false>(A, ring);
+#endif
 }
 
 // ---------------------------------------------------------------- small kernels
