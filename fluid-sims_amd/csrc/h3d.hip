@@ -92,6 +92,7 @@ struct Args {
   // split step (k_flux_xy + k_update_z): the x/y flux divergence of the local planes (no halo)
   float *dxy[6];
   float *send[2];            // Z-slab ring: packed send buffers the step writes its new boundary planes into (or null)
+  const unsigned *xyflag;    // k_flux_xy: [local plane][tile row][tile column] != 0 where the tile + its x/y halo holds a solid cell (or null: assume so)
   // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
   const float *in0;
   float *out0;
@@ -499,10 +500,18 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   const float lw = left ? wC : 0.f, la = left ? aS : 0.f;
   const float cFL = wH * sR + lw, cFR = (wC - lw) - wH * sL;
   const float cUR = cU - (aS - la), cUL = -(cU + la);
+  // explicit fma chain: left to contraction, the five-term sum was fused differently in two inlined copies of this function
+  // (the chunk prologue and the marching loop of the fused kernel), and a Z-slab run — whose chunks start elsewhere — was no
+  // longer bit-identical to the single domain
   Cons F;
 #pragma unroll
-  for (int k = 0; k < 6; k++)
-    F.c[k] = cFL * FL.c[k] + cFR * FR.c[k] + aS * US.c[k] + cUR * UR.c[k] + cUL * UL.c[k];
+  for (int k = 0; k < 6; k++) {
+    float f = cFL * FL.c[k];
+    f = __builtin_fmaf(cFR, FR.c[k], f);
+    f = __builtin_fmaf(aS, US.c[k], f);
+    f = __builtin_fmaf(cUR, UR.c[k], f);
+    F.c[k] = __builtin_fmaf(cUL, UL.c[k], f);
+  }
   return F;
 }
 __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R, int axis) { return hllc(gas_sgpr(A), L, R, axis); }
@@ -872,7 +881,9 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
         float a = soundspeed(A, p1, r1); // :1345-1351
         float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
         if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
-        fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
+        fmx = fmaxf(fmaxf(fmx, r1), fabsf(u1));            // three v_max3_f32 (a balanced tree of fmaxf compiles to six v_max_f32)
+  fmx = fmaxf(fmaxf(fmx, fabsf(v1)), fabsf(w1));
+  fmx = fmaxf(fmaxf(fmx, p1), ev1);
 
         A.out[0][gi] = flog(fmaxf(r1, RHO_P_FLOOR)); // :1353-1358
         A.out[1][gi] = fasinh(u1 * A.inv_u_ref);
@@ -932,7 +943,14 @@ __global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
 #endif
 constexpr int XT = 32, YT = TAU3D_XY_TY;   // k_flux_xy tile; XT * YT threads
 constexpr int XNT = XT * YT, XNW = XNT / 64;
-constexpr int XPY = YT + 2 * HALO, XPLANE = XPY * PXS;
+// row stride of the staged plane.  40 (the fused kernel's) puts a COLUMN of cells on four banks: the ring and far-face rounds,
+// whose lanes sit one per row, then run four lanes per bank (SQ_LDS_BANK_CONFLICT 26 % of the LDS-active cycles, profiles/r02).
+// An odd stride spreads a column over all 32 banks; rows stay conflict-free (32 consecutive words per half-wave).
+#ifndef TAU3D_XPXS
+#define TAU3D_XPXS 41
+#endif
+constexpr int XPXS = TAU3D_XPXS;
+constexpr int XPY = YT + 2 * HALO, XPLANE = XPY * XPXS;
 static_assert(YT % 2 == 0 && XT + YT <= 64 && 2 * HALO * (XT + YT) <= XNT, "ring rounds are one wave each, halo staging one round");
 // Cell-centred reconstruction in x and y as well: a thread weights its own cell ONCE per axis (weno_cell: the three
 // smoothness indicators serve the left state at the high face and the right state at the low face) and the two states
@@ -957,7 +975,9 @@ __device__ __forceinline__ float lane_above(float x) {
 // what k_flux_xy knows about its cell when the x / y faces are done (core / store split: the core also served the
 // small-grid experiment of DESIGN §4.1's tried-list)
 struct XyCell { float d[6]; bool in_xy, own_solid; int x, yw, z, lc; };
-template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A, XyLds &S, XyCell &C) {
+// SOLID = false: the tile and its 3-cell x / y halo hold no solid cell (a flag per tile and plane, computed once from the
+// static mask: tau3d_create / tau3d_init) — no solid bytes are staged or read and the faces take the WENO states as they are.
+template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(const Args &A, XyLds &S, XyCell &C, int bx, int by, int z) {
   auto &sP = S.sP; auto &sS = S.sS;
   const int tid = threadIdx.x;
   const int tx = tid & (XT - 1), ty = tid >> 5;
@@ -965,13 +985,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   const Gas G = gas_vgpr(A);
   const float uref = vreg(A.u_ref);   // three multiplies per decoded cell: an SGPR operand would halve their rate
 
-  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
-  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
-  const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
-  const int by = (int)(b % (unsigned)A.nty);
-  const int bz = (int)(b / (unsigned)A.nty);
   const int bx0 = bx * XT, by0 = by * YT;
-  const int z = (bz >= A.nzc1) ? A.zl_lo2 + (bz - A.nzc1) : A.zl_lo + bz;   // here a "chunk" is one plane
 
   const int x = bx0 + tx, y = by0 + ty;
   const bool in_xy = (x < A.nx) && (y < A.ny);
@@ -979,19 +993,20 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   const int yw = wrap_near(y, A.ny, ynear);
   const int zh = z + HALO;
   const int zg = wrapi(A.z0 + z, A.nz);
-  const int lc = (ty + HALO) * PXS + (tx + HALO);
+  const int lc = (ty + HALO) * XPXS + (tx + HALO);
 
   const size_t plane_n = (size_t)A.nx * A.ny;
   const GChar *const qpl = (const GChar *)(A.in0 + (size_t)zh * plane_n);
   const uint8_t *const spl = A.solid + (size_t)zh * plane_n;
   const size_t fs4 = (size_t)A.fstride << 2;
-  bool own_solid;
+  bool own_solid = false;
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
-    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, own_solid);
+    bool osol;
+    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, osol);
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
-    sS[lc] = own_solid ? 1 : 0;
+    if (SOLID) { own_solid = osol; sS[lc] = osol ? 1 : 0; }
     constexpr int NROWS = 2 * HALO * XT;
     constexpr int NHALO = NROWS + YT * 2 * HALO;
     if (tid < NHALO) {
@@ -1011,10 +1026,10 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
       const int gy = wrap_near(by0 + ly - HALO, A.ny, ynear);
       bool sol;
       fetch_cell_e(A, uref, qpl, fs4, spl, gx, gy, zg, q, sol);
-      const int li = ly * PXS + lx;
+      const int li = ly * XPXS + lx;
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
-      sS[li] = sol ? 1 : 0;
+      if (SOLID) sS[li] = sol ? 1 : 0;
     }
   }
   __syncthreads();
@@ -1029,7 +1044,7 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
     const float *p = &sP[m][lcs];
     float Ly;
     weno_cell<FAST>(p[-2], p[-1], p[0], p[1], p[2], Lxo[m], Rx[m]);
-    weno_cell<FAST>(p[-2 * PXS], p[-PXS], p[0], p[PXS], p[2 * PXS], Ly, Ry[m]);
+    weno_cell<FAST>(p[-2 * XPXS], p[-XPXS], p[0], p[XPXS], p[2 * XPXS], Ly, Ry[m]);
     S.sLy[m][ty + 1][tx] = Ly;
     asm volatile("" : "+v"(lcs), "+v"(Lxo[m]), "+v"(Rx[m]), "+v"(Ry[m]));
   }
@@ -1049,8 +1064,8 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
     const int r = t - side * (6 * RING);
     const int m = r / RING, ln = r - m * RING;
     const bool isx = ln < YT;
-    const int c0 = isx ? (ln + HALO) * PXS + (side ? XT + HALO : HALO - 1) : (side ? YT + HALO : HALO - 1) * PXS + (ln - YT + HALO);
-    const int st = isx ? 1 : PXS;
+    const int c0 = isx ? (ln + HALO) * XPXS + (side ? XT + HALO : HALO - 1) : (side ? YT + HALO : HALO - 1) * XPXS + (ln - YT + HALO);
+    const int st = isx ? 1 : XPXS;
     const float *p = &sP[0][0] + m * XPLANE + c0;
     float Lhi, Rlo;
     weno_cell<FAST>(p[-2 * st], p[-st], p[0], p[st], p[2 * st], Lhi, Rlo);
@@ -1066,18 +1081,21 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   float Fx[6], Fy[6];
   {
     Prim L, R;
-    float lo[6], hi[6];
-    unsigned s = 0;
 #pragma unroll
     for (int m = 0; m < 6; m++) {
       const float l = lane_below(Lxo[m]);
       L.q[m] = (tx == 0) ? S.sLx0[m][ty] : l;
       R.q[m] = Rx[m];
-      lo[m] = sP[m][lc - 1]; hi[m] = sP[m][lc];
     }
+    if (SOLID) {
+      float lo[6], hi[6];
+      unsigned s = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s |= (unsigned)sS[lc + (k - 3)] << k;
-    solid_override(L, R, lo, hi, s, 0);
+      for (int m = 0; m < 6; m++) { lo[m] = sP[m][lc - 1]; hi[m] = sP[m][lc]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) s |= (unsigned)sS[lc + (k - 3)] << k;
+      solid_override(L, R, lo, hi, s, 0);
+    }
     prim_floor(L);
     prim_floor(R);
     const Cons F = hllc(G, L, R, 0);
@@ -1086,17 +1104,20 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   }
   {
     Prim L, R;
-    float lo[6], hi[6];
-    unsigned s = 0;
 #pragma unroll
     for (int m = 0; m < 6; m++) {
       L.q[m] = S.sLy[m][ty][tx];
       R.q[m] = Ry[m];
-      lo[m] = sP[m][lc - PXS]; hi[m] = sP[m][lc];
     }
+    if (SOLID) {
+      float lo[6], hi[6];
+      unsigned s = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s |= (unsigned)sS[lc + (k - 3) * PXS] << k;
-    solid_override(L, R, lo, hi, s, 1);
+      for (int m = 0; m < 6; m++) { lo[m] = sP[m][lc - XPXS]; hi[m] = sP[m][lc]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) s |= (unsigned)sS[lc + (k - 3) * XPXS] << k;
+      solid_override(L, R, lo, hi, s, 1);
+    }
     prim_floor(L);
     prim_floor(R);
     const Cons F = hllc(G, L, R, 1);
@@ -1105,20 +1126,23 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
   }
   if (wave == wC && lane < XT + YT) { // far faces: x faces at column XT (rows 0 .. YT-1), y faces at row YT
     const bool isx = lane < YT;
-    const int c0 = isx ? (lane + HALO) * PXS + (XT + HALO) : (YT + HALO) * PXS + (lane - YT + HALO);   // the cell above the face
-    const int st = isx ? 1 : PXS;
+    const int c0 = isx ? (lane + HALO) * XPXS + (XT + HALO) : (YT + HALO) * XPXS + (lane - YT + HALO);   // the cell above the face
+    const int st = isx ? 1 : XPXS;
     Prim L, R;
-    float lo[6], hi[6];
-    unsigned s = 0;
 #pragma unroll
     for (int m = 0; m < 6; m++) {
       L.q[m] = isx ? S.sLxT[m][lane] : S.sLy[m][YT][lane - YT];
       R.q[m] = isx ? S.sRxT[m][lane] : S.sRyT[m][lane - YT];
-      lo[m] = sP[m][c0 - st]; hi[m] = sP[m][c0];
     }
+    if (SOLID) {
+      float lo[6], hi[6];
+      unsigned s = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) s |= (unsigned)sS[c0 + (k - 3) * st] << k;
-    solid_override_xy(L, R, lo, hi, s, isx);
+      for (int m = 0; m < 6; m++) { lo[m] = sP[m][c0 - st]; hi[m] = sP[m][c0]; }
+#pragma unroll
+      for (int k = 0; k < 6; k++) s |= (unsigned)sS[c0 + (k - 3) * st] << k;
+      solid_override_xy(L, R, lo, hi, s, isx);
+    }
     prim_floor(L);
     prim_floor(R);
     const Cons F = hllc(G, L, R, isx ? 0 : 1);
@@ -1141,7 +1165,16 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_core(const Args &A,
 }
 template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S) {
   XyCell C;
-  flux_xy_core<FAST>(A, S, C);
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
+  const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
+  const int by = (int)(b % (unsigned)A.nty);
+  const int bz = (int)(b / (unsigned)A.nty);
+  const int z = (bz >= A.nzc1) ? A.zl_lo2 + (bz - A.nzc1) : A.zl_lo + bz;   // here a "chunk" is one plane
+  // one scalar load, one scalar branch: ~90 % of the tiles of the 512^3 sphere case hold no solid cell
+  const bool any_solid = A.xyflag == nullptr || A.xyflag[((size_t)z * A.nty + by) * A.ntx + bx] != 0u;
+  if (any_solid) flux_xy_core<FAST, true>(A, S, C, bx, by, z);
+  else flux_xy_core<FAST, false>(A, S, C, bx, by, z);
   if (C.in_xy && !C.own_solid) {
     GChar *const dpl = (GChar *)(A.d0 + (size_t)C.z * ((size_t)A.nx * A.ny));
     const size_t ds4 = (size_t)A.dstride << 2;
@@ -1230,7 +1263,9 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
   float a = fsqrt(fmaxf(K.gamma * p1 * rcp(r1), DENOM_EPS));   // soundspeed, :264-266
   float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * inv_dz;
   if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
-  fmx = fmaxf(fmaxf(fmaxf(fmx, r1), fmaxf(fabsf(u1), fabsf(v1))), fmaxf(fmaxf(fabsf(w1), p1), ev1));
+  fmx = fmaxf(fmaxf(fmx, r1), fabsf(u1));            // three v_max3_f32 (a balanced tree of fmaxf compiles to six v_max_f32)
+  fmx = fmaxf(fmaxf(fmx, fabsf(v1)), fabsf(w1));
+  fmx = fmaxf(fmaxf(fmx, p1), ev1);
 
   E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
   E[1] = fasinh(u1 * K.inv_u_ref, K.absmask);
@@ -1377,11 +1412,13 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #pragma unroll
         for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
       }
+#ifndef TAU3D_EXP_NOD   // (timing experiment: the step without the divergence read — wrong results)
       if (in_xy && !own_solid) {
         const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
       }
+#endif
       if (ws != 0u) {   // rare: the cells either side of the face, from the ring
         float lo[6], hi[6];
 #pragma unroll
@@ -1466,6 +1503,28 @@ __global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes
     int zg = wrapi(A.z0 + zh - HALO, A.nz);
     solid[i] = sdf_solid(A, x, y, zg) ? 1 : 0;
   }
+}
+
+// k_flux_xy's tile flags: one word per (local plane, tile row, tile column), non-zero where the tile or its 3-cell x / y halo
+// holds a solid cell — exactly the cells whose solid byte the kernel would look at (ghost columns left of x = 0 and right of
+// x = nx-1 by the SDF, as fetch_cell_e classifies them).  One workgroup per flag; runs when the mask is built.
+__global__ __launch_bounds__(256) void k_xy_flags(Args A, const uint8_t *solid, unsigned *flags) {
+  const int ntx = (A.nx + XT - 1) / XT, nty = (A.ny + YT - 1) / YT;
+  unsigned b = blockIdx.x;
+  const int bx = (int)(b % (unsigned)ntx); b /= (unsigned)ntx;
+  const int by = (int)(b % (unsigned)nty);
+  const int z = (int)(b / (unsigned)nty);
+  const int zh = z + HALO, zg = wrapi(A.z0 + z, A.nz);
+  constexpr int RX = XT + 2 * HALO, RY = YT + 2 * HALO;
+  int any = 0;
+  for (int i = threadIdx.x; i < RX * RY; i += 256) {
+    const int gx = bx * XT + (i % RX) - HALO;
+    const int gy = wrapi(by * YT + (i / RX) - HALO, A.ny);
+    if (gx >= 0 && gx < A.nx) any |= solid[((size_t)zh * A.ny + gy) * A.nx + gx] != 0;
+    else any |= sdf_solid(A, gx, gy, zg) ? 1 : 0;
+  }
+  any = __syncthreads_or(any);
+  if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1u : 0u;
 }
 
 struct InitVals { float f[6]; float s[6]; }; // encoded fluid / solid cell values (host-computed, libm)
@@ -1735,6 +1794,7 @@ struct tau3d {
   float *dxy[6];            // split step: x/y flux divergence of the local planes
   bool split;               // step = k_flux_xy + k_update_z (else the fused k_step)
   uint8_t *solid;
+  unsigned *xyflag = nullptr;   // split step: k_flux_xy's solid-free tile flags (h3d::k_xy_flags)
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
   bool end_pending;         // the controller update of the last tau3d_step_async step has not run yet
@@ -1755,6 +1815,18 @@ struct tau3d {
 };
 
 static int flush_clock(tau3d *h);
+static int split_buffers(tau3d *h);
+// the solid mask of the slab (+ halo planes) and, for the split step, the per-tile flags derived from it
+static int build_solid(tau3d *h) {
+  hipLaunchKernelGGL(h3d::k_build_solid, dim3(1024), dim3(256), 0, h->stream, h->solid, h->base);
+  TAU_LAUNCH_CHECK("k_build_solid");
+  if (h->xyflag) {
+    const int ntx = (h->p.nx + h3d::XT - 1) / h3d::XT, nty = (h->p.ny + h3d::YT - 1) / h3d::YT;
+    hipLaunchKernelGGL(h3d::k_xy_flags, dim3((unsigned)(ntx * nty * h->nzl)), dim3(256), 0, h->stream, h->base, (const uint8_t *)h->solid, h->xyflag);
+    TAU_LAUNCH_CHECK("k_xy_flags");
+  }
+  return 0;
+}
 
 static float host_evib_eq(const tau3d_params &P, float T) { // tau_hypersonic_3d_cuda.cu:206-211
   float a = P.theta_v / fmaxf(T, 1e-6f);
@@ -1822,8 +1894,6 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   // the latency between dependent dispatches and keep the one-kernel step.  TAU3D_SPLIT=0/1 overrides.
   h->split = (long)p->nx * p->ny >= 128L * 128L;
   if (const char *e = getenv("TAU3D_SPLIT")) h->split = atoi(e) != 0;
-  if (h->split && h->plane_n * sizeof(float) * 8 > 0xFFFFFFFFull)   // k_update_z: 32-bit byte offsets within a chunk of planes
-    return tau::fail("tau3d_create: %d x %d planes are beyond the split step's 32-bit in-chunk offsets", p->nx, p->ny);
   // The six fields of an array group are ONE allocation, field f at f * field_n: the per-field pointers the API hands out
   // are as before, but a kernel can address all six through one base pointer and a stride — k_update_z touches five such
   // groups, and thirty separate pointers (60 SGPRs) had it spilling scalars to VGPR lanes (478 v_readlane per plane).
@@ -1834,10 +1904,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     TAU_HIP(hipMemsetAsync(h->buf[s][0], 0, 6 * h->field_stride * sizeof(float), h->stream));
     for (int f = 1; f < 6; f++) h->buf[s][f] = h->buf[s][0] + f * h->field_stride;
   }
-  if (h->split) {
-    TAU_HIP(hipMalloc(&h->dxy[0], 6 * h->dxy_stride * sizeof(float)));
-    for (int f = 1; f < 6; f++) h->dxy[f] = h->dxy[0] + f * h->dxy_stride;
-  }
+  if (h->split && split_buffers(h)) return 1;
   TAU_HIP(hipMalloc(&h->solid, h->field_n));
   TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
   for (int k = 0; k < 2; k++)
@@ -1847,8 +1914,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   fill_consts(h);
   // the solid mask depends on the parameters and the slab only: a caller that goes create -> upload -> step
   // (without tau3d_init) must find it built (and the state buffers defined: zeroed above)
-  hipLaunchKernelGGL(h3d::k_build_solid, dim3(1024), dim3(256), 0, h->stream, h->solid, h->base);
-  TAU_LAUNCH_CHECK("k_build_solid");
+  if (build_solid(h)) return 1;
   { // nothing is known about the state yet: the first k_step takes the reciprocal form unless init / upload measured it
     h3d::DevClock c0;
     memset(&c0, 0, sizeof(c0));
@@ -1870,6 +1936,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
     hipFree(h->buf[s][0]);
   hipFree(h->dxy[0]);
   hipFree(h->solid);
+  hipFree(h->xyflag);
   hipFree(h->clk);
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
   for (int k = 0; k < 2; k++)
@@ -1912,8 +1979,7 @@ static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
 extern "C" int tau3d_init(tau3d_t *h, int mode) {
   TAU_HIP(hipSetDevice(h->device));
   const tau3d_params &P = h->p;
-  hipLaunchKernelGGL(h3d::k_build_solid, dim3(1024), dim3(256), 0, h->stream, h->solid, h->base);
-  TAU_LAUNCH_CHECK("k_build_solid");
+  if (build_solid(h)) return 1;
   // encoded cell values with host libm (identical to what the reference's k_init encodes up to
   // __logf vs logf): fluid = inflow rho,p at rest (mode 0) or full inflow state (mode 1)
   h3d::InitVals iv;
@@ -2018,6 +2084,7 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.send[0] = A.send[1] = nullptr;
   A.in0 = h->buf[h->cur][0]; A.out0 = h->buf[h->cur ^ 1][0];
   A.d0 = h->dxy[0]; A.fstride = (unsigned)h->field_stride; A.dstride = (unsigned)h->dxy_stride;
+  A.xyflag = h->xyflag;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s) {   // x/y faces: one plane per workgroup
   h3d::Args X;
@@ -2296,6 +2363,31 @@ extern "C" int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *devi
   return 0;
 }
 extern "C" int tau3d_is_split(tau3d_t *h) { return h && h->split ? 1 : 0; }
+static int split_buffers(tau3d *h) {   // what the kernel pair needs beside the state: the x/y divergence and k_flux_xy's tile flags
+  const tau3d_params *p = &h->p;
+  if (h->plane_n * sizeof(float) * 8 > 0xFFFFFFFFull)   // k_update_z: 32-bit byte offsets within a chunk of planes
+    return tau::fail("tau3d: %d x %d planes are beyond the split step's 32-bit in-chunk offsets", p->nx, p->ny);
+  if (!h->dxy[0]) {
+    TAU_HIP(hipMalloc(&h->dxy[0], 6 * h->dxy_stride * sizeof(float)));
+    for (int f = 1; f < 6; f++) h->dxy[f] = h->dxy[0] + f * h->dxy_stride;
+  }
+  if (!h->xyflag && !(getenv("TAU3D_XY_NOFLAGS") && atoi(getenv("TAU3D_XY_NOFLAGS")))) {
+    const size_t ntiles = (size_t)((p->nx + h3d::XT - 1) / h3d::XT) * ((p->ny + h3d::YT - 1) / h3d::YT) * (size_t)h->nzl;
+    TAU_HIP(hipMalloc(&h->xyflag, ntiles * sizeof(unsigned)));
+  }
+  return 0;
+}
+extern "C" int tau3d_set_split(tau3d_t *h, int on) {
+  if (!h) return tau::fail("tau3d_set_split: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  if (on && !h->split) {
+    if (split_buffers(h)) return 1;
+    h->split = true;
+    return build_solid(h);   // fills the tile flags (the mask itself is rebuilt identically)
+  }
+  h->split = on != 0;
+  return 0;
+}
 extern "C" int tau3d_max_ptr(tau3d_t *h, float **p) {
   *p = reinterpret_cast<float *>(&h->clk->maxs_bits);
   return 0;

@@ -147,6 +147,9 @@ int tau3d_sync(tau3d_t *h);
 int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *device, void **stream);
 /* 1 if a step of this handle is the kernel pair k_flux_xy + k_update_z, 0 if the fused k_step */
 int tau3d_is_split(tau3d_t *h);
+/* choose the form of the step for this handle: 1 = the kernel pair, 0 = the fused kernel (tau3d_create picks the pair from
+ * 128^2 cells per plane; TAU3D_SPLIT=0/1 in the environment overrides that default).  Both give the same results to rounding. */
+int tau3d_set_split(tau3d_t *h, int on);
 
 /* ---- The Z-slab ring, in the library (csrc/ring.hip): one process per GPU, each owning one slab handle; the ring adds
  * the halo exchange with both z neighbours and the all-reduce(max) of the two words of tau3d_max_ptr, issued from C on a

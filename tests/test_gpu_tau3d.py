@@ -37,12 +37,22 @@ def test_init_and_mask_bit_exact(eng, oracle_built, shape):
     e.close()
 
 
-@pytest.mark.parametrize("shape,mode,warm", [((32, 32, 32), 0, 0), ((32, 32, 32), 1, 30), ((48, 40, 24), 1, 25),
-                                             ((64, 64, 64), 1, 40), ((40, 24, 16), 1, 20), ((96, 64, 32), 1, 40)])
-def test_single_step_parity(eng, oracle_built, shape, mode, warm):
-    """One k_step on identical input (developed by `warm` engine steps from the impulsive start)."""
+# split = None: the form tau3d_create picks (the fused k_step below 128^2 cells per plane); True: the kernel pair
+# k_flux_xy + k_update_z — the step bench.py times at 512^3 — forced through tau3d_set_split
+@pytest.mark.parametrize("shape,mode,warm,split", [
+    ((32, 32, 32), 0, 0, None), ((32, 32, 32), 1, 30, None), ((48, 40, 24), 1, 25, None), ((64, 64, 64), 1, 40, None),
+    ((40, 24, 16), 1, 20, None), ((96, 64, 32), 1, 40, None),
+    # (planes of 160 x 128 / 256 x 192 with only 12 / 16 z planes — dz ten times dx — leave the sane range within 40 impulsive
+    #  steps, in the oracle as in the engine: the forced-split cases keep the cells near cubic)
+    ((96, 64, 32), 1, 40, True), ((160, 128, 96), 1, 40, True), ((256, 192, 128), 1, 40, True), ((48, 40, 24), 1, 25, True),
+    ((32, 32, 32), 0, 0, True)])
+def test_single_step_parity(eng, oracle_built, shape, mode, warm, split):
+    """One step on identical input (developed by `warm` engine steps from the impulsive start)."""
     nx, ny, nz = shape
     e = eng.Tau3D(nx, ny, nz)
+    if split is not None:
+        e.set_split(split)
+        assert e.is_split() == split
     o = oracle_built.Oracle3D(nx, ny, nz)
     e.init(mode)
     if mode:
@@ -129,16 +139,23 @@ def test_deterministic(eng):
     assert outs[0][1] == outs[1][1]
 
 
-def test_full_size_slab_vs_oracle(eng, oracle_built):
-    """BASELINE size 512^3: after a short impulsive warm-up, one step on the GPU; an 8-plane slab
-    through the bow-shock region is recomputed by the oracle from the same input planes."""
+@pytest.mark.parametrize("warm,zoff", [(12, -40), (100, -4), (60, -4), (60, -40)])
+def test_full_size_slab_vs_oracle(eng, oracle_built, warm, zoff):
+    """BASELINE size 512^3 (the kernel pair bench.py times): after an impulsive warm-up, one step on the GPU; an 8-plane
+    slab is recomputed by the oracle from the same input planes.  (12, -40): off-centre cut through sphere and shock;
+    (100, -4): the planes through the sphere's centre — stagnation line and bow-shock stand-off — after 100 steps.
+    After 60 steps the impulsive start has just evacuated the lee side of the sphere: the first fluid cells behind the wall
+    sit at rho = 3e-5 (1/600 of the free stream) between a 0.1-density wall state and a 60-unit velocity jump, and one or
+    two of the 1.7 M cells of a slab land at 1.2 - 1.5e-5 against the oracle — the round-2 kernels too (scratch measurement
+    in DESIGN §2).  Those two cases assert exactly that: at most 3 cells beyond 1e-5, none beyond 2.5e-5."""
     n = 512
     e = eng.Tau3D(n)
+    assert e.is_split()
     e.init(1)
     e.set_clock(0.02, 1e-4)
-    e.step(12)
+    e.step(warm)
     c = e.clock()
-    zc = n // 2 - 40   # cuts the sphere (r = 128 cells) and the shock in front of it
+    zc = n // 2 + zoff   # cuts the sphere (r = 128 cells) and the shock in front of it
     inp = e.download_planes(zc - 3, zc + 8 + 3)
     dt = float(np.float32(c.t * np.float32(np.exp(np.float32(c.d_tau)))) * np.float32(c.d_tau))
     e.step_explicit(dt, 1.0)
@@ -150,6 +167,19 @@ def test_full_size_slab_vs_oracle(eng, oracle_built):
     want = o.interior(out)
     fluid = o.interior([o.solid])[0] == 0
     assert fluid.sum() < fluid.size, "slab should intersect the body"
+    if warm == 60:
+        from tests.parity import conserved
+        worst = np.zeros(fluid.shape)
+        for g, w in zip(got[:4], want[:4]):
+            worst = np.maximum(worst, np.abs(g.astype(np.float64) - w))
+        Ug, _ = conserved(got)
+        Uw, sc = conserved(want)
+        for g, w, s in zip(Ug[:5], Uw[:5], sc[:5]):
+            worst = np.maximum(worst, np.abs(g - w) / s)
+        worst = worst[fluid]
+        assert int((worst > 1e-5).sum()) <= 3 and worst.max() <= 2.5e-5, (int((worst > 1e-5).sum()), worst.max())
+        e.close()
+        return
     r = assert_parity(got, want, mask=fluid, what="512^3 slab")
     print("512^3 slab parity", {k: f"{v:.2e}" for k, v in r.items()})
     e.close()
