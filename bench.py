@@ -198,10 +198,18 @@ def other_configs(f, torch, dev):
     for label, pre in (("lattice start (after 20 sub-steps)", 0), ("developed state (after 1500 more sub-steps)", 1500)):
         if pre:
             s.step_async(pre)
+        s.sync()
+        pairs0 = s.count_pairs()                       # ordered pairs inside the 2h support at the start of the timed window ...
         ms = _event_timed(torch, stream, lambda: s.step_async(200), s.sync)
+        pairs1 = s.count_pairs()                       # ... and at its end: each sub-step's density AND force pass evaluate every one of them
+        pair_rate = 0.5 * (pairs0 + pairs1) * 2 * 200 / ms / 1e6
         out.append({"config": f"tau_sph {N} particles, {label}", "steps": 200,
                     "value": round(N * 200 / ms / 1e6, 3), "unit": "Gparticle-sub-steps/s", "ms_per_step": round(ms / 200, 5),
-                    "roofline": _roof("sph sub-step (cell build + k_density + k_forces)", ms / 200, N, 100,
+                    "pair_interactions": {"value": round(pair_rate, 1), "unit": "G pair-interactions/s",
+                                          "neighbours_per_particle": round(0.5 * (pairs0 + pairs1) / N, 1),
+                                          "note": "ordered pairs (i, j) within 2h x 2 neighbour passes per sub-step; pair count = mean of the "
+                                                  "counts before and after the timed window (tausph_count_pairs)"},
+                    "roofline": _roof("sph sub-step (counting-sort cell build + k_density + k_forces)", ms / 200, N, 100,
                                       "valu (pair evaluation)")})
     s.close()
 

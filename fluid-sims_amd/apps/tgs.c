@@ -6,6 +6,7 @@
  * reference runs forever — here 0 selects 1000 steps so the program terminates.
  */
 #include "tau_cli.h"
+#include <getopt.h>
 
 static void usage(const char *prog) { /* :65-81 */
   printf("Usage: %s [options]\n", prog);
@@ -33,26 +34,34 @@ int main(int argc, char **argv) {
   int steps = 0;
   unsigned seed = 1337;
   const char *dump = NULL;
-  for (int i = 1; i < argc; i++) {
-    const char *a = argv[i];
-    const char *v = (i + 1 < argc) ? argv[i + 1] : NULL;
-    if (!strcmp(a, "-h") || !strcmp(a, "--help")) { usage(argv[0]); return 0; }
-    else if (!strcmp(a, "--headless") || !strcmp(a, "--halfblocks")) continue;
-    else if (!v) { fprintf(stderr, "%s: option '%s' requires an argument\n", argv[0], a); return 1; }
-    else if (!strcmp(a, "--nx")) P.nx = atoi(v);      /* atoi/atof as the reference parses them, :106-127 */
-    else if (!strcmp(a, "--ny")) P.ny = atoi(v);
-    else if (!strcmp(a, "--dx")) P.dx = (float)atof(v);
-    else if (!strcmp(a, "--dt")) P.dt = (float)atof(v);
-    else if (!strcmp(a, "--Du")) P.Du = (float)atof(v);
-    else if (!strcmp(a, "--Dv")) P.Dv = (float)atof(v);
-    else if (!strcmp(a, "--F")) P.feed = (float)atof(v);
-    else if (!strcmp(a, "--k")) P.kill = (float)atof(v);
-    else if (!strcmp(a, "--steps")) steps = atoi(v);
-    else if (!strcmp(a, "--stride") || !strcmp(a, "--fps")) { /* display only */ }
-    else if (!strcmp(a, "--seed")) seed = (unsigned)strtoul(v, NULL, 10);
-    else if (!strcmp(a, "--dump")) dump = v;
-    else { fprintf(stderr, "%s: unrecognized option '%s'\n", argv[0], a); return 1; }
-    i++;
+  /* getopt_long with the reference's own table (:84-104): `--nx 128`, `--nx=128` and unambiguous abbreviations all parse,
+     unknown options get getopt's message and are skipped — as there.  --dump is additive. */
+  static const struct option long_opts[] = {
+      {"nx", required_argument, 0, 0},     {"ny", required_argument, 0, 0},    {"dx", required_argument, 0, 0},
+      {"dt", required_argument, 0, 0},     {"Du", required_argument, 0, 0},    {"Dv", required_argument, 0, 0},
+      {"F", required_argument, 0, 0},      {"k", required_argument, 0, 0},     {"steps", required_argument, 0, 0},
+      {"headless", no_argument, 0, 0},     {"stride", required_argument, 0, 0}, {"fps", required_argument, 0, 0},
+      {"seed", required_argument, 0, 0},   {"halfblocks", no_argument, 0, 0},  {"dump", required_argument, 0, 0},
+      {"help", no_argument, 0, 'h'},       {0, 0, 0, 0}};
+  for (;;) {
+    int idx = 0;
+    const int c = getopt_long(argc, argv, "h", long_opts, &idx);
+    if (c == -1) break;
+    if (c == 'h') { usage(argv[0]); return 0; }
+    if (c) continue;
+    const char *opt = long_opts[idx].name;    /* atoi / atof as the reference parses them, :106-127 */
+    if (!strcmp(opt, "nx")) P.nx = atoi(optarg);
+    else if (!strcmp(opt, "ny")) P.ny = atoi(optarg);
+    else if (!strcmp(opt, "dx")) P.dx = (float)atof(optarg);
+    else if (!strcmp(opt, "dt")) P.dt = (float)atof(optarg);
+    else if (!strcmp(opt, "Du")) P.Du = (float)atof(optarg);
+    else if (!strcmp(opt, "Dv")) P.Dv = (float)atof(optarg);
+    else if (!strcmp(opt, "F")) P.feed = (float)atof(optarg);
+    else if (!strcmp(opt, "k")) P.kill = (float)atof(optarg);
+    else if (!strcmp(opt, "steps")) steps = atoi(optarg);
+    else if (!strcmp(opt, "seed")) seed = (unsigned)strtoul(optarg, NULL, 10);
+    else if (!strcmp(opt, "dump")) dump = optarg;
+    /* headless, halfblocks, stride, fps: display only */
   }
   if (P.nx == 0) P.nx = 128;
   if (P.ny == 0) P.ny = 128;

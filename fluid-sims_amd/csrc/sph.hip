@@ -4,11 +4,20 @@
 // atomicExch: nondeterministic order, pointer chasing) -> k_density_pressure_cell -> k_forces_cell ->
 // k_integrate; every neighbour visit is a dependent global load.
 //
-// Here the uniform grid is rebuilt by a DETERMINISTIC counting order instead of linked lists:
-//   1. k_keys      cell index of every particle (same float divide + floor + clamp as
-//                  grid_x/grid_y, :141-157 — the integer index is bit-exact)
-//   2. radix sort  (cell, particle id) pairs — stable, so particles inside a cell are in ascending id
-//   3. k_cell_start / k_gather   cell -> [start, end) ranges; particle records gathered into cell order
+// Here the uniform grid is rebuilt by a DETERMINISTIC counting sort instead of linked lists (k_clear_heads / k_build_cells,
+// :159-176; all hand-written, no sort library):
+//   1. k_count     cell index of every particle (same float divide + floor + clamp as grid_x/grid_y, :141-157 — the
+//                  integer index is bit-exact) and a slot inside its cell: one atomicAdd per (wave, cell) — the lanes of a
+//                  wave that share a cell are found with ballots and ranked with a popcount of the lanes below
+//   2. k_tile_sums / k_scan   exclusive prefix of the per-cell counts -> cellStart[M + 1] (two small launches, no
+//                  inter-workgroup waiting); the counts are zeroed for the next sub-step on the way
+//   3. k_scatter   particle id -> cellStart[cell] + slot: every cell's particles are now contiguous, in the order the
+//                  atomics happened to run
+//   4. k_rank_gather   restores the order a stable sort would give: a particle's place in its cell is the number of
+//                  ids in that cell's segment below its own (n ~ 16 loads per particle, all lanes of a cell reading the
+//                  same words); the records are gathered into that place (16-B + 8-B, cell order)
+//   So cells ascend, ids ascend inside a cell — bit-identical lists run after run and identical to the stable radix sort
+//   this replaces (rounds 1-2: hipcub::DeviceRadixSort, six rocPRIM dispatches per sub-step).
 //   4. k_density   one lane per (sorted) particle; the three cells of a grid row are ONE contiguous
 //                  record range, so a particle walks 3 ranges of ~48 contiguous 16-B records instead of
 //                  9 linked lists; the 64 lanes of a wave sit in ~4 neighbouring cells and read the
@@ -20,7 +29,6 @@
 
 #include "../../include/taueng.h"
 #include "tau_common.h"
-#include <hipcub/hipcub.hpp>
 #include <cmath>
 #include <new>
 #include <random>
@@ -36,7 +44,9 @@ struct Args {
   float2 *pos, *vel, *acc;
   float *s, *press;
   int *cellOf;
-  unsigned *keys, *ids, *keys_s, *ids_s;
+  unsigned *keys, *ids, *keys_s, *ids_s;   // per particle: cell, slot in the cell; per sorted place: cell, particle id
+  unsigned *tmpKey, *tmpId;                // per scattered place (cells contiguous, order inside a cell not yet fixed)
+  unsigned *cellCount, *tileSum;           // particles per cell (M + 1 padded to whole scan tiles; zero between sub-steps), sums per scan tile
   int *cellStart;     // M + 1
   float4 *recA;       // sorted: x, y, vx, vy
   float2 *recB;       // sorted: p / rho^2, rho
@@ -54,36 +64,154 @@ __device__ __forceinline__ int grid_c(float x, float cell, int G) { // grid_x / 
 }
 __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
 
-__global__ __launch_bounds__(256) void k_keys(const Args A) { // k_build_cells' index arithmetic, :170-174
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= A.N) return;
-  float2 p = A.pos[i];
-  int c = grid_c(p.y, A.cell, A.Gy) * A.Gx + grid_c(p.x, A.cell, A.Gx);
-  A.keys[i] = (unsigned)c;
-  A.ids[i] = (unsigned)i;
-  A.cellOf[i] = c;
-}
+// ---- cell build: counting sort --------------------------------------------------------------------
+constexpr int SCAN_T = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_T * SCAN_ITEMS;   // cells per scan workgroup
 
-// cellStart[c] = first sorted slot whose key is >= c (lower bound), one lane per cell: empty cells
-// and the empty top of the box cost a 22-step binary search each instead of a serial fill
-__global__ __launch_bounds__(256) void k_cell_start(const Args A) {
-  int c = blockIdx.x * 256 + threadIdx.x;
-  if (c > A.M) return;
-  int lo = 0, hi = A.N;
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if ((int)A.keys_s[mid] < c) lo = mid + 1; else hi = mid;
+__global__ __launch_bounds__(256) void k_count(const Args A) { // k_build_cells' index arithmetic, :170-174, + the slot
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < A.N;
+  unsigned c = 0xFFFFFFFFu;
+  if (valid) {
+    const float2 p = A.pos[i];
+    c = (unsigned)(grid_c(p.y, A.cell, A.Gy) * A.Gx + grid_c(p.x, A.cell, A.Gx));
+    A.keys[i] = c;
+    A.cellOf[i] = (int)c;
   }
-  A.cellStart[c] = lo;
+  // One atomicAdd per RUN of consecutive lanes in the same cell (ids are spatially coherent: neighbouring ids mostly share a
+  // cell): run heads from a compare with the lane below, a ballot of the heads, and bit arithmetic on it give every lane
+  // its run's head lane, its rank in the run and the run's length — no loop, whatever the particle order (scattered ids
+  // degrade to one atomic per lane, never to more work per lane).  Two runs of one cell in a wave are simply two atomics.
+  const unsigned lane = __lane_id();
+  const unsigned cprev = (unsigned)__shfl_up((int)c, 1, 64);
+  const bool head = valid && (lane == 0u || c != cprev);
+  const unsigned long long heads = __ballot(head), vmask = __ballot(valid);
+  const unsigned long long below = heads & (~0ull >> (63u - lane));            // heads at or below this lane
+  const int hl = below ? 63 - __clzll((long long)below) : 0;
+  const unsigned long long above = (lane == 63u) ? 0ull : (heads >> (lane + 1u)) << (lane + 1u);   // heads above this lane
+  const int nexth = above ? (__ffsll((long long)above) - 1) : (64 - __clzll((long long)(vmask | 1ull)));   // (valid lanes are a prefix of the wave)
+  unsigned base = 0;
+  if (head) base = atomicAdd(&A.cellCount[c], (unsigned)(nexth - (int)lane));
+  base = (unsigned)__shfl((int)base, hl, 64);
+  if (valid) A.ids[i] = base + (lane - (unsigned)hl);
 }
 
-__global__ __launch_bounds__(256) void k_gather(const Args A) {
-  int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= A.N) return;
-  unsigned id = A.ids_s[k];
-  float2 p = A.pos[id], v = A.vel[id];
-  A.recA[k] = make_float4(p.x, p.y, v.x, v.y);
-  A.recP[k] = p;
+// exclusive prefix of cellCount[0 .. M] (M + 1 entries: entry M is always 0, so cellStart[M] = N).  Every workgroup of k_scan
+// first adds up what lies below its 4096-cell tile — the raw counts themselves while there are at most DIRECT_TILES tiles
+// (one launch: 65 536 particles are two tiles), else the tile sums of a k_tile_sums launch — and then scans its tile.  No
+// workgroup ever waits for another.  (k_rank_gather clears the counts for the next sub-step.)
+constexpr int DIRECT_TILES = 16;
+__device__ __forceinline__ unsigned block_sum_256(unsigned v, unsigned *sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const unsigned t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+__global__ __launch_bounds__(SCAN_T) void k_tile_sums(const Args A) {
+  __shared__ unsigned sh[4];
+  const uint4 *src = (const uint4 *)(A.cellCount + (size_t)blockIdx.x * SCAN_TILE);
+  unsigned v = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS / 4; k++) { const uint4 q = src[k * SCAN_T + threadIdx.x]; v += q.x + q.y + q.z + q.w; }
+  v = block_sum_256(v, sh);
+  if (threadIdx.x == 0) A.tileSum[blockIdx.x] = v;
+}
+__global__ __launch_bounds__(SCAN_T) void k_scan(const Args A, int ntiles) {
+  __shared__ unsigned sh[4];
+  __shared__ unsigned swave[4];
+  const int tid = threadIdx.x, tile = blockIdx.x;
+  unsigned before = 0;                                   // particles in the tiles below this one
+  if (ntiles > DIRECT_TILES) {
+    for (int t = tid; t < tile; t += SCAN_T) before += A.tileSum[t];
+    before = block_sum_256(before, sh);
+  } else if (tile > 0) {
+    const uint4 *lowc = (const uint4 *)A.cellCount;
+    for (int t = tid; t < tile * (SCAN_TILE / 4); t += SCAN_T) { const uint4 q = lowc[t]; before += q.x + q.y + q.z + q.w; }
+    before = block_sum_256(before, sh);
+  }
+  // 16 consecutive cells per thread
+  const uint4 *cnt = (const uint4 *)(A.cellCount + (size_t)tile * SCAN_TILE) + tid * (SCAN_ITEMS / 4);
+  unsigned v[SCAN_ITEMS];
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS / 4; k++) {
+    const uint4 q = cnt[k];
+    v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+  }
+  unsigned tsum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) tsum += v[k];
+  // exclusive scan of the 256 thread sums: inclusive wave scan, then the wave totals
+  unsigned inc = tsum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned n = (unsigned)__shfl_up((int)inc, o, 64); if ((tid & 63) >= o) inc += n; }
+  if ((tid & 63) == 63) swave[tid >> 6] = inc;
+  __syncthreads();
+  unsigned wbase = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++) wbase += (w < (tid >> 6)) ? swave[w] : 0u;
+  unsigned run = before + wbase + (inc - tsum);
+  const size_t c0 = (size_t)tile * SCAN_TILE + (size_t)tid * SCAN_ITEMS;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (c0 + k <= (size_t)A.M) A.cellStart[c0 + k] = (int)run;
+    run += v[k];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const Args A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.N) return;
+  const unsigned c = A.keys[i];
+  const unsigned p = (unsigned)A.cellStart[c] + A.ids[i];
+  A.tmpKey[p] = c;
+  A.tmpId[p] = (unsigned)i;
+}
+
+// place p of the scattered order -> place s + (number of ids of the cell below its own): ascending ids inside the cell,
+// what k_build_cells' lists would hold if its atomics ran in id order (:165-176).  Also the gather of the records.
+__global__ __launch_bounds__(256) void k_rank_gather(const Args A, int ncount) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  for (int q = p; q < ncount; q += gridDim.x * 256) A.cellCount[q] = 0u;   // the counts have been scanned: zero for the next build
+  if (p >= A.N) return;
+  const unsigned c = A.tmpKey[p], id = A.tmpId[p];
+  const int s = A.cellStart[c], e = A.cellStart[c + 1];
+  int r = 0;
+  for (int q = s; q < e; q++) r += (A.tmpId[q] < id) ? 1 : 0;
+  const int k = s + r;
+  A.keys_s[k] = c;
+  A.ids_s[k] = id;
+  const float2 pp = A.pos[id], v = A.vel[id];
+  A.recA[k] = make_float4(pp.x, pp.y, v.x, v.y);
+  A.recP[k] = pp;
+}
+
+// ordered pairs (i, j), i != j, closer than 2h among the records of the last build — what the density and force passes of
+// that sub-step evaluated (diagnostic: bench.py's pair-interactions/s; not part of a step)
+__global__ __launch_bounds__(256) void k_count_pairs(const Args A, unsigned long long *out) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long n = 0;
+  if (k < A.N) {
+    const float2 me = A.recP[k];
+    const int c = (int)A.keys_s[k];
+    const int gy = c / A.Gx, gx = c - gy * A.Gx;
+    const int cxlo = max(gx - 1, 0), cxhi = min(gx + 1, A.Gx - 1);
+    const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
+    for (int oy = -1; oy <= 1; ++oy) {
+      const int cy = gy + oy;
+      if ((unsigned)cy >= (unsigned)A.Gy) continue;
+      const int j0 = A.cellStart[cy * A.Gx + cxlo], j1 = A.cellStart[cy * A.Gx + cxhi + 1];
+      for (int j = j0; j < j1; j++) {
+        const float2 o = A.recP[j];
+        const float dx = me.x - o.x, dy = me.y - o.y;
+        n += (j != k && dx * dx + dy * dy < twoh2) ? 1ull : 0ull;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_xor(n, o, 64);
+  if ((threadIdx.x & 63) == 0 && n) atomicAdd(out, n);
 }
 
 __device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :105-116
@@ -476,9 +604,8 @@ struct tausph {
   hipStream_t stream;
   bool own_stream;
   sph::Args a;
-  void *cub_tmp;
-  size_t cub_bytes;
-  int key_bits;
+  int ntiles;        // scan tiles of the cell counts
+  unsigned long long *pairs;   // device word of tausph_count_pairs (lazy)
   float tau, t;
   long step;
   float rain_carry;
@@ -529,6 +656,11 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipMalloc(&A.keys, N * 4)); TAU_HIP(hipMalloc(&A.ids, N * 4));
   TAU_HIP(hipMalloc(&A.keys_s, N * 4)); TAU_HIP(hipMalloc(&A.ids_s, N * 4));
   TAU_HIP(hipMalloc(&A.cellStart, ((size_t)A.M + 1) * sizeof(int)));
+  TAU_HIP(hipMalloc(&A.tmpKey, N * 4)); TAU_HIP(hipMalloc(&A.tmpId, N * 4));
+  h->ntiles = (int)(((size_t)A.M + 1 + sph::SCAN_TILE - 1) / sph::SCAN_TILE);
+  TAU_HIP(hipMalloc(&A.cellCount, (size_t)h->ntiles * sph::SCAN_TILE * sizeof(unsigned)));
+  TAU_HIP(hipMalloc(&A.tileSum, (size_t)h->ntiles * sizeof(unsigned)));
+  TAU_HIP(hipMemsetAsync(A.cellCount, 0, (size_t)h->ntiles * sph::SCAN_TILE * sizeof(unsigned), h->stream));   // k_scan leaves it zero again
   TAU_HIP(hipMalloc(&A.recA, N * sizeof(float4))); TAU_HIP(hipMalloc(&A.recB, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.recP, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.nbrMask, N * sizeof(unsigned) * 12));
@@ -546,12 +678,6 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   // 0.64-0.87 vs 0.29-0.45 ms)
   h->lpp = (P->N < (1 << 17)) ? 4 : 1;
   if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 4) h->lpp = v; }
-  h->key_bits = 1;
-  while ((1 << h->key_bits) < A.M) h->key_bits++;
-  h->cub_tmp = nullptr; h->cub_bytes = 0;
-  TAU_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, h->cub_bytes, A.keys, A.keys_s, A.ids, A.ids_s, (int)N, 0,
-                                             h->key_bits, h->stream));
-  TAU_HIP(hipMalloc(&h->cub_tmp, h->cub_bytes));
   h->tau = 0.f; h->t = P->t0 * expf(h->tau); h->step = 0; // :577-578
   *out = guard.release();
   return 0;
@@ -563,7 +689,8 @@ extern "C" void tausph_destroy(tausph_t *h) {
   sph::Args &A = h->a;
   hipFree(A.pos); hipFree(A.vel); hipFree(A.acc); hipFree(A.s); hipFree(A.press); hipFree(A.cellOf);
   hipFree(A.keys); hipFree(A.ids); hipFree(A.keys_s); hipFree(A.ids_s); hipFree(A.cellStart);
-  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(A.recA2); hipFree(A.rainWinner); hipFree(h->raster); hipFree(h->cub_tmp);
+  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(A.recA2); hipFree(A.rainWinner); hipFree(h->raster);
+  hipFree(A.tmpKey); hipFree(A.tmpId); hipFree(A.cellCount); hipFree(A.tileSum); hipFree(h->pairs);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -633,14 +760,19 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
   sph::Args A = h->a;
   A.dt = dt;
   const unsigned gs = (unsigned)((A.N + 255) / 256);
-  hipLaunchKernelGGL(sph::k_keys, dim3(gs), dim3(256), 0, h->stream, A);
-  TAU_LAUNCH_CHECK("sph::k_keys");
-  TAU_HIP(hipcub::DeviceRadixSort::SortPairs(h->cub_tmp, h->cub_bytes, A.keys, A.keys_s, A.ids, A.ids_s, A.N, 0,
-                                             h->key_bits, h->stream));
-  hipLaunchKernelGGL(sph::k_cell_start, dim3((unsigned)((A.M + 1 + 255) / 256)), dim3(256), 0, h->stream, A);
-  TAU_LAUNCH_CHECK("sph::k_cell_start");
-  hipLaunchKernelGGL(sph::k_gather, dim3(gs), dim3(256), 0, h->stream, A);
-  TAU_LAUNCH_CHECK("sph::k_gather");
+  // the cell build (k_clear_heads + k_build_cells, :159-176): counting sort, four or five small launches
+  hipLaunchKernelGGL(sph::k_count, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_count");
+  if (h->ntiles > sph::DIRECT_TILES) {
+    hipLaunchKernelGGL(sph::k_tile_sums, dim3((unsigned)h->ntiles), dim3(sph::SCAN_T), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_tile_sums");
+  }
+  hipLaunchKernelGGL(sph::k_scan, dim3((unsigned)h->ntiles), dim3(sph::SCAN_T), 0, h->stream, A, h->ntiles);
+  TAU_LAUNCH_CHECK("sph::k_scan");
+  hipLaunchKernelGGL(sph::k_scatter, dim3(gs), dim3(256), 0, h->stream, A);
+  TAU_LAUNCH_CHECK("sph::k_scatter");
+  hipLaunchKernelGGL(sph::k_rank_gather, dim3(gs), dim3(256), 0, h->stream, A, h->ntiles * sph::SCAN_TILE);
+  TAU_LAUNCH_CHECK("sph::k_rank_gather");
   // four lanes per particle while there are too few particles to fill the chip with one
   if (h->lpp == 4) {
     const unsigned gq = (unsigned)((A.N + 63) / 64);
@@ -710,6 +842,19 @@ extern "C" int tausph_rasterize(tausph_t *h, int W, int H, int32_t *host_grid2) 
   return 0;
 }
 extern "C" int64_t tausph_rain_spawned(tausph_t *h) { return (int64_t)h->rain_spawned; }
+extern "C" int tausph_count_pairs(tausph_t *h, int64_t *ordered_pairs) {
+  if (!h || !ordered_pairs) return tau::fail("tausph_count_pairs: null argument");
+  TAU_HIP(hipSetDevice(h->device));
+  if (!h->pairs) TAU_HIP(hipMalloc(&h->pairs, sizeof(unsigned long long)));
+  TAU_HIP(hipMemsetAsync(h->pairs, 0, sizeof(unsigned long long), h->stream));
+  hipLaunchKernelGGL(sph::k_count_pairs, dim3((unsigned)((h->a.N + 255) / 256)), dim3(256), 0, h->stream, h->a, h->pairs);
+  TAU_LAUNCH_CHECK("sph::k_count_pairs");
+  unsigned long long v = 0;
+  TAU_HIP(hipMemcpyAsync(&v, h->pairs, sizeof v, hipMemcpyDeviceToHost, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
+  *ordered_pairs = (int64_t)v;
+  return 0;
+}
 extern "C" int tausph_sync(tausph_t *h) {
   TAU_HIP(hipSetDevice(h->device));
   TAU_HIP(hipStreamSynchronize(h->stream));

@@ -209,6 +209,7 @@ def load():
         "taulbm_sync": ([vp], i32),
         "tausph_rasterize": ([vp, i32, i32, vp], i32),
         "tausph_rain_spawned": ([vp], C.c_int64),
+        "tausph_count_pairs": ([vp, C.POINTER(C.c_int64)], i32),
         "tauflow_params_default": ([C.POINTER(FlowParams), i32, i32, i32], None),
         "tauflow_create": ([C.POINTER(vp), C.POINTER(FlowParams), i32, i32, vp], i32),
         "tauflow_destroy": ([vp], None),
@@ -686,6 +687,12 @@ class Sph2D:
 
     def rain_spawned(self):
         return int(self._L.tausph_rain_spawned(self._h))
+
+    def count_pairs(self):
+        """ordered pairs (i != j) inside the 2h support among the records of the last cell build"""
+        n = C.c_int64()
+        _ck(self._L.tausph_count_pairs(self._h, C.byref(n)))
+        return n.value
 
 
 class Lbm2D:

@@ -274,6 +274,9 @@ int tausph_sync(tausph_t *h);
  * particle) are resolved deterministically: the highest drop index wins. */
 int tausph_rasterize(tausph_t *h, int W, int H, int32_t *host_grid2);        /* k_clear_grid + k_rasterize, :357-374: W x 2H counts */
 int64_t tausph_rain_spawned(tausph_t *h);                                    /* drops spawned so far */
+/* diagnostic: ordered pairs (i, j), i != j, closer than the 2h support among the records of the LAST cell build — the
+ * pair interactions each neighbour pass of that sub-step evaluated (needs at least one sub-step) */
+int tausph_count_pairs(tausph_t *h, int64_t *ordered_pairs);
 
 /* =====================================================================
  * Gray-Scott — replaces step_kernel launch + swap, tau_gray_scott.cu:321-329

@@ -73,6 +73,41 @@ def test_gpu_programs_refuse_without_gpu(built):
         assert r.returncode == 1 and "no CPU path" in r.stderr
 
 
+def test_getopt_long_forms_without_gpu(built):
+    """the reference's getopt_long tables accept `--opt=value` and unambiguous abbreviations (tau_gray_scott.cu:84-104,
+    tau_sph.cu:395-418): parsing gets past them (to the no-GPU refusal on this box), unknown options get getopt's message"""
+    import fluid_sims_amd as f
+    if f.load().tau_device_available():
+        pytest.skip("a GPU is visible")
+    for cmd in (["tgs", "--nx=64", "--ny", "32", "--st=5", "--F=0.03"], ["tau_sph", "--n=4096", "--dTau=1e-3", "-s", "7"],
+                ["tau_burgers", "--nx=64", "--ny=64"], ["tau_lbm", "--nx=64", "--no-obstacle"]):
+        r = run(os.path.join(built, cmd[0]), *cmd[1:])
+        assert r.returncode == 1 and "no CPU path" in r.stderr and "unrecognized" not in r.stderr, (cmd, r.stderr)
+    r = run(os.path.join(built, "tgs"), "--bogus")
+    assert "unrecognized option '--bogus'" in r.stderr
+
+
+def test_tau3d_multi_rank_refuses_without_gpu(built):
+    """tau3d --gpus N forks its ranks before touching the HIP runtime; each rank reports the missing device itself"""
+    import fluid_sims_amd as f
+    if f.load().tau_device_available():
+        pytest.skip("a GPU is visible")
+    r = run(os.path.join(built, "tau3d"), "--n", "32", "--frames", "1", "--gpus", "2", "--transport", "host")
+    assert r.returncode == 1 and r.stderr.count("no CPU path") == 2 and "rank 1 exited with 1" in r.stderr
+    assert run(os.path.join(built, "tau3d"), "--gpus", "0").returncode == 1
+    assert "rccl | host" in run(os.path.join(built, "tau3d"), "--transport", "mpi").stderr
+
+
+@pytest.mark.gpu
+def test_tgs_getopt_forms(built):
+    """`--nx=64 --st=20` (getopt_long forms of the reference, tau_gray_scott.cu:95-104) run the same problem as the spaced forms"""
+    a = run(os.path.join(built, "tgs"), "--nx=64", "--ny=48", "--st=20", "--seed=5")
+    b = run(os.path.join(built, "tgs"), "--nx", "64", "--ny", "48", "--steps", "20", "--seed", "5")
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert re.search(r"sum u = \S+, sum v = \S+", a.stdout).group(0) == re.search(r"sum u = \S+, sum v = \S+", b.stdout).group(0)
+    assert "20 steps on 64x48" in a.stdout
+
+
 @pytest.mark.gpu
 def test_tgs_end_to_end(built):
     g = GOLD["gray_scott_128sq_100steps"]
