@@ -627,16 +627,15 @@ struct StepLds {
   float sFy[6][TY + 1][TX];      // low-y face flux of cell (y, x); row TY = far edge
   float sRed[2][NT / 64];
 };
-template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, StepLds &S) {
+// `b`: linear work item (tile x, tile y, z chunk) of this pass; dt, gain: the step's clock; maxw: the step's two max words
+template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, StepLds &S, unsigned b, const float dt, const float gain,
+                                                               unsigned *maxw) {
   auto &sP = S.sP; auto &sS = S.sS; auto &sFx = S.sFx; auto &sFy = S.sFy; auto &sRed = S.sRed;
 
   const int tid = threadIdx.x;
   const int tx = tid & (TX - 1), ty = tid >> 5;
   const int lane = tid & 63, wave = tid >> 6;
 
-  // linear block id -> (tile x, tile y, z chunk), XCD-contiguous
-  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
-  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
   const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
   const int by = (int)(b % (unsigned)A.nty);
   const int bz = (int)(b / (unsigned)A.nty);
@@ -650,9 +649,6 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
   const int yw = (y >= A.ny) ? y - A.ny : y;   // partial tiles: own column is a wrapped / ghost column
   const size_t plane_n = (size_t)A.nx * A.ny;
   const size_t col = (size_t)yw * A.nx + min(x, A.nx - 1);
-
-  const float dt = A.clk->dt;
-  const float gain = A.clk->gain;
 
   // own column: planes z-1 .. z+3 around the current plane z (W[1] is the cell being updated)
   float W[5][6];
@@ -882,8 +878,8 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
         float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
         if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
         fmx = fmaxf(fmaxf(fmx, r1), fabsf(u1));            // three v_max3_f32 (a balanced tree of fmaxf compiles to six v_max_f32)
-  fmx = fmaxf(fmaxf(fmx, fabsf(v1)), fabsf(w1));
-  fmx = fmaxf(fmaxf(fmx, p1), ev1);
+        fmx = fmaxf(fmaxf(fmx, fabsf(v1)), fabsf(w1));
+        fmx = fmaxf(fmaxf(fmx, p1), ev1);
 
         A.out[0][gi] = flog(fmaxf(r1, RHO_P_FLOOR)); // :1353-1358
         A.out[1][gi] = fasinh(u1 * A.inv_u_ref);
@@ -914,15 +910,18 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
     float m = sRed[tid][0];
 #pragma unroll
     for (int k = 1; k < NW; k++) m = fmaxf(m, sRed[tid][k]);
-    tau::atomic_max_float_bits(tid ? &A.clk->fmax_bits : &A.clk->maxs_bits, m);
+    tau::atomic_max_float_bits(maxw + tid, m);
   }
 }
 
 __global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
   __shared__ StepLds S;
+  // linear block id -> work item, XCD-contiguous
+  const unsigned b = tau::xcd_swizzle(blockIdx.x, (unsigned)(A.ntx * A.nty * A.nzc));
+  const float dt = A.clk->dt, gain = A.clk->gain;
   // one scalar decision for the whole launch (see WLAM above)
-  if (fast_form(A.clk->fmax_in, A.in_fmax)) step_body<true>(A, S);
-  else step_body<false>(A, S);
+  if (fast_form(A.clk->fmax_in, A.in_fmax)) step_body<true>(A, S, b, dt, gain, &A.clk->maxs_bits);
+  else step_body<false>(A, S, b, dt, gain, &A.clk->maxs_bits);
 }
 
 // ---------------------------------------------------------------- the split step: k_flux_xy + k_update_z
@@ -1611,6 +1610,14 @@ __global__ void k_clock_set_explicit(DevClock *c, float dt, float gain) {
   c->dt = dt; c->gain = gain; c->maxs_bits = 0u;
   field_max_commit(c);
 }
+// ---- small grids.  A 64^3 step is two dependent dispatches (halo copy + clock, k_step): 38.7 us, of which a 32^3 step — almost
+// no work — already costs 26.5.  Measured in round 3 and NOT kept: a hipGraph of the same launches replays at the
+// same pace (37.7 us: the latency is on the device, between dependent dispatches and inside k_step's own chain of loads and
+// barriers); the whole step loop as ONE resident cooperative grid (periodic z wrap instead of the halo copy, a clock replica
+// per workgroup instead of the clock kernel, triple-buffered max words, one grid barrier per step) was bit-identical with
+// cooperative_groups::grid.sync() but slower at every size — 29.9 / 61.1 / 86.4 / 170 us per step at 32^3 / 48^3 / 64^3 / 96^3
+// against 26.5 / 37.0 / 38.6 / 93.4 — and no faster with a hand-written arrival-counter barrier (28.8 / 53.6 / 80.9 / 144).
+
 // largest |primitive| of planes [zh_lo, zh_hi) of the halo layout, folded into fmax_bits (after init / upload)
 __global__ __launch_bounds__(256) void k_field_max(Args A, int zh_lo, int zh_hi) {
   __shared__ float red[4];
