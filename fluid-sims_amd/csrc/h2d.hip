@@ -622,6 +622,9 @@ struct MRing {
   __device__ __forceinline__ void put(int slot, const MCell &q) const {
     w[slot][0][lane] = q.c.r; w[slot][1][lane] = q.c.mx; w[slot][2][lane] = q.c.my; w[slot][3][lane] = q.c.E;
     w[slot][4][lane] = __int_as_float((int)q.m | ((int)q.in << 1));
+    // get() / fld() of OTHER lanes read what this lane just wrote: the wave barrier (no instruction, a scheduling fence) keeps
+    // the compiler from ever moving such a read above the stores, whatever its alias analysis concludes about constant slots
+    __builtin_amdgcn_wave_barrier();
   }
   __device__ __forceinline__ MCell get(int slot, int d) const {   // the cell d lanes below (d > 0) / above; own value at the wave's ends
     const int l = min(max(lane - d, 0), 63);
@@ -841,8 +844,11 @@ __global__ void k_unit(const Args A, float *out) {
 __global__ void k_unit_neighbors(const Args A, int x, int y, float *out) {
   const size_t ic = (size_t)y * A.W + x;
   const C4 wg = wall_ghost(A, c2p(A, C4{A.in[0][ic], A.in[1][ic], A.in[2][ic], A.in[3][ic]}));
-  const C4 left = ghost_sel(wg, march_load(A, x - 1, y, 0)), right = ghost_sel(wg, march_load(A, x + 1, y, 0)),
-           up = ghost_sel(wg, march_load(A, x, y + 1, 0)), top = ghost_sel(wg, march_load(A, x, A.H + 20, 0));
+  // row0 = the (clamped) row each lookup reads: march_load's 32-bit offsets are relative to it and stay small on any grid
+  // (with row0 = 0 they span the whole grid and wrap from 2^30 cells on)
+  auto rowc = [&](int r) { return max(0, min(r, A.H - 1)); };
+  const C4 left = ghost_sel(wg, march_load(A, x - 1, y, rowc(y))), right = ghost_sel(wg, march_load(A, x + 1, y, rowc(y))),
+           up = ghost_sel(wg, march_load(A, x, y + 1, rowc(y + 1))), top = ghost_sel(wg, march_load(A, x, A.H + 20, rowc(A.H + 20)));
   out[0] = left.r; out[1] = left.mx; out[2] = right.r; out[3] = right.mx; out[4] = up.mx;     // k_test_neighbors
   out[5] = left.r; out[6] = left.mx; out[7] = up.mx; out[8] = top.r;                          // k_test_neighbor_for_diff
 }

@@ -68,3 +68,25 @@ def test_mask_and_conservation_sanity(cpu2d):
     s.step(5)
     st = s.state()
     assert np.isfinite(st).all() and (st[..., 0] > 0).all()
+
+
+def test_fields_match_reference_fixture_bit_for_bit(cpu2d):
+    """SURVEY §8c fixture (ii) for config C1: whole fields, not checksums.  tests/golden/cpu2d_ref_96x64_steps12_13.npz holds
+    what the reference's own tau_hypersonic.c (W, H patched to 96 x 64) produced after 12 and after 13 steps — data written
+    by scripts/regen_checkvalues.sh in the build container.  The restated solver must reproduce both states exactly, and the
+    13th step from the fixture's 12-step state likewise (a single step on developed flow)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cpu2d_ref_96x64_steps12_13.npz"))
+    W, H = int(g["W"]), int(g["H"])
+    s = cpu2d.CpuHypersonic2D(W, H)
+    assert np.array_equal(s.mask(), g["mask"])
+    s.step(int(g["steps0"]))
+    st = s.state()                               # (H, W, 4) AoS: rho, mx, my, E
+    assert s.t == float(g["t0"])
+    for k in range(4):
+        assert np.array_equal(st[:, :, k], g["U0"][k]), f"field {k} after {int(g['steps0'])} steps"
+    s.step(1)
+    st = s.state()
+    assert s.t == float(g["t1"])
+    for k in range(4):
+        assert np.array_equal(st[:, :, k], g["U1"][k]), f"field {k} after {int(g['steps1'])} steps"
+    assert np.abs(g["U1"][1] - g["U0"][1]).max() > 1.0   # the fixture is a developed, changing flow
