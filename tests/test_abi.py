@@ -44,3 +44,16 @@ def test_no_cpu_fallback():
     for ctor in (lambda: f.Tau3D(32), lambda: f.GrayScott(64, 64), lambda: f.Laplacian2D(64, 64, "sw", 0.1, 0.1)):
         with pytest.raises(f.TauError):
             ctor()
+
+
+def test_slab_bounds_without_gpu():
+    """tau3d_slab_bounds (the C ring's partition, csrc/ring.hip) against fluid-sims_amd/slab.py's: contiguous, covering, >= 6 planes"""
+    import fluid_sims_amd as f
+    from importlib import import_module
+    slab = import_module("fluid_sims_amd.slab")
+    for nz, world in ((512, 8), (64, 3), (50, 4), (48, 8), (13, 2)):
+        got = [f.slab_bounds(nz, world, r) for r in range(world)]
+        assert got == [slab.slab_bounds(nz, world, r) for r in range(world)]
+        assert got[0][0] == 0 and sum(n for _, n in got) == nz and all(a[0] + a[1] == b[0] for a, b in zip(got, got[1:]))
+    with pytest.raises(f.TauError, match="need >= 6"):
+        f.slab_bounds(40, 8, 0)
