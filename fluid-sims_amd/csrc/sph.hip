@@ -55,6 +55,7 @@ struct Args {
   float4 *recA2;      // sorted: x, y, vx, vy AFTER the integrate (only when XSPH is on)
   int *rainWinner;    // per particle: highest drop index that picked it this launch, else -1 (only with rain)
   float xsphEps;
+  int countNext;      // k_forces also counts its moved particles into the cells of the NEXT build (k_count's work, fused)
 };
 
 __device__ __forceinline__ int grid_c(float x, float cell, int G) { // grid_x / grid_y, :141-157
@@ -67,6 +68,27 @@ __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x)
 // ---- cell build: counting sort --------------------------------------------------------------------
 constexpr int SCAN_T = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_T * SCAN_ITEMS;   // cells per scan workgroup
 
+// A particle's slot inside its cell for the next scatter: one atomicAdd per RUN of consecutive lanes in the same cell (lanes are
+// consecutive particle ids in k_count, consecutive sorted places in k_forces: neighbouring lanes mostly share a cell): run heads
+// from a compare with the lane below, a ballot of the heads, and bit arithmetic on it give every lane its run's head lane, its
+// rank in the run and the run's length — no loop, whatever the particle order (scattered cells degrade to one atomic per lane,
+// never to more work per lane).  Two runs of one cell in a wave are simply two atomics.  The valid lanes must be a prefix of
+// the wave's active lanes; call it from converged code.
+__device__ __forceinline__ unsigned cell_slot(const Args &A, unsigned c, bool valid) {
+  const unsigned lane = __lane_id();
+  const unsigned cprev = (unsigned)__shfl_up((int)c, 1, 64);
+  const bool head = valid && (lane == 0u || c != cprev);
+  const unsigned long long heads = __ballot(head), vmask = __ballot(valid);
+  const unsigned long long below = heads & (~0ull >> (63u - lane));            // heads at or below this lane
+  const int hl = below ? 63 - __clzll((long long)below) : 0;
+  const unsigned long long above = (lane == 63u) ? 0ull : (heads >> (lane + 1u)) << (lane + 1u);   // heads above this lane
+  const int nexth = above ? (__ffsll((long long)above) - 1) : (64 - __clzll((long long)(vmask | 1ull)));
+  unsigned base = 0;
+  if (head) base = atomicAdd(&A.cellCount[c], (unsigned)(nexth - (int)lane));
+  base = (unsigned)__shfl((int)base, hl, 64);
+  return base + (lane - (unsigned)hl);
+}
+
 __global__ __launch_bounds__(256) void k_count(const Args A) { // k_build_cells' index arithmetic, :170-174, + the slot
   const int i = blockIdx.x * 256 + threadIdx.x;
   const bool valid = i < A.N;
@@ -75,24 +97,9 @@ __global__ __launch_bounds__(256) void k_count(const Args A) { // k_build_cells'
     const float2 p = A.pos[i];
     c = (unsigned)(grid_c(p.y, A.cell, A.Gy) * A.Gx + grid_c(p.x, A.cell, A.Gx));
     A.keys[i] = c;
-    A.cellOf[i] = (int)c;
   }
-  // One atomicAdd per RUN of consecutive lanes in the same cell (ids are spatially coherent: neighbouring ids mostly share a
-  // cell): run heads from a compare with the lane below, a ballot of the heads, and bit arithmetic on it give every lane
-  // its run's head lane, its rank in the run and the run's length — no loop, whatever the particle order (scattered ids
-  // degrade to one atomic per lane, never to more work per lane).  Two runs of one cell in a wave are simply two atomics.
-  const unsigned lane = __lane_id();
-  const unsigned cprev = (unsigned)__shfl_up((int)c, 1, 64);
-  const bool head = valid && (lane == 0u || c != cprev);
-  const unsigned long long heads = __ballot(head), vmask = __ballot(valid);
-  const unsigned long long below = heads & (~0ull >> (63u - lane));            // heads at or below this lane
-  const int hl = below ? 63 - __clzll((long long)below) : 0;
-  const unsigned long long above = (lane == 63u) ? 0ull : (heads >> (lane + 1u)) << (lane + 1u);   // heads above this lane
-  const int nexth = above ? (__ffsll((long long)above) - 1) : (64 - __clzll((long long)(vmask | 1ull)));   // (valid lanes are a prefix of the wave)
-  unsigned base = 0;
-  if (head) base = atomicAdd(&A.cellCount[c], (unsigned)(nexth - (int)lane));
-  base = (unsigned)__shfl((int)base, hl, 64);
-  if (valid) A.ids[i] = base + (lane - (unsigned)hl);
+  const unsigned slot = cell_slot(A, c, valid);
+  if (valid) A.ids[i] = slot;
 }
 
 // exclusive prefix of cellCount[0 .. M] (M + 1 entries: entry M is always 0, so cellStart[M] = N).  Every workgroup of k_scan
@@ -172,19 +179,35 @@ __global__ __launch_bounds__(256) void k_scatter(const Args A) {
 // place p of the scattered order -> place s + (number of ids of the cell below its own): ascending ids inside the cell,
 // what k_build_cells' lists would hold if its atomics ran in id order (:165-176).  Also the gather of the records.
 __global__ __launch_bounds__(256) void k_rank_gather(const Args A, int ncount) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  __shared__ unsigned sId[256];
+  const int p0 = blockIdx.x * 256, p = p0 + threadIdx.x;
   for (int q = p; q < ncount; q += gridDim.x * 256) A.cellCount[q] = 0u;   // the counts have been scanned: zero for the next build
-  if (p >= A.N) return;
-  const unsigned c = A.tmpKey[p], id = A.tmpId[p];
+  const bool valid = p < A.N;
+  unsigned c = 0, id = 0;
+  if (valid) { c = A.tmpKey[p]; id = A.tmpId[p]; }
+  sId[threadIdx.x] = id;
+  __syncthreads();
+  if (!valid) return;
+  // the cell's segment [s, e): the part inside this workgroup's 256 places comes from LDS (a cell is ~16 consecutive places, so
+  // almost all of it), the rest from memory
   const int s = A.cellStart[c], e = A.cellStart[c + 1];
+  const int a = max(s, p0), b = min(e, p0 + 256);
   int r = 0;
-  for (int q = s; q < e; q++) r += (A.tmpId[q] < id) ? 1 : 0;
+  for (int q = s; q < a; q++) r += (A.tmpId[q] < id) ? 1 : 0;
+  for (int q = a; q < b; q++) r += (sId[q - p0] < id) ? 1 : 0;
+  for (int q = max(b, s); q < e; q++) r += (A.tmpId[q] < id) ? 1 : 0;
   const int k = s + r;
   A.keys_s[k] = c;
   A.ids_s[k] = id;
   const float2 pp = A.pos[id], v = A.vel[id];
   A.recA[k] = make_float4(pp.x, pp.y, v.x, v.y);
   A.recP[k] = pp;
+}
+
+// cellOf[particle] of the last build, from its sorted arrays (tausph_download: the integer cell index gy * Gx + gx, :170-174)
+__global__ __launch_bounds__(256) void k_cell_of(const Args A) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k < A.N) A.cellOf[A.ids_s[k]] = (int)A.keys_s[k];
 }
 
 // ordered pairs (i, j), i != j, closer than 2h among the records of the last build — what the density and force passes of
@@ -517,6 +540,13 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   A.pos[id] = make_float2(x, y);
   A.vel[id] = make_float2(vx, vy);
   if (A.recA2) A.recA2[k] = make_float4(x, y, vx, vy);
+  if (A.countNext) {   // the moved particle's cell and slot for the NEXT sub-step's build: k_count without its launch and its read of pos
+    const unsigned c = (unsigned)(grid_c(y, A.cell, A.Gy) * A.Gx + grid_c(x, A.cell, A.Gx));
+    A.keys[id] = c;
+    // one lane per particle: the wave's lanes are consecutive sorted places (a prefix of them valid); four lanes per particle
+    // (small N): every fourth lane is left here — a plain atomic each
+    A.ids[id] = (LPP == 1) ? cell_slot(A, c, true) : atomicAdd(&A.cellCount[c], 1u);
+  }
 }
 
 // XSPH velocity smoothing, k_xsph_cell + k_apply_xsph (:274-322; launched after the integrate, :698-704).
@@ -605,6 +635,8 @@ struct tausph {
   bool own_stream;
   sph::Args a;
   int ntiles;        // scan tiles of the cell counts
+  bool counted;      // the cells of the current positions are already counted (by the last k_forces): the build starts at the scan
+  bool fuse_count;   // k_forces counts for the next build (TAU_SPH_FUSE_COUNT=0 switches it off)
   unsigned long long *pairs;   // device word of tausph_count_pairs (lazy)
   float tau, t;
   long step;
@@ -676,8 +708,13 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   // one lane per particle does not fill 1 024 SIMDs below ~100 k particles (lattice sub-step, 1 vs 4 lanes: 4 096:
   // 110 vs 69 us, 65 536: 134 vs 112 us, 262 144: 226 vs 289 us; the reference's compressed default run at 65 536:
   // 0.64-0.87 vs 0.29-0.45 ms)
+  h->counted = false;
+  h->fuse_count = !(getenv("TAU_SPH_FUSE_COUNT") && atoi(getenv("TAU_SPH_FUSE_COUNT")) == 0);
   h->lpp = (P->N < (1 << 17)) ? 4 : 1;
   if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 4) h->lpp = v; }
+  // (four lanes per particle: the force pass leaves every fourth lane at the end, the count would be one contended atomic per
+  //  particle — 65 536 compressed: 326 against 313 us per step — so the small-N form keeps the separate k_count)
+  if (h->lpp != 1) h->fuse_count = false;
   h->tau = 0.f; h->t = P->t0 * expf(h->tau); h->step = 0; // :577-578
   *out = guard.release();
   return 0;
@@ -697,6 +734,10 @@ extern "C" void tausph_destroy(tausph_t *h) {
 
 extern "C" int tausph_upload(tausph_t *h, const float *pos_xy, const float *vel_xy) {
   TAU_HIP(hipSetDevice(h->device));
+  if (h->counted) {   // the positions the last k_forces counted are being replaced
+    TAU_HIP(hipMemsetAsync(h->a.cellCount, 0, (size_t)h->ntiles * sph::SCAN_TILE * sizeof(unsigned), h->stream));
+    h->counted = false;
+  }
   size_t b = (size_t)h->p.N * sizeof(float2);
   TAU_HIP(hipMemcpyAsync(h->a.pos, pos_xy, b, hipMemcpyHostToDevice, h->stream));
   TAU_HIP(hipMemcpyAsync(h->a.vel, vel_xy, b, hipMemcpyHostToDevice, h->stream));
@@ -734,7 +775,11 @@ extern "C" int tausph_download(tausph_t *h, float *pos_xy, float *vel_xy, float 
   if (acc_xy) TAU_HIP(hipMemcpyAsync(acc_xy, h->a.acc, N * 8, hipMemcpyDeviceToHost, h->stream));
   if (s) TAU_HIP(hipMemcpyAsync(s, h->a.s, N * 4, hipMemcpyDeviceToHost, h->stream));
   if (press) TAU_HIP(hipMemcpyAsync(press, h->a.press, N * 4, hipMemcpyDeviceToHost, h->stream));
-  if (cellOf) TAU_HIP(hipMemcpyAsync(cellOf, h->a.cellOf, N * 4, hipMemcpyDeviceToHost, h->stream));
+  if (cellOf) {
+    hipLaunchKernelGGL(sph::k_cell_of, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->a);
+    TAU_LAUNCH_CHECK("sph::k_cell_of");
+    TAU_HIP(hipMemcpyAsync(cellOf, h->a.cellOf, N * 4, hipMemcpyDeviceToHost, h->stream));
+  }
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -744,6 +789,15 @@ extern "C" int tausph_state_ptrs(tausph_t *h, float **pos, float **vel, float **
   if (acc) *acc = (float *)h->a.acc;
   if (s) *s = h->a.s;
   if (press) *press = h->a.press;
+  return 0;
+}
+extern "C" int tausph_state_written(tausph_t *h) {   // the caller moved particles through tausph_state_ptrs: count the cells again
+  if (!h) return tau::fail("tausph_state_written: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  if (h->counted) {
+    TAU_HIP(hipMemsetAsync(h->a.cellCount, 0, (size_t)h->ntiles * sph::SCAN_TILE * sizeof(unsigned), h->stream));
+    h->counted = false;
+  }
   return 0;
 }
 extern "C" int tausph_grid(tausph_t *h, int *Gx, int *Gy, float *cell, float *hh, float *mass) {
@@ -761,8 +815,12 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
   A.dt = dt;
   const unsigned gs = (unsigned)((A.N + 255) / 256);
   // the cell build (k_clear_heads + k_build_cells, :159-176): counting sort, four or five small launches
-  hipLaunchKernelGGL(sph::k_count, dim3(gs), dim3(256), 0, h->stream, A);
-  TAU_LAUNCH_CHECK("sph::k_count");
+  if (!h->counted) {
+    hipLaunchKernelGGL(sph::k_count, dim3(gs), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_count");
+  }
+  A.countNext = h->fuse_count ? 1 : 0;
+  h->counted = h->fuse_count;
   if (h->ntiles > sph::DIRECT_TILES) {
     hipLaunchKernelGGL(sph::k_tile_sums, dim3((unsigned)h->ntiles), dim3(sph::SCAN_T), 0, h->stream, A);
     TAU_LAUNCH_CHECK("sph::k_tile_sums");
@@ -795,6 +853,10 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
     int nspawn = (int)h->rain_carry;
     h->rain_carry -= nspawn;
     if (nspawn > 0) {
+      if (h->counted) {   // drops move particles after they were counted: the next build counts again
+        TAU_HIP(hipMemsetAsync(A.cellCount, 0, (size_t)h->ntiles * sph::SCAN_TILE * sizeof(unsigned), h->stream));
+        h->counted = false;
+      }
       const unsigned seed = (unsigned)(h->p.seed + (int)h->step), gr = (unsigned)((nspawn + 127) / 128);
       hipLaunchKernelGGL(sph::k_rain_claim, dim3(gr), dim3(128), 0, h->stream, A, nspawn, seed);
       TAU_LAUNCH_CHECK("sph::k_rain_claim");

@@ -210,6 +210,7 @@ def load():
         "tausph_rasterize": ([vp, i32, i32, vp], i32),
         "tausph_rain_spawned": ([vp], C.c_int64),
         "tausph_count_pairs": ([vp, C.POINTER(C.c_int64)], i32),
+        "tausph_state_written": ([vp], i32),
         "tauflow_params_default": ([C.POINTER(FlowParams), i32, i32, i32], None),
         "tauflow_create": ([C.POINTER(vp), C.POINTER(FlowParams), i32, i32, vp], i32),
         "tauflow_destroy": ([vp], None),
