@@ -166,7 +166,7 @@ def other_configs(f, torch, dev):
     ms = _event_timed(torch, stream, lambda: e.step_async(200), e.sync)
     out.append({"config": f"tau_hypersonic_cuda 2D {n}x{n} fp32 (one fused kernel per step)", "steps": 200, "warmup": 50,
                 "value": round(n * n * 200 / ms / 1e6, 3), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 200, 5),
-                "roofline": _roof("h2d::k_march", ms / 200, n * n, 33, "valu")})
+                "roofline": _roof("h2d::k_march_lds<1>", ms / 200, n * n, 33, "valu")})
     e.close()
 
     # ---- C3: tau_gray_scott 8192^2, init_pattern(seed 1337), 1000 steps: four time levels per pass (the default), and the
