@@ -252,7 +252,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--n", type=int, default=512, help="grid edge (headline: 512)")
+    ap.add_argument("--grid", dest="n", type=int, default=512,
+                    help="grid edge (headline: 512).  (Not --n: torch.distributed.run's own parser takes that for an abbreviation of --nnodes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the two extra SURVEY 8d inputs (reference IC, no body)")
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE.json configs (2D Euler, Gray-Scott, SPH, CPU)")

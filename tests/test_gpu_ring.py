@@ -101,7 +101,7 @@ def test_bench_force_slab_c_ring(eng):
     """bench.py's N > 1 code path on one GPU: the C ring with RCCL to itself, one JSON line"""
     import json
     import sys
-    r = run(sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--n", "128", "--steps", "4", "--warmup", "2",
+    r = run(sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--grid", "128", "--steps", "4", "--warmup", "2",
             "--force-slab", "--self-p2p", "--no-cpu-baseline", "--no-configs", "--no-variants")
     assert r.returncode == 0, r.stdout + r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
