@@ -74,19 +74,21 @@ constexpr int SCAN_T = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_T * SCAN_ITEMS;   
 // rank in the run and the run's length — no loop, whatever the particle order (scattered cells degrade to one atomic per lane,
 // never to more work per lane).  Two runs of one cell in a wave are simply two atomics.  The valid lanes must be a prefix of
 // the wave's active lanes; call it from converged code.
+// STRIDE: the active lanes are every STRIDE-th lane (k_forces with four lanes per particle leaves lane 0 of each quad).
+template <int STRIDE>
 __device__ __forceinline__ unsigned cell_slot(const Args &A, unsigned c, bool valid) {
   const unsigned lane = __lane_id();
-  const unsigned cprev = (unsigned)__shfl_up((int)c, 1, 64);
-  const bool head = valid && (lane == 0u || c != cprev);
+  const unsigned cprev = (unsigned)__shfl_up((int)c, STRIDE, 64);
+  const bool head = valid && (lane < (unsigned)STRIDE || c != cprev);
   const unsigned long long heads = __ballot(head), vmask = __ballot(valid);
   const unsigned long long below = heads & (~0ull >> (63u - lane));            // heads at or below this lane
   const int hl = below ? 63 - __clzll((long long)below) : 0;
   const unsigned long long above = (lane == 63u) ? 0ull : (heads >> (lane + 1u)) << (lane + 1u);   // heads above this lane
-  const int nexth = above ? (__ffsll((long long)above) - 1) : (64 - __clzll((long long)(vmask | 1ull)));
+  const int nexth = above ? (__ffsll((long long)above) - 1) : (63 - __clzll((long long)(vmask | 1ull)) + STRIDE);   // (the last run ends behind the last valid lane)
   unsigned base = 0;
-  if (head) base = atomicAdd(&A.cellCount[c], (unsigned)(nexth - (int)lane));
+  if (head) base = atomicAdd(&A.cellCount[c], (unsigned)((nexth - (int)lane) / STRIDE));
   base = (unsigned)__shfl((int)base, hl, 64);
-  return base + (lane - (unsigned)hl);
+  return base + (lane - (unsigned)hl) / (unsigned)STRIDE;
 }
 
 __global__ __launch_bounds__(256) void k_count(const Args A) { // k_build_cells' index arithmetic, :170-174, + the slot
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void k_count(const Args A) { // k_build_cells'
     c = (unsigned)(grid_c(p.y, A.cell, A.Gy) * A.Gx + grid_c(p.x, A.cell, A.Gx));
     A.keys[i] = c;
   }
-  const unsigned slot = cell_slot(A, c, valid);
+  const unsigned slot = cell_slot<1>(A, c, valid);
   if (valid) A.ids[i] = slot;
 }
 
@@ -543,9 +545,8 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   if (A.countNext) {   // the moved particle's cell and slot for the NEXT sub-step's build: k_count without its launch and its read of pos
     const unsigned c = (unsigned)(grid_c(y, A.cell, A.Gy) * A.Gx + grid_c(x, A.cell, A.Gx));
     A.keys[id] = c;
-    // one lane per particle: the wave's lanes are consecutive sorted places (a prefix of them valid); four lanes per particle
-    // (small N): every fourth lane is left here — a plain atomic each
-    A.ids[id] = (LPP == 1) ? cell_slot(A, c, true) : atomicAdd(&A.cellCount[c], 1u);
+    // the wave's remaining lanes are consecutive sorted places (every LPP-th lane, a prefix of them): runs of one cell
+    A.ids[id] = cell_slot<LPP>(A, c, true);
   }
 }
 
@@ -712,9 +713,7 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   h->fuse_count = !(getenv("TAU_SPH_FUSE_COUNT") && atoi(getenv("TAU_SPH_FUSE_COUNT")) == 0);
   h->lpp = (P->N < (1 << 17)) ? 4 : 1;
   if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 4) h->lpp = v; }
-  // (four lanes per particle: the force pass leaves every fourth lane at the end, the count would be one contended atomic per
-  //  particle — 65 536 compressed: 326 against 313 us per step — so the small-N form keeps the separate k_count)
-  if (h->lpp != 1) h->fuse_count = false;
+
   h->tau = 0.f; h->t = P->t0 * expf(h->tau); h->step = 0; // :577-578
   *out = guard.release();
   return 0;
