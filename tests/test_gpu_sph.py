@@ -298,3 +298,29 @@ def test_acc_error_is_the_oracles_own_summation_order_spread(eng, oracle_built):
     assert (spread / mag).max() > 1e-5                       # two legal orders of the reference's own sum: beyond the literal 1e-5
     assert (err / summed).max() <= 3.0 * (spread / summed).max() + 1e-6
     e.close()
+
+
+@pytest.mark.parametrize("N", [16384, 200000])
+def test_upload_between_substeps_discards_the_fused_count(eng, N):
+    """k_forces counts the particles it moved into the cells of the next build.  An upload in between replaces those positions:
+    the next sub-step must count again — bit-identical (cell indices, densities, positions) to a fresh handle given the same state."""
+    a = eng.Sph2D(N)
+    a.reset_particles()
+    a.step(5)                                   # a's last k_forces has counted its moved particles
+    b = eng.Sph2D(N)
+    b.reset_particles()
+    b.step(2)
+    st = b.download()                           # some other state
+    b.close()
+    a.upload(st["pos"], st["vel"])
+    fresh = eng.Sph2D(N)
+    fresh.upload(st["pos"], st["vel"])
+    dt = 1e-4
+    for h in (a, fresh):
+        h.substep(dt)
+        h.substep(dt)                           # the second one runs on the fused count of the first
+    ga, gf = a.download(), fresh.download()
+    for k in ("cell", "pos", "vel", "acc", "s", "press"):
+        assert np.array_equal(ga[k], gf[k]), k
+    a.close()
+    fresh.close()
