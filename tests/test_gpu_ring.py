@@ -107,3 +107,29 @@ def test_bench_force_slab_c_ring(eng):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["ring"]["transport"] == "rccl" and j["ring"]["comm_ranks"] == 1 and j["value"] > 0
+
+
+def test_ring_rendezvous_times_out_instead_of_hanging(eng, tmp_path):
+    """a rank whose peers never show up gets an error after TAU3D_RING_TIMEOUT seconds (here: rank 1 of 2 waiting for rank 0's
+    rendezvous file, then rank 0 of 2 waiting at the start barrier) — never a hang inside ncclCommInitRank"""
+    import sys
+    code = r"""
+import sys, ctypes
+sys.path.insert(0, %r)
+import fluid_sims_amd as f
+rank = int(sys.argv[1])
+p = f.Tau3DParams(); f.load().tau3d_params_default(ctypes.byref(p), 32, 32, 32)
+z0, nzl = f.slab_bounds(32, 2, rank)
+e = f.Tau3D(32, 32, 32, params=p, z0=z0, nzl=nzl)
+e.init(1)
+try:
+    f.Tau3DRing(e, rank, 2, f.RING_HOST, rendezvous=sys.argv[2], job_key=12345)
+except f.TauError as ex:
+    print("TauError:", ex); sys.exit(7)
+sys.exit(0)
+""" % ROOT
+    env = dict(os.environ, TAU3D_RING_TIMEOUT="3")
+    for rank, words in ((1, "waited"), (0, "timed out")):
+        r = subprocess.run([sys.executable, "-c", code, str(rank), str(tmp_path / f"rv{rank}")], capture_output=True, text=True,
+                           cwd=ROOT, env=env, timeout=120)
+        assert r.returncode == 7 and words in r.stdout, (rank, r.stdout, r.stderr)
