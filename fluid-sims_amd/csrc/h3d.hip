@@ -960,7 +960,8 @@ struct XyLds {
   float sP[6][XPLANE];          // the plane, primitives, x/y halo 3
   uint8_t sS[XPLANE];
   float sLy[6][YT + 1][XT];     // [r][x]: left state of the face below row r (from the cell in row r-1; r = 0: ring)
-  float sFy[6][YT + 1][XT];     // flux through that face
+  // (the flux through that face takes the SAME slot: a slot's left state is read by exactly one lane — the one that then
+  //  writes the flux there — so no second [6][YT + 1][XT] array: 51 -> 38 KB per workgroup, four workgroups per CU)
   float sLx0[6][YT];            // left state of the tile's low-x faces (ring cell x = -1)
   float sLxT[6][YT];            // left state of the far x faces (own column XT-1)
   float sRxT[6][YT];            // right state of the far x faces (ring cell x = XT)
@@ -1057,7 +1058,7 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   // one round of all eight waves and a 64-task remainder on one wave (rotating with the plane).  With one lane per ring
   // cell and the six variables in sequence, two waves ran ~270 instructions each while the other six sat at the barrier.
   constexpr int RING = XT + YT, RTASKS = 2 * 6 * RING;
-  static_assert(RTASKS > XNT && RTASKS - XNT <= 64, "ring tasks: one round of the workgroup + one wave");
+  static_assert(RTASKS <= XNT + 64, "ring tasks: one round of the workgroup (+ one wave)");
   auto ring_task = [&](int t) {
     const int side = t >= 6 * RING ? 1 : 0;   // 0: low ring (left states), 1: high ring (right states)
     const int r = t - side * (6 * RING);
@@ -1072,8 +1073,8 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
                       : (isx ? &S.sLx0[0][0] + m * YT + ln : &S.sLy[0][0][0] + m * ((YT + 1) * XT) + (ln - YT));
     *dst = side ? Rlo : Lhi;
   };
-  ring_task(tid);
-  if (wave == wA) ring_task(XNT + lane);
+  if (RTASKS >= XNT || tid < RTASKS) ring_task(tid);
+  if (RTASKS > XNT && wave == wA) ring_task(XNT + lane);
   __syncthreads();
 
   // ---- faces: low-x and low-y of the own cell; the tile's far faces
@@ -1121,7 +1122,7 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
     prim_floor(R);
     const Cons F = hllc(G, L, R, 1);
 #pragma unroll
-    for (int m = 0; m < 6; m++) { Fy[m] = F.c[m]; S.sFy[m][ty][tx] = F.c[m]; }
+    for (int m = 0; m < 6; m++) { Fy[m] = F.c[m]; S.sLy[m][ty][tx] = F.c[m]; }
   }
   if (wave == wC && lane < XT + YT) { // far faces: x faces at column XT (rows 0 .. YT-1), y faces at row YT
     const bool isx = lane < YT;
@@ -1147,7 +1148,7 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
     const Cons F = hllc(G, L, R, isx ? 0 : 1);
 #pragma unroll
     for (int m = 0; m < 6; m++) {
-      if (isx) S.sFxT[m][lane] = F.c[m]; else S.sFy[m][YT][lane - YT] = F.c[m];
+      if (isx) S.sFxT[m][lane] = F.c[m]; else S.sLy[m][YT][lane - YT] = F.c[m];
     }
   }
   __syncthreads();
@@ -1158,7 +1159,7 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   for (int m = 0; m < 6; m++) {
     const float up = lane_above(Fx[m]);
     const float fxh = (tx == XT - 1) ? S.sFxT[m][ty] : up;
-    C.d[m] = (fxh - Fx[m]) * inv_dx + (S.sFy[m][ty + 1][tx] - Fy[m]) * inv_dy;
+    C.d[m] = (fxh - Fx[m]) * inv_dx + (S.sLy[m][ty + 1][tx] - Fy[m]) * inv_dy;
   }
   C.in_xy = in_xy; C.own_solid = own_solid; C.x = x; C.yw = yw; C.z = z; C.lc = lc;
 }
