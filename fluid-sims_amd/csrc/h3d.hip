@@ -1203,8 +1203,8 @@ __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
 // the constants update_cell uses three times per cell, in VGPRs (an SGPR operand halves the issue rate); gamma and gamma - 1
 // come from the Gas copy the z face already holds.  k_update_z has three registers to spare under its five-wave limit (96):
 // the constants with one use per cell stay in SGPRs.
-struct UpdK { float gm1, gamma, inv_u_ref, absmask; };
-__device__ __forceinline__ UpdK updk_vgpr(const Args &A, const Gas &G) { return UpdK{G.gm1, G.gamma, vreg(A.inv_u_ref), vlit(0x7fffffffu)}; }
+struct UpdK { float gm1, inv_gm1, gamma, inv_u_ref, absmask; };
+__device__ __forceinline__ UpdK updk_vgpr(const Args &A, const Gas &G) { return UpdK{G.gm1, G.inv_gm1, G.gamma, vreg(A.inv_u_ref), vlit(0x7fffffffu)}; }
 __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const float (&own)[6], const float (&D)[6], const float (&Fz_lo)[6],
                                             const float (&Fz_hi)[6], float dt, float inv_dz, float gain, int x, float (&E)[6],
                                             float &smax, float &fmx) {
@@ -1213,8 +1213,10 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
   U0[0] = r0; U0[1] = r0 * u0; U0[2] = r0 * v0; U0[3] = r0 * w0;
   {
     float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
-    float eth = p0 * rcp(fmaxf(K.gm1 * r0, RHO_P_FLOOR));
-    U0[4] = r0 * (ke + eth + e0);
+    // r e_th = r p / max((gamma - 1) r, floor) = p / (gamma - 1) wherever the floor does not bite (r >= 1e-29): no reciprocal
+    // (hllc forms its conserved states the same way)
+    const float reth = (K.gm1 * r0 >= RHO_P_FLOOR) ? p0 * K.inv_gm1 : (p0 * r0) * (1.f / RHO_P_FLOOR);
+    U0[4] = r0 * (ke + e0) + reth;
     U0[5] = r0 * e0;
   }
   float U1[6];
@@ -1233,9 +1235,13 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
   const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
                      __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
                    r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
-  if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; }
-  float T1 = p1 * rcp(r1 * A.R);
-  ev1 = fmaxf(ev1 + (evib_eq(A, T1) - ev1) * (dt * A.inv_tau_vib), 0.f);
+  if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; ir1 = rcp(r1); }
+  {   // evib_eq(T), T = p / (r R), :206-211: theta_v / max(T, floor) = theta_v r R / max(p, floor r R) — one reciprocal for T and 1 / T
+    const float rR = r1 * A.R;
+    const float av = (A.theta_v * rR) * rcp(fmaxf(p1, NEWTON_TEMP_FLOOR * rR));
+    const float eq = A.Rtheta * rcp(fmaxf(fexp(av) - 1.f, NEWTON_TEMP_FLOOR));
+    ev1 = fmaxf(ev1 + (eq - ev1) * (dt * A.inv_tau_vib), 0.f);
+  }
 
   if (A.sponge_n > 0 && x < A.sponge_n) {
     float s = 1.0f - (float)x / (float)A.sponge_n;
@@ -1247,6 +1253,7 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
     v1 = v1 + k * (gain * A.in_v - v1);
     w1 = w1 + k * (gain * A.in_w - w1);
     ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+    ir1 = rcp(r1);
   }
   if (A.sponge_out_n > 0 && x >= (A.nx - A.sponge_out_n)) {
     int xo2 = x - (A.nx - A.sponge_out_n);
@@ -1259,8 +1266,9 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
     v1 = v1 + k * (0.0f - v1);
     w1 = w1 + k * (0.0f - w1);
     ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
+    ir1 = rcp(r1);
   }
-  float a = fsqrt(fmaxf(K.gamma * p1 * rcp(r1), DENOM_EPS));   // soundspeed, :264-266
+  float a = fsqrt(fmaxf(K.gamma * p1 * ir1, DENOM_EPS));   // soundspeed, :264-266 (1 / r: the update's own, re-formed only where a sponge or the reset changed r)
   float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * inv_dz;
   if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
   fmx = fmaxf(fmaxf(fmx, r1), fabsf(u1));            // three v_max3_f32 (a balanced tree of fmaxf compiles to six v_max_f32)
