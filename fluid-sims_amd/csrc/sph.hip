@@ -212,6 +212,14 @@ __global__ __launch_bounds__(256) void k_cell_of(const Args A) {
   if (k < A.N) A.cellOf[A.ids_s[k]] = (int)A.keys_s[k];
 }
 
+// before any build: the cell index of the current positions (same arithmetic as k_count)
+__global__ __launch_bounds__(256) void k_cell_of_pos(const Args A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= A.N) return;
+  const float2 p = A.pos[i];
+  A.cellOf[i] = grid_c(p.y, A.cell, A.Gy) * A.Gx + grid_c(p.x, A.cell, A.Gx);
+}
+
 // ordered pairs (i, j), i != j, closer than 2h among the records of the last build — what the density and force passes of
 // that sub-step evaluated (diagnostic: bench.py's pair-interactions/s; not part of a step)
 __global__ __launch_bounds__(256) void k_count_pairs(const Args A, unsigned long long *out) {
@@ -636,6 +644,7 @@ struct tausph {
   bool own_stream;
   sph::Args a;
   int ntiles;        // scan tiles of the cell counts
+  bool built;        // a sub-step has built the cell arrays (keys_s / ids_s / cellStart are defined)
   bool counted;      // the cells of the current positions are already counted (by the last k_forces): the build starts at the scan
   bool fuse_count;   // k_forces counts for the next build (TAU_SPH_FUSE_COUNT=0 switches it off)
   unsigned long long *pairs;   // device word of tausph_count_pairs (lazy)
@@ -710,6 +719,7 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   // 110 vs 69 us, 65 536: 134 vs 112 us, 262 144: 226 vs 289 us; the reference's compressed default run at 65 536:
   // 0.64-0.87 vs 0.29-0.45 ms)
   h->counted = false;
+  h->built = false;
   h->fuse_count = !(getenv("TAU_SPH_FUSE_COUNT") && atoi(getenv("TAU_SPH_FUSE_COUNT")) == 0);
   h->lpp = (P->N < (1 << 17)) ? 4 : 1;
   if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 4) h->lpp = v; }
@@ -775,7 +785,8 @@ extern "C" int tausph_download(tausph_t *h, float *pos_xy, float *vel_xy, float 
   if (s) TAU_HIP(hipMemcpyAsync(s, h->a.s, N * 4, hipMemcpyDeviceToHost, h->stream));
   if (press) TAU_HIP(hipMemcpyAsync(press, h->a.press, N * 4, hipMemcpyDeviceToHost, h->stream));
   if (cellOf) {
-    hipLaunchKernelGGL(sph::k_cell_of, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->a);
+    if (h->built) hipLaunchKernelGGL(sph::k_cell_of, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->a);
+    else hipLaunchKernelGGL(sph::k_cell_of_pos, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, h->stream, h->a);   // no sub-step yet: nothing sorted
     TAU_LAUNCH_CHECK("sph::k_cell_of");
     TAU_HIP(hipMemcpyAsync(cellOf, h->a.cellOf, N * 4, hipMemcpyDeviceToHost, h->stream));
   }
@@ -820,6 +831,7 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
   }
   A.countNext = h->fuse_count ? 1 : 0;
   h->counted = h->fuse_count;
+  h->built = true;
   if (h->ntiles > sph::DIRECT_TILES) {
     hipLaunchKernelGGL(sph::k_tile_sums, dim3((unsigned)h->ntiles), dim3(sph::SCAN_T), 0, h->stream, A);
     TAU_LAUNCH_CHECK("sph::k_tile_sums");
@@ -905,6 +917,7 @@ extern "C" int tausph_rasterize(tausph_t *h, int W, int H, int32_t *host_grid2) 
 extern "C" int64_t tausph_rain_spawned(tausph_t *h) { return (int64_t)h->rain_spawned; }
 extern "C" int tausph_count_pairs(tausph_t *h, int64_t *ordered_pairs) {
   if (!h || !ordered_pairs) return tau::fail("tausph_count_pairs: null argument");
+  if (!h->built) return tau::fail("tausph_count_pairs: no sub-step has built the cells yet");
   TAU_HIP(hipSetDevice(h->device));
   if (!h->pairs) TAU_HIP(hipMalloc(&h->pairs, sizeof(unsigned long long)));
   TAU_HIP(hipMemsetAsync(h->pairs, 0, sizeof(unsigned long long), h->stream));

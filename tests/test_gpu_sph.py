@@ -324,3 +324,18 @@ def test_upload_between_substeps_discards_the_fused_count(eng, N):
         assert np.array_equal(ga[k], gf[k]), k
     a.close()
     fresh.close()
+
+
+def test_download_before_any_substep(eng):
+    """cellOf before any sub-step has built the cell arrays: the cell index of the current positions (nothing is sorted yet)"""
+    N = 5000
+    e = eng.Sph2D(N)
+    e.reset_particles()
+    st = e.download()
+    Gx, Gy, cell, hh, mass = e.grid()
+    gx = np.clip(np.floor(st["pos"][:, 0] / np.float32(cell)).astype(np.int64), 0, Gx - 1)
+    gy = np.clip(np.floor(st["pos"][:, 1] / np.float32(cell)).astype(np.int64), 0, Gy - 1)
+    assert np.array_equal(st["cell"], (gy * Gx + gx).astype(st["cell"].dtype))
+    with pytest.raises(eng.TauError, match="no sub-step"):
+        e.count_pairs()
+    e.close()
