@@ -332,7 +332,8 @@ def test_download_before_any_substep(eng):
     e = eng.Sph2D(N)
     e.reset_particles()
     st = e.download()
-    Gx, Gy, cell, hh, mass = e.grid()
+    g = e.grid()
+    Gx, Gy, cell = g["Gx"], g["Gy"], g["cell"]
     gx = np.clip(np.floor(st["pos"][:, 0] / np.float32(cell)).astype(np.int64), 0, Gx - 1)
     gy = np.clip(np.floor(st["pos"][:, 1] / np.float32(cell)).astype(np.int64), 0, Gy - 1)
     assert np.array_equal(st["cell"], (gy * Gx + gx).astype(st["cell"].dtype))
