@@ -262,6 +262,10 @@ def main():
     ap.add_argument("--self-p2p", action="store_true",
                     help="with --force-slab on one GPU: exchange the halos with OURSELVES through RCCL send/recv and all-reduce the "
                          "max words (a communicator of one) instead of device copies")
+    ap.add_argument("--ring-transport", choices=("rccl", "host"), default="rccl",
+                    help="rccl: ncclSend / ncclRecv / ncclAllReduce, one device per rank (the measured configuration); host: halos staged "
+                         "through shared memory so that the ranks may SHARE a device — exercises this script's N > 1 path on a one-GPU box "
+                         "(process group over gloo); not a performance configuration")
     ap.add_argument("--ring-driver", choices=("c", "python"), default="c",
                     help="c: the library's ring (tau3d_ring_*, librccl called from C); python: fluid-sims_amd/slab.py over torch.distributed")
     args = ap.parse_args()
@@ -283,9 +287,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (libtaueng has no CPU path)")
     ndev = torch.cuda.device_count()
-    if ndev < world:
+    shared = args.ring_transport == "host"
+    if ndev < world and not shared:
         raise SystemExit(f"bench.py --gpus {world}: rank {rank} sees {ndev} device(s); the Z-slab ring needs {world} devices, "
                          f"one MI355X per rank")
+    if shared:
+        local = local % ndev
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -297,7 +304,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29581")
-        if world > 1:
+        if world > 1 and shared:
+            dist.init_process_group("gloo")
+        elif world > 1:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
@@ -337,14 +346,14 @@ def main():
         ring_info = {"driver": "python (torch.distributed batch_isend_irecv + all_reduce)"}
     else:
         # the library's ring: every rank passes the same rendezvous path and job key (agreed through torch.distributed)
-        key = torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device=dev)
+        key = torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device="cpu" if shared else dev)
         if world > 1:
             dist.broadcast(key, 0)
         key = int(key.item())
         eng = f.Tau3D(n, n, n, params=params, z0=z0, nzl=nzl, device=local)
         eng.init(1)
         eng.set_clock(0.02, 1e-4)
-        transport = f.RING_RCCL if (world > 1 or args.self_p2p) else f.RING_LOCAL
+        transport = f.RING_HOST if (shared and world > 1) else (f.RING_RCCL if (world > 1 or args.self_p2p) else f.RING_LOCAL)
         ring = f.Tau3DRing(eng, rank, world, transport, rendezvous=f"/dev/shm/tau3d_bench_{key & 0xffffffffff:x}" if world > 1 else None,
                            job_key=key)
         ring.prime()
@@ -353,7 +362,8 @@ def main():
         get_clock = ring.clock
         h = eng
         ring_info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)",
-                         transport={f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies"}[transport])
+                         transport={f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies",
+                                    f.RING_HOST: "host-staged (ranks share a device: not a performance configuration)"}[transport])
 
     step(args.warmup)
     sync()
@@ -371,10 +381,11 @@ def main():
 
     per_rank_ms = None
     if world > 1:
-        tmax = torch.tensor([el], dtype=torch.float64, device=dev)
+        cdev = "cpu" if shared else dev
+        tmax = torch.tensor([el], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         el = float(tmax.item())
-        km = torch.zeros(world, dtype=torch.float64, device=dev)
+        km = torch.zeros(world, dtype=torch.float64, device=cdev)
         km[rank] = k_ms / max(args.steps, 1)
         dist.all_reduce(km, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 4) for x in km.tolist()]

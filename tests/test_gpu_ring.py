@@ -133,3 +133,21 @@ sys.exit(0)
         r = subprocess.run([sys.executable, "-c", code, str(rank), str(tmp_path / f"rv{rank}")], capture_output=True, text=True,
                            cwd=ROOT, env=env, timeout=120)
         assert r.returncode == 7 and words in r.stdout, (rank, r.stdout, r.stderr)
+
+
+def test_bench_two_ranks_end_to_end_on_one_gpu(eng):
+    """`python bench.py --gpus 2` as the driver calls it: bench.py spawns its own ranks under torch.distributed.run, each rank
+    builds its slab and the library ring, rank 0 prints ONE JSON line with n_gpus = 2 and the per-rank kernel times.  On this
+    one-GPU box the ranks share the device (--ring-transport host, process group over gloo); with RCCL the same command is
+    the measured N = 2 configuration."""
+    import json
+    import sys
+    r = run(sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2",
+            "--ring-transport", "host")
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["config"]["decomposition"] == "z-slab x2" and j["value"] > 0
+    assert len(j["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and all(t > 0 for t in j["roofline"]["per_rank_kernel_ms_per_step"])
+    assert "host-staged" in j["ring"]["transport"]
