@@ -52,18 +52,25 @@ struct Args {
   float visc_frac;       // dt fraction of the fused viscosity pass (1/K)
 };
 
+// (codec constants out of SGPRs, as in h3d.hip: a VOP3 instruction — anything with |x|, bfi — cannot carry a literal, the constant
+//  lands in an SGPR and an SGPR source halves the issue rate; so: a SIGNED exponential (no |x| multiply, no copysign) in sinh, and
+//  the sign mask of asinh's copysign in a VGPR)
 __device__ __forceinline__ float fsinh(float x) {
-  float ax = fabsf(x), x2 = x * x;
+  float x2 = x * x;
   float series = x * (1.f + x2 * (1.f / 6.f) * (1.f + x2 * (1.f / 20.f) * (1.f + x2 * (1.f / 42.f))));
-  float e = __builtin_amdgcn_exp2f(ax * 1.44269504088896341f);
-  float big = copysignf(0.5f * (e - __builtin_amdgcn_rcpf(e)), x);
-  return (ax < 0.5f) ? series : big;
+  float e = __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+  float big = 0.5f * (e - __builtin_amdgcn_rcpf(e));
+  return (fabsf(x) < 0.5f) ? series : big;
 }
 __device__ __forceinline__ float fasinh(float x) {
   float ax = fabsf(x), x2 = x * x;
+  // x - x^3/6 + 3x^5/40 - 15x^7/336 + 105x^9/3456
   float series = ax * (1.f + x2 * (-1.f / 6.f + x2 * (3.f / 40.f + x2 * (-15.f / 336.f + x2 * (105.f / 3456.f)))));
   float big = __builtin_amdgcn_logf(ax + __builtin_amdgcn_sqrtf(x2 + 1.0f)) * 0.69314718055994531f;
-  return copysignf((ax < 0.125f) ? series : big, x);
+  float mag = (ax < 0.125f) ? series : big, mask, r;
+  asm("v_mov_b32 %0, 0x7fffffff" : "=v"(mask));
+  asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(mag), "v"(x));
+  return r;
 }
 __device__ __forceinline__ float minmodf(float a, float b) { // tau_burgers.cu:332-334
   return (a * b <= 0.0f) ? 0.0f : copysignf(fminf(fabsf(a), fabsf(b)), a);
