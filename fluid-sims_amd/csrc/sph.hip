@@ -64,6 +64,7 @@ __device__ __forceinline__ int grid_c(float x, float cell, int G) { // grid_x / 
   return g >= G ? G - 1 : g;
 }
 __device__ __forceinline__ float rcpf(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float rsqf(float x) { return __builtin_amdgcn_rsqf(x); }
 
 // ---- cell build: counting sort --------------------------------------------------------------------
 constexpr int SCAN_T = 256, SCAN_ITEMS = 16, SCAN_TILE = SCAN_T * SCAN_ITEMS;   // cells per scan workgroup
@@ -251,9 +252,10 @@ __device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :1
   float q = r * ih;
   float q2 = q * q;
   float t = 2.f - q;
-  float w1 = 1.f - 1.5f * q2 + 0.75f * q2 * q;
-  float w2 = 0.25f * t * t * t;
-  return alpha * ((q < 1.0f) ? w1 : ((q < 2.0f) ? w2 : 0.f));
+  const float w1 = 1.f - 1.5f * q2 + 0.75f * q2 * q;
+  const float w2 = 0.25f * t * t * t;
+  const float w12 = (q < 1.0f) ? w1 : w2;      // both pieces are a few multiplies: selects, no exec-mask branches in the pair loop
+  return alpha * ((q < 2.0f) ? w12 : 0.f);
 }
 
 // ---- neighbour passes ------------------------------------------------------------------------------
@@ -328,7 +330,13 @@ __device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw) {
 // quad reduction.  The masks in LDS and in nbrMask are indexed by particle either way.
 //
 // iterate the set bits of this lane's mask words (column `pl` of sM) in ascending candidate order
-template <int LPP, class F>
+#ifndef TAUSPH_NH_D
+#define TAUSPH_NH_D 2   // pair evaluations per trip, density pass
+#endif
+#ifndef TAUSPH_NH_F
+#define TAUSPH_NH_F 2   // forces pass
+#endif
+template <int LPP, int NH, class F>
 __device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int pl, int sub, const Walk &wk, F &&body) {
   int w = sub;
   unsigned m = sM[w][pl];
@@ -346,9 +354,19 @@ __device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int pl, 
       wbase = b0 + (w >= WPR ? d1 : 0) + (w >= 2 * WPR ? d2 : 0) + ((w & (WPR - 1)) << 5);
     }
     if (m != 0u) {
-      const int j = wbase + __builtin_ctz(m);
-      m &= m - 1u;
-      body(j);
+      // NH hits per trip where the word holds as many: the pair evaluations are independent until their sums, so the second
+      // one's LDS read and its rsq / rcp run in the shadow of the first's (a pass is a chain of ~100 dependent trips per wave
+      // at four to seven waves per SIMD: latency, not issue, is what a trip costs).  `on` = false: the body adds exact zeros.
+      int j[NH];
+      bool on[NH];
+#pragma unroll
+      for (int e = 0; e < NH; e++) {
+        on[e] = m != 0u;
+        j[e] = on[e] ? wbase + __builtin_ctz(on[e] ? m : 1u) : j[0];
+        m &= m - 1u;                      // (0 stays 0)
+      }
+#pragma unroll
+      for (int e = 0; e < NH; e++) body(j[e], on[e]);
     }
   }
 }
@@ -370,7 +388,7 @@ __device__ __forceinline__ void for_each_overflow(const Walk &wk, int sub, T &&i
       while (m != 0u) {
         const int j = j0 + __builtin_ctz(m);
         m &= m - 1u;
-        body(j);
+        body(j, true);
       }
     }
 }
@@ -407,13 +425,14 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
     }
   }
   float rho = 0.f;
-  auto add = [&](int j) {
+  auto add = [&](int j, bool on) {
     const float2 o = P[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
     const float r2 = dx * dx + dy * dy;
-    rho += A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
+    const float w = A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
+    rho += on ? w : 0.f;
   };
-  for_each_hit<LPP>(sM, pl, sub, wk, add);
+  for_each_hit<LPP, TAUSPH_NH_D>(sM, pl, sub, wk, add);
   for_each_overflow<LPP>(wk, sub, [&](int j) {
     const float2 o = P[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
 }
 
 // acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
-template <int LPP, class ArrA, class ArrB>
+template <int LPP, bool VISC, class ArrA, class ArrB>
 __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], int pl, int sub, int kk, const Walk &wk,
                                            float4 me, float2 meB, ArrA RA, ArrB RB) {
   const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
@@ -470,31 +489,34 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], i
   // One neighbour inside the support.  Straight-line on purpose: the reference's skips (self, coincident
   // particles :231-233, gradW's r guard :119, receding pairs :254) become selects that contribute exact
   // zeros, which costs a few VALU ops but no exec-mask juggling inside the hottest loop of the pass.
-  auto add = [&](int j) {
+  auto add = [&](int j, bool on) {
     const float4 o = RA[j];
     const float2 oB = RB[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
     const float r2 = dx * dx + dy * dy;
-    const float r = __builtin_amdgcn_sqrtf(r2);
-    const bool valid = (j != kk) & (r2 > 1e-16f) & (r > 1e-8f);
+    // two transcendentals per pair instead of four (each is a quarter-rate instruction, and the pass is short of VALU issue):
+    // 1/r from rsq with r = r2 / r, and the two divisions of the viscosity term (:256-258) as one reciprocal of the product
+    const float ir = rsqf(r2), r = r2 * ir;
+    const bool valid = on & (j != kk) & (r2 > 1e-16f) & (r > 1e-8f);
     // gradW_cubic, :118-133
     const float q = r * ih, t = 2.0f - q;
-    const float dWdq = alpha * ((q < 1.0f) ? (-3.0f * q + 2.25f * q * q) : (-0.75f * t * t));
-    const float g = valid ? dWdq * ih * rcpf(r) : 0.f;
+    const float dWa = -3.0f * q + 2.25f * q * q, dWb = -0.75f * t * t;
+    const float dWdq = alpha * ((q < 1.0f) ? dWa : dWb);
+    const float g0 = dWdq * ih * ir;
+    const float g = valid ? g0 : 0.f;               // (a select of two VALUES: `valid ? expr : 0` becomes an exec-mask branch)
     const float gwx = g * dx, gwy = g * dy;
     float coef = -A.mass * (meB.x + oB.x);   // -m (p_i/rho_i^2 + p_j/rho_j^2)
-    if (A.useVisc) {
+    if (VISC) {   // (A.useVisc, resolved outside the loop: a uniform branch between the two evaluations of a trip would order them)
       const float dvx = me.z - o.z, dvy = me.w - o.w;
       const float dot = fminf(dvx * dx + dvy * dy, 0.f);   // receding pairs: mu = 0, Pi = 0, coef unchanged
-      const float mu = (h * dot) * rcpf(r2 + eps2);
-      const float rhoBar = 0.5f * (meB.y + oB.y);
-      const float Pi_ij = (-A.viscAlpha * A.c0 * mu) * rcpf(rhoBar);
+      // mu = h dot / (r2 + eps2), Pi = -alpha c0 mu / (0.5 (rho_i + rho_j))
+      const float Pi_ij = (-2.f * A.viscAlpha * A.c0 * h) * dot * rcpf((r2 + eps2) * (meB.y + oB.y));
       coef += -A.mass * Pi_ij;
     }
     ax += coef * gwx;
     ay += coef * gwy;
   };
-  for_each_hit<LPP>(sM, pl, sub, wk, add);
+  for_each_hit<LPP, TAUSPH_NH_F>(sM, pl, sub, wk, add);
   for_each_overflow<LPP>(wk, sub, [&](int j) {
     const float4 o = RA[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
@@ -530,9 +552,11 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    a = accel_of<LPP>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+    a = A.useVisc ? accel_of<LPP, true>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB)
+                  : accel_of<LPP, false>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
   } else {
-    a = accel_of<LPP>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+    a = A.useVisc ? accel_of<LPP, true>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
+                  : accel_of<LPP, false>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
   }
   if (sub != 0) return;
   float ax = a.x, ay = a.y;
