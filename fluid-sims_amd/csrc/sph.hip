@@ -385,10 +385,14 @@ __device__ __forceinline__ void for_each_overflow(const Walk &wk, int sub, T &&i
 #pragma unroll 4
       for (int b = 0; b < cnt; b++) m = m + m + (inrange(j0 + b) ? 1u : 0u);
       m = __builtin_bitreverse32(m) >> (32 - cnt);                 // candidate b -> bit b (cnt >= 1 here)
-      while (m != 0u) {
-        const int j = j0 + __builtin_ctz(m);
+      while (m != 0u) {                                            // two hits per trip, as in for_each_hit
+        const int ja = j0 + __builtin_ctz(m);
         m &= m - 1u;
-        body(j, true);
+        const bool two = m != 0u;
+        const int jb = two ? j0 + __builtin_ctz(two ? m : 1u) : ja;
+        m &= m - 1u;
+        body(ja, true);
+        body(jb, two);
       }
     }
 }
