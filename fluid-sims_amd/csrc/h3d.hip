@@ -914,6 +914,7 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
   }
 }
 
+#ifndef TAU3D_SPLIT_TU   // (the split-step translation unit holds k_flux_xy and k_update_z only, see below)
 __global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
   __shared__ StepLds S;
   // linear block id -> work item, XCD-contiguous
@@ -923,6 +924,7 @@ __global__ __launch_bounds__(NT, TAU3D_STEP_WAVES) void k_step(const Args A) {
   if (fast_form(A.clk->fmax_in, A.in_fmax)) step_body<true>(A, S, b, dt, gain, &A.clk->maxs_bits);
   else step_body<false>(A, S, b, dt, gain, &A.clk->maxs_bits);
 }
+#endif
 
 // ---------------------------------------------------------------- the split step: k_flux_xy + k_update_z
 // The fused kernel above carries a five-plane register window through a tile that also stages LDS planes: 168 VGPRs,
@@ -1187,6 +1189,11 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 #ifndef TAU3D_XY_WAVES
 #define TAU3D_XY_WAVES 6
 #endif
+// The two kernels of the split step are compiled in a translation unit of their own (this file again with -DTAU3D_SPLIT_TU,
+// Makefile: build/h3d_split.o) under `-mllvm -amdgpu-sched-strategy=max-ilp`: the ILP-first list scheduler is worth 1.5-2 % on
+// both (3.89 -> 3.82 and 2.29 -> 2.26 ms at 512^3, same box, interleaved) within their launch-bound register caps, while it takes
+// the fused k_step — bounded at two waves per SIMD — from 152 to 252 VGPRs and 96^3 from 92 to 105 us.  The option is per module.
+#ifdef TAU3D_SPLIT_TU
 __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyLds S;
 #ifdef TAU3D_FAST_ONLY   // ISA statistics only (scripts/isa_kernel_mix.py): the object then holds the one body that runs
@@ -1196,6 +1203,10 @@ __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   else flux_xy_body<false>(A, S);
 #endif
 }
+void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A) { hipLaunchKernelGGL(k_flux_xy, dim3(nwg), dim3(XNT), 0, s, A); }
+#else
+void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A);   // XNT threads per workgroup
+#endif
 
 // The update of one fluid cell, :1266-1358: conservative update from the x/y divergence D and the two z-face fluxes,
 // repairs, Landau-Teller relaxation, sponges, the max-wavespeed / max-|primitive| contributions, re-encoding.  One
@@ -1490,6 +1501,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   }
 }
 
+#ifdef TAU3D_SPLIT_TU
 __global__ __launch_bounds__(ZNT, 5) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
   __shared__ ZRing ring;
 #ifdef TAU3D_FAST_ONLY
@@ -1499,6 +1511,10 @@ __global__ __launch_bounds__(ZNT, 5) void k_update_z(const Args A) {   // 5 wave
   else update_z_body<false>(A, ring);
 #endif
 }
+void launch_update_z(unsigned nwg, hipStream_t s, const Args &A) { hipLaunchKernelGGL(k_update_z, dim3(nwg), dim3(ZNT), 0, s, A); }
+}  // namespace h3d — the split-step translation unit ends here
+#else
+void launch_update_z(unsigned nwg, hipStream_t s, const Args &A);   // ZNT threads per workgroup
 
 // ---------------------------------------------------------------- small kernels
 __global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes included
@@ -2108,7 +2124,7 @@ static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s)
   const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
   X.zchunk = 1; X.nzc1 = n1; X.nzc = n1 + n2;
   X.ntx = (X.nx + h3d::XT - 1) / h3d::XT; X.nty = (X.ny + h3d::YT - 1) / h3d::YT;
-  hipLaunchKernelGGL(h3d::k_flux_xy, dim3((unsigned)(X.ntx * X.nty * X.nzc)), dim3(h3d::XNT), 0, s, X);
+  h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X);
   TAU_LAUNCH_CHECK("k_flux_xy");
   return 0;
 }
@@ -2132,7 +2148,7 @@ static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipS
   Z.nzc1 = (n1 + Z.zchunk - 1) / Z.zchunk;
   Z.nzc = Z.nzc1 + (n2 ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
   if (pack) { Z.send[0] = h->xbuf[0][0]; Z.send[1] = h->xbuf[0][1]; }
-  hipLaunchKernelGGL(h3d::k_update_z, dim3((unsigned)(tz * Z.nzc)), dim3(h3d::ZNT), 0, s, Z);
+  h3d::launch_update_z((unsigned)(tz * Z.nzc), s, Z);
   TAU_LAUNCH_CHECK("k_update_z");
   return 0;
 }
@@ -2547,3 +2563,4 @@ extern "C" int tau3d_sync(tau3d_t *h) {
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
+#endif  // !TAU3D_SPLIT_TU

@@ -372,7 +372,9 @@ static int run_steps(Pair *pr, Args A, int nsteps) {
   static const bool fuse_env = !(getenv("TAU_ST2_FUSE") && atoi(getenv("TAU_ST2_FUSE")) == 0);
   static const int frows = getenv("TAU_ST2_FROWS") ? atoi(getenv("TAU_ST2_FROWS")) : 32;
   static const int kmax_env = getenv("TAU_ST2_LEVELS") ? atoi(getenv("TAU_ST2_LEVELS")) : 4;
-  const int kmax = pr->levels > 0 ? pr->levels : kmax_env;
+  // Burgers: three levels per pass (91 VGPRs, five waves per SIMD; the sinh / asinh round trip between levels is VALU work that
+  // four levels at 115 VGPRs / four waves hide less well: 302 against 289 Gcell/s at 8192^2), Gray-Scott / shallow water: four
+  const int kmax = pr->levels > 0 ? pr->levels : (getenv("TAU_ST2_LEVELS") ? kmax_env : (KIND == K_BURGERS ? 3 : 4));
   const bool fuse = fuse_env && kmax >= 2 && kmax <= 4 && (A.nx & 3) == 0 && A.nx >= 8 && A.ny >= 2;
   static const int bfast = getenv("TAU_ST2_BURGERS_FAST") ? atoi(getenv("TAU_ST2_BURGERS_FAST")) : 0;
   A.burgers_fast = bfast;
