@@ -1502,7 +1502,10 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 }
 
 #ifdef TAU3D_SPLIT_TU
-__global__ __launch_bounds__(ZNT, 5) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
+#ifndef TAU3D_Z_WAVES
+#define TAU3D_Z_WAVES 5
+#endif
+__global__ __launch_bounds__(ZNT, TAU3D_Z_WAVES) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
   __shared__ ZRing ring;
 #ifdef TAU3D_FAST_ONLY
   update_z_body<true>(A, ring);
