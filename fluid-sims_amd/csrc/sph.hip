@@ -279,6 +279,12 @@ constexpr int ROWCAP = 32 * WPR;    // candidates per row range covered by the m
 constexpr int NW = 3 * WPR;
 constexpr int CAP = 3 * (256 + 128); // staged records: 3 rows x (the workgroup's run + one cell either side)
 
+// per lanes-per-particle configuration: particles per workgroup and the staged records (LPP = 2: half the run, so half the
+// union: 24 KB instead of 40 per workgroup in the force pass — six workgroups per CU instead of four)
+template <int LPP> struct Cfg {
+  static constexpr int PPW = 256 / LPP;
+  static constexpr int CAPL = (LPP == 2) ? 3 * (128 + 128) : CAP;
+};
 struct Walk {                        // one lane's three candidate ranges
   int jb[3], jn[3];
 };
@@ -303,7 +309,7 @@ struct Stage {
   int base[3], len[3], delta[3];
   bool on;
 };
-__device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw) {
+__device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw, int cap) {
   Stage st;
   const int kl = min(k0 + ppw - 1, A.N - 1);
   const int c0 = (int)A.keys_s[k0], c1 = (int)A.keys_s[kl];
@@ -319,7 +325,7 @@ __device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw) {
     st.delta[r] = total - st.base[r];
     total += st.len[r];
   }
-  st.on = (c1 / A.Gx == gy) && total <= CAP;
+  st.on = (c1 / A.Gx == gy) && total <= cap;
   return st;
 }
 
@@ -336,8 +342,8 @@ __device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw) {
 #ifndef TAUSPH_NH_F
 #define TAUSPH_NH_F 2   // forces pass
 #endif
-template <int LPP, int NH, class F>
-__device__ __forceinline__ void for_each_hit(const unsigned (*sM)[256], int pl, int sub, const Walk &wk, F &&body) {
+template <int LPP, int NH, int PW, class F>
+__device__ __forceinline__ void for_each_hit(const unsigned (*sM)[PW], int pl, int sub, const Walk &wk, F &&body) {
   int w = sub;
   unsigned m = sM[w][pl];
   const int b0 = wk.jb[0], d1 = wk.jb[1] - wk.jb[0], d2 = wk.jb[2] - wk.jb[1];
@@ -397,13 +403,14 @@ __device__ __forceinline__ void for_each_overflow(const Walk &wk, int sub, T &&i
     }
 }
 template <int LPP> __device__ __forceinline__ float quad_sum(float v) {
-  if (LPP == 4) { v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); }
+  if (LPP >= 2) v += __shfl_xor(v, 1, 64);
+  if (LPP == 4) v += __shfl_xor(v, 2, 64);
   return v;
 }
 
 // density of one particle; P indexes candidate positions (LDS slots or sorted records — wk is in the same space)
-template <int LPP, class PosArr>
-__device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], int pl, int sub, int k, const Walk &wk,
+template <int LPP, int PW, class PosArr>
+__device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int k, const Walk &wk,
                                             float2 me, PosArr P) {
   const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
   const float ih = 1.0f / A.h;
@@ -436,7 +443,7 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
     const float w = A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
     rho += on ? w : 0.f;
   };
-  for_each_hit<LPP, TAUSPH_NH_D>(sM, pl, sub, wk, add);
+  for_each_hit<LPP, TAUSPH_NH_D, PW>(sM, pl, sub, wk, add);
   for_each_overflow<LPP>(wk, sub, [&](int j) {
     const float2 o = P[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
@@ -447,11 +454,11 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[256], 
 
 template <int LPP>
 __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pressure_cell, :178-213
-  constexpr int PPW = 256 / LPP;      // particles per workgroup
-  __shared__ unsigned sM[NW][256];
-  __shared__ float2 sP[CAP];
+  constexpr int PPW = Cfg<LPP>::PPW;      // particles per workgroup
+  __shared__ unsigned sM[NW][PPW];
+  __shared__ float2 sP[Cfg<LPP>::CAPL];
   const int tid = threadIdx.x, pl = tid / LPP, sub = tid % LPP, k0 = blockIdx.x * PPW, k = k0 + pl;
-  const Stage st = make_stage(A, k0, PPW);
+  const Stage st = make_stage(A, k0, PPW, Cfg<LPP>::CAPL);
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -465,9 +472,9 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    rho = density_of<LPP>(A, sM, pl, sub, k, wk, me, (const float2 *)sP);
+    rho = density_of<LPP, PPW>(A, sM, pl, sub, k, wk, me, (const float2 *)sP);
   } else {
-    rho = density_of<LPP>(A, sM, pl, sub, k, wk, me, (const float2 *)A.recP);
+    rho = density_of<LPP, PPW>(A, sM, pl, sub, k, wk, me, (const float2 *)A.recP);
   }
   if (sub != 0) return;
   const float si = logf(fmaxf(rho, 1e-6f));
@@ -482,8 +489,8 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
 }
 
 // acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
-template <int LPP, bool VISC, class ArrA, class ArrB>
-__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], int pl, int sub, int kk, const Walk &wk,
+template <int LPP, bool VISC, int PW, class ArrA, class ArrB>
+__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int kk, const Walk &wk,
                                            float4 me, float2 meB, ArrA RA, ArrB RB) {
   const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
   const float ih = 1.0f / h;
@@ -520,7 +527,7 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], i
     ax += coef * gwx;
     ay += coef * gwy;
   };
-  for_each_hit<LPP, TAUSPH_NH_F>(sM, pl, sub, wk, add);
+  for_each_hit<LPP, TAUSPH_NH_F, PW>(sM, pl, sub, wk, add);
   for_each_overflow<LPP>(wk, sub, [&](int j) {
     const float4 o = RA[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
@@ -531,12 +538,12 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[256], i
 
 template <int LPP>
 __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell :215-272 + k_integrate :324-355
-  constexpr int PPW = 256 / LPP;
-  __shared__ unsigned sM[NW][256];
-  __shared__ float4 sA[CAP];
-  __shared__ float2 sB[CAP];
+  constexpr int PPW = Cfg<LPP>::PPW;
+  __shared__ unsigned sM[NW][PPW];
+  __shared__ float4 sA[Cfg<LPP>::CAPL];
+  __shared__ float2 sB[Cfg<LPP>::CAPL];
   const int tid = threadIdx.x, pl = tid / LPP, sub = tid % LPP, k0 = blockIdx.x * PPW, k = k0 + pl;
-  const Stage st = make_stage(A, k0, PPW);
+  const Stage st = make_stage(A, k0, PPW, Cfg<LPP>::CAPL);
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++)
@@ -556,11 +563,11 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    a = A.useVisc ? accel_of<LPP, true>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB)
-                  : accel_of<LPP, false>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB)
+                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
   } else {
-    a = A.useVisc ? accel_of<LPP, true>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
-                  : accel_of<LPP, false>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
+                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
   }
   if (sub != 0) return;
   float ax = a.x, ay = a.y;
@@ -750,7 +757,7 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   h->built = false;
   h->fuse_count = !(getenv("TAU_SPH_FUSE_COUNT") && atoi(getenv("TAU_SPH_FUSE_COUNT")) == 0);
   h->lpp = (P->N < (1 << 17)) ? 4 : 1;
-  if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 4) h->lpp = v; }
+  if (const char *e = getenv("TAU_SPH_LPP")) { int v = atoi(e); if (v == 1 || v == 2 || v == 4) h->lpp = v; }
 
   h->tau = 0.f; h->t = P->t0 * expf(h->tau); h->step = 0; // :577-578
   *out = guard.release();
@@ -876,6 +883,12 @@ extern "C" int tausph_substep_async(tausph_t *h, float dt) { // the five launche
     hipLaunchKernelGGL(sph::k_density<4>, dim3(gq), dim3(256), 0, h->stream, A);
     TAU_LAUNCH_CHECK("sph::k_density");
     hipLaunchKernelGGL(sph::k_forces<4>, dim3(gq), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_forces");
+  } else if (h->lpp == 2) {
+    const unsigned gh = (unsigned)((A.N + 127) / 128);
+    hipLaunchKernelGGL(sph::k_density<2>, dim3(gh), dim3(256), 0, h->stream, A);
+    TAU_LAUNCH_CHECK("sph::k_density");
+    hipLaunchKernelGGL(sph::k_forces<2>, dim3(gh), dim3(256), 0, h->stream, A);
     TAU_LAUNCH_CHECK("sph::k_forces");
   } else {
     hipLaunchKernelGGL(sph::k_density<1>, dim3(gs), dim3(256), 0, h->stream, A);
