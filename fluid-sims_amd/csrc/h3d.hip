@@ -1174,7 +1174,9 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   const int bz = (int)(b / (unsigned)A.nty);
   const int z = (bz >= A.nzc1) ? A.zl_lo2 + (bz - A.nzc1) : A.zl_lo + bz;   // here a "chunk" is one plane
   // one scalar load, one scalar branch: ~90 % of the tiles of the 512^3 sphere case hold no solid cell
-  const bool any_solid = A.xyflag == nullptr || A.xyflag[((size_t)z * A.nty + by) * A.ntx + bx] != 0u;
+  const unsigned tflag = A.xyflag == nullptr ? 1u : A.xyflag[((size_t)z * A.nty + by) * A.ntx + bx];
+  if (tflag == 2u) return;   // the tile is inside the body: no cell of it takes a divergence (4 % of the tiles of the 512^3 sphere case)
+  const bool any_solid = tflag != 0u;
   if (any_solid) flux_xy_core<FAST, true>(A, S, C, bx, by, z);
   else flux_xy_core<FAST, false>(A, S, C, bx, by, z);
   if (C.in_xy && !C.own_solid) {
@@ -1408,7 +1410,18 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     const char *const rb = (const char *)&ring[0][0][0];   // byte offsets: what ds_read takes, the variable's part as its immediate
     auto rd = [&](int a, int m) { return *(const float *)(rb + a + m * (ZNT * 4)); };
     const int t4 = tid * 4;
-    {
+    // A wave whose 64 columns are inside the body at planes z AND z+1 needs no z face here: both cells either side are copied
+    // through (the reference's threads return at once there, :1063-1072), and the left state carried to the next face is
+    // discarded there too — plane z+1 is in that face's stencil, so it takes the first-order / mirror form (solid_override).
+    const bool face_dead = __builtin_amdgcn_ballot_w64(in_xy && ((ws >> 2) & 3u) != 3u) == 0ull;
+    if (face_dead) {
+      if (more) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
+      }
+#pragma unroll
+      for (int m = 0; m < 6; m++) Fz_hi[m] = 0.f;
+    } else {
       Prim L, R;
 #pragma unroll
       for (int m = 0; m < 6; m++) L.q[m] = Lz[m];
@@ -1543,15 +1556,22 @@ __global__ __launch_bounds__(256) void k_xy_flags(Args A, const uint8_t *solid, 
   const int z = (int)(b / (unsigned)nty);
   const int zh = z + HALO, zg = wrapi(A.z0 + z, A.nz);
   constexpr int RX = XT + 2 * HALO, RY = YT + 2 * HALO;
-  int any = 0;
+  int any = 0, fluid_own = 0;   // fluid_own: a cell of the tile itself (inside the grid) that is NOT solid
   for (int i = threadIdx.x; i < RX * RY; i += 256) {
-    const int gx = bx * XT + (i % RX) - HALO;
-    const int gy = wrapi(by * YT + (i / RX) - HALO, A.ny);
-    if (gx >= 0 && gx < A.nx) any |= solid[((size_t)zh * A.ny + gy) * A.nx + gx] != 0;
-    else any |= sdf_solid(A, gx, gy, zg) ? 1 : 0;
+    const int ix = (i % RX) - HALO, iy = (i / RX) - HALO;
+    const int gx = bx * XT + ix, gyu = by * YT + iy;
+    const int gy = wrapi(gyu, A.ny);
+    bool sol;
+    if (gx >= 0 && gx < A.nx) sol = solid[((size_t)zh * A.ny + gy) * A.nx + gx] != 0;
+    else sol = sdf_solid(A, gx, gy, zg);
+    any |= sol ? 1 : 0;
+    if (ix >= 0 && ix < XT && iy >= 0 && iy < YT && gx < A.nx && gyu < A.ny) fluid_own |= sol ? 0 : 1;
   }
   any = __syncthreads_or(any);
-  if (threadIdx.x == 0) flags[blockIdx.x] = any ? 1u : 0u;
+  fluid_own = __syncthreads_or(fluid_own);
+  // 0: no solid cell in reach; 1: some; 2: every cell of the tile is solid — solid cells are copied through by k_update_z and take
+  // no divergence (the reference's threads return at once there, :1063-1072), so k_flux_xy has nothing to produce for the tile
+  if (threadIdx.x == 0) flags[blockIdx.x] = !any ? 0u : (fluid_own ? 1u : 2u);
 }
 
 struct InitVals { float f[6]; float s[6]; }; // encoded fluid / solid cell values (host-computed, libm)
