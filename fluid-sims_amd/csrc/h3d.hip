@@ -103,6 +103,7 @@ struct Args {
   int zl_lo, zl_hi;          // local plane range to update
   int zl_lo2, zl_hi2, nzc1;  // optional second range in the same launch (chunks >= nzc1 belong to it); nzc1 = nzc if unused
   int zchunk;                // planes marched by one workgroup
+  int wrap_halo;             // k_update_z (single periodic domain): the first / last three new planes also go into the opposite z halo
   int ntx, nty, nzc;         // tiles in x, y; chunks in z
   float dx, dy, dz, inv_dx, inv_dy, inv_dz;
   float u_ref, inv_u_ref, R, gamma, gm1, inv_gm1, Twall, theta_v, Rtheta, inv_tau_vib;
@@ -1493,6 +1494,18 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         if (z < HALO) send_plane(A.send[0], z);
         else if (z >= A.nzl - HALO) send_plane(A.send[1], z - (A.nzl - HALO));
       }
+      // single periodic domain: the same planes are the NEW state's z halos (what k_halo_periodic would copy before the next
+      // step: 37.7 MB and a dependent dispatch); halo layout, local plane z sits at z + HALO
+      if (A.wrap_halo) {
+        auto wrap_plane = [&](int zh) {
+          GChar *const wB = (GChar *)(A.out0 + (size_t)zh * plane_n);
+          const unsigned vb = lane_off(col4);
+#pragma unroll
+          for (int m = 0; m < 6; m++) gst(wB + m * f4, vb, E[m]);
+        };
+        if (z < HALO) wrap_plane(z + A.nzl + HALO);
+        if (z >= A.nzl - HALO) wrap_plane(z - A.nzl + HALO);
+      }
     }
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
@@ -1610,12 +1623,13 @@ __device__ __forceinline__ void clock_end(DevClock *c) { // d_tau controller, :1
 // The single-domain step loop folds the two 1-thread clock kernels into the halo copy that precedes every k_step
 // (controller of the step before, then the clock of this one): two dependent dispatches per step instead of four,
 // which is what a 64^3 run is made of (clk == nullptr: plain halo copy).
-struct HaloArgs { float *f[6]; size_t plane_n; int nzl; DevClock *clk; int do_end; };
+struct HaloArgs { float *f[6]; size_t plane_n; int nzl; DevClock *clk; int do_end; int copy; };
 __global__ void k_halo_periodic(HaloArgs H) {
   if (H.clk && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     if (H.do_end) clock_end(H.clk);
     clock_begin(H.clk);
   }
+  if (!H.copy) return;          // the halos are in place (k_update_z wrote them): the clock only
   const size_t n4 = (size_t)HALO * H.plane_n; // floats per halo block
   const int f = blockIdx.y >> 1, side = blockIdx.y & 1;
   float *base = H.f[f];
@@ -1853,6 +1867,8 @@ struct tau3d {
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
   bool end_pending;         // the controller update of the last tau3d_step_async step has not run yet
+  bool halo_fresh = false;  // the z halos of the current state are in place (written by the k_update_z of a tau3d_step_async step)
+  bool wrap_now = false;    // the step being issued is such a step
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
   float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
@@ -2032,6 +2048,7 @@ static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
 }
 
 extern "C" int tau3d_init(tau3d_t *h, int mode) {
+  h->halo_fresh = false;
   TAU_HIP(hipSetDevice(h->device));
   const tau3d_params &P = h->p;
   if (build_solid(h)) return 1;
@@ -2057,6 +2074,7 @@ extern "C" int tau3d_init(tau3d_t *h, int mode) {
 }
 
 extern "C" int tau3d_upload_state(tau3d_t *h, const float *const host[6]) {
+  h->halo_fresh = false;
   TAU_HIP(hipSetDevice(h->device));
   size_t n = h->plane_n * (size_t)h->nzl;
   for (int f = 0; f < 6; f++)
@@ -2086,6 +2104,7 @@ extern "C" int tau3d_download_solid(tau3d_t *h, uint8_t *host) {
   return 0;
 }
 static int planes_copy(tau3d_t *h, int zl_lo, int zl_hi, const float *const up[6], float *const down[6]) {
+  h->halo_fresh = false;
   if (zl_lo < -h3d::HALO || zl_hi > h->nzl + h3d::HALO || zl_lo >= zl_hi)
     return tau::fail("tau3d planes: range [%d,%d) outside [-3,%d)", zl_lo, zl_hi, h->nzl + 3);
   TAU_HIP(hipSetDevice(h->device));
@@ -2122,6 +2141,9 @@ static int fill_halo(tau3d_t *h, bool with_clock) {
   H.clk = with_clock ? h->clk : nullptr; H.do_end = h->end_pending ? 1 : 0;
   for (int f = 0; f < 6; f++) H.f[f] = h->buf[h->cur][f];
   H.plane_n = h->plane_n; H.nzl = h->nzl;
+  H.copy = (with_clock && h->halo_fresh) ? 0 : 1;
+  if (!H.copy) hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(1, 1), dim3(64), 0, h->stream, H);
+  else
   hipLaunchKernelGGL(h3d::k_halo_periodic, dim3(64, 12), dim3(256), 0, h->stream, H);
   TAU_LAUNCH_CHECK("k_halo_periodic");
   if (with_clock) h->end_pending = false;
@@ -2140,6 +2162,7 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.in0 = h->buf[h->cur][0]; A.out0 = h->buf[h->cur ^ 1][0];
   A.d0 = h->dxy[0]; A.fstride = (unsigned)h->field_stride; A.dstride = (unsigned)h->dxy_stride;
   A.xyflag = h->xyflag;
+  A.wrap_halo = (h->wrap_now && lo == 0 && hi == h->nzl && lo2 >= hi2) ? 1 : 0;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s) {   // x/y faces: one plane per workgroup
   h3d::Args X;
@@ -2182,6 +2205,7 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
   const bool two = zl_lo2 < zl_hi2;
   if (two && (zl_lo2 < zl_hi || zl_hi2 > h->nzl)) return tau::fail("tau3d_step_edges: bad second range [%d,%d)", zl_lo2, zl_hi2);
   TAU_HIP(hipSetDevice(h->device));
+  h->halo_fresh = false;   // (tau3d_step_async sets it again after a step whose k_update_z wrote the halos)
   h3d::Args A = h->base;
   for (int f = 0; f < 6; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.zl_lo = zl_lo; A.zl_hi = zl_hi;
@@ -2309,6 +2333,7 @@ extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
   return slab_timed(h, h->nzl - 2 * depth, slab_interior_body, depth);
 }
 extern "C" int tau3d_slab_end_async(tau3d_t *h) {
+  h->halo_fresh = false;
   h->cur ^= 1;             // std::swap x6, :1706-1711
   h->end_pending = true;   // the controller update (after the caller's all-reduce) rides on the next tau3d_slab_begin_async
   return 0;
@@ -2321,6 +2346,7 @@ extern "C" int tau3d_clock_begin_async(tau3d_t *h) {
   return 0;
 }
 extern "C" int tau3d_clock_end_async(tau3d_t *h) {
+  h->halo_fresh = false;
   hipLaunchKernelGGL(h3d::k_clock_end, dim3(1), dim3(1), 0, h->stream, h->clk);
   TAU_LAUNCH_CHECK("k_clock_end");
   h->cur ^= 1; // std::swap x6, :1706-1711
@@ -2332,7 +2358,13 @@ extern "C" int tau3d_step_async(tau3d_t *h, int nsteps) {
   TAU_HIP(hipSetDevice(h->device));
   for (int s = 0; s < nsteps; s++) {
     if (fill_halo(h, true)) return 1;                        // + controller of the previous step + clock of this one
-    if (tau3d_step_range_async(h, 0, h->nzl, nullptr)) return 1;
+    // split step: k_update_z writes the new state's z halos itself (the copy above then only runs after init / upload / ...)
+    h->wrap_now = h->split && h->nzl >= 2 * h3d::HALO && !getenv("TAU3D_NO_WRAP");
+    const int rc = step_ranges(h, 0, h->nzl, 0, 0, nullptr);
+    const bool wrapped = h->wrap_now;
+    h->wrap_now = false;
+    if (rc) return 1;
+    h->halo_fresh = wrapped;
     h->cur ^= 1;                                             // std::swap x6, :1706-1711
     h->end_pending = true;                                   // its controller update rides on the next halo copy
   }
@@ -2393,6 +2425,7 @@ extern "C" int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, siz
   return 0;
 }
 extern "C" int tau3d_state_written(tau3d_t *h) {
+  h->halo_fresh = false;
   TAU_HIP(hipSetDevice(h->device));
   return measure_field(h, -h3d::HALO, h->nzl + h3d::HALO, false);
 }

@@ -413,3 +413,34 @@ np.save(sys.argv[1], np.stack(e.download()))
     assert np.isfinite(outs[0]).all()
     for o in outs[1:]:
         assert np.array_equal(o, outs[0])
+
+
+def test_z_halos_written_by_the_step_itself(eng):
+    """tau3d_step_async on the split path: k_update_z writes the new state's periodic z halos (no halo copy between steps).
+    (a) after a run the halo planes ARE the opposite interior planes; (b) a run whose halos are declared stale half way (any
+    plane transfer does: the next step then copies them with k_halo_periodic, as every step did before) ends bit-identical."""
+    shape = (160, 128, 24)
+
+    def fresh():
+        e = eng.Tau3D(*shape)
+        assert e.is_split()
+        e.init(1)
+        e.set_clock(0.02, 1e-4)
+        return e
+    a = fresh()
+    a.step(7)
+    nz = shape[2]
+    for got, want in ((a.download_planes(-3, 0), a.download_planes(nz - 3, nz)), (a.download_planes(nz, nz + 3), a.download_planes(0, 3))):
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    want, wclock = a.download(), a.clock().as_dict()
+    a.close()
+    b = fresh()
+    for _ in range(7):
+        b.step_async(1)
+        b.download_planes(0, 1)
+    got, gclock = b.download(), b.clock().as_dict()
+    b.close()
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w)
+    assert gclock == wclock
