@@ -323,6 +323,7 @@ def main():
             torch.cuda.synchronize()
 
     ring_info = None
+    closer = None
     if not use_ring:
         eng = f.Tau3D(n, n, n, params=params, device=local)
         eng.init(1)
@@ -331,39 +332,61 @@ def main():
         sync = eng.sync
         get_clock = eng.clock
         h = eng
-    elif py_ring:
-        from importlib import import_module
-        slab = import_module("fluid_sims_amd.slab")
-        be = slab.EngineSlabBackend(f.taueng, params, z0, nzl, local)
-        be.h.init(1)
-        be.h.set_clock(0.02, 1e-4)
-        ring = slab.SlabRing(be, rank, world, self_p2p=args.self_p2p)
-        ring.prime()
-        step = lambda k: ring.step(k)               # noqa: E731
-        sync = ring.finish
-        get_clock = be.h.clock
-        h = be.h
-        ring_info = {"driver": "python (torch.distributed batch_isend_irecv + all_reduce)"}
     else:
-        # the library's ring: every rank passes the same rendezvous path and job key (agreed through torch.distributed)
-        key = torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device="cpu" if shared else dev)
-        if world > 1:
-            dist.broadcast(key, 0)
-        key = int(key.item())
-        eng = f.Tau3D(n, n, n, params=params, z0=z0, nzl=nzl, device=local)
-        eng.init(1)
-        eng.set_clock(0.02, 1e-4)
-        transport = f.RING_HOST if (shared and world > 1) else (f.RING_RCCL if (world > 1 or args.self_p2p) else f.RING_LOCAL)
-        ring = f.Tau3DRing(eng, rank, world, transport, rendezvous=f"/dev/shm/tau3d_bench_{key & 0xffffffffff:x}" if world > 1 else None,
-                           job_key=key)
-        ring.prime()
-        step = lambda k: ring.step(k)               # noqa: E731
-        sync = ring.finish
-        get_clock = ring.clock
-        h = eng
-        ring_info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)",
-                         transport={f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies",
-                                    f.RING_HOST: "host-staged (ranks share a device: not a performance configuration)"}[transport])
+        def python_ring(why=None):
+            from importlib import import_module
+            slab = import_module("fluid_sims_amd.slab")
+            be = slab.EngineSlabBackend(f.taueng, params, z0, nzl, local)
+            be.h.init(1)
+            be.h.set_clock(0.02, 1e-4)
+            ring = slab.SlabRing(be, rank, world, self_p2p=args.self_p2p and need_pg)
+            ring.prime()
+            info = {"driver": "python (torch.distributed batch_isend_irecv + all_reduce)"}
+            if why:
+                info["fallback_from_c_ring"] = why
+            return (lambda k: ring.step(k)), ring.finish, be.h.clock, be.h, info, None
+
+        def c_ring():
+            # the library's ring: every rank passes the same rendezvous path and job key (agreed through torch.distributed)
+            key = torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device="cpu" if shared else dev)
+            if world > 1:
+                dist.broadcast(key, 0)
+            key = int(key.item())
+            eng = f.Tau3D(n, n, n, params=params, z0=z0, nzl=nzl, device=local)
+            eng.init(1)
+            eng.set_clock(0.02, 1e-4)
+            transport = f.RING_HOST if (shared and world > 1) else (f.RING_RCCL if (world > 1 or args.self_p2p) else f.RING_LOCAL)
+            err = None
+            ring = None
+            try:
+                if os.environ.get("TAU_BENCH_FAIL_C_RING"):
+                    raise RuntimeError("TAU_BENCH_FAIL_C_RING is set (test of the fallback)")
+                ring = f.Tau3DRing(eng, rank, world, transport,
+                                   rendezvous=f"/dev/shm/tau3d_bench_{key & 0xffffffffff:x}" if world > 1 else None, job_key=key)
+                ring.prime()
+            except Exception as e:  # a rank that cannot build the ring tells the others (below): all of them fall back together
+                err = f"rank {rank}: {e}"
+            if world > 1:   # agree: the C ring runs only if EVERY rank has it
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if shared else dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0 and err is None:
+                    err = "another rank could not create the C ring"
+            if err:
+                if ring is not None:
+                    ring.close()
+                eng.close()
+                return None, err
+            info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)",
+                        transport={f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies",
+                                   f.RING_HOST: "host-staged (ranks share a device: not a performance configuration)"}[transport])
+            return ((lambda k: ring.step(k)), ring.finish, ring.clock, eng, info, ring.close), None
+
+        got, why = (None, None) if py_ring else c_ring()
+        if got is None:
+            if why and rank == 0:
+                print(f"bench.py: C ring unavailable ({why}); falling back to the torch.distributed ring", file=sys.stderr)
+            got = python_ring(why)
+        step, sync, get_clock, h, ring_info, closer = got
 
     step(args.warmup)
     sync()
@@ -489,8 +512,8 @@ def main():
             pass
         print(json.dumps(out), flush=True)
 
-    if use_ring and not py_ring:
-        ring.close()
+    if use_ring and closer is not None:
+        closer()
     if need_pg:
         dist.destroy_process_group()
 

@@ -151,3 +151,17 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(eng):
     assert j["n_gpus"] == 2 and j["config"]["decomposition"] == "z-slab x2" and j["value"] > 0
     assert len(j["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and all(t > 0 for t in j["roofline"]["per_rank_kernel_ms_per_step"])
     assert "host-staged" in j["ring"]["transport"]
+
+
+def test_bench_falls_back_to_the_torch_ring_when_the_c_ring_cannot_be_built(eng):
+    """every rank agrees (all-reduce of a flag) before the C ring is used; if one cannot build it, all of them run the
+    torch.distributed ring of rounds 1-2 instead and the JSON line says so"""
+    import json
+    import sys
+    env = dict(os.environ, TAU_BENCH_FAIL_C_RING="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "3", "--warmup", "1",
+                        "--ring-transport", "host"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["value"] > 0
+    assert "python" in j["ring"]["driver"] and "TAU_BENCH_FAIL_C_RING" in j["ring"]["fallback_from_c_ring"]
