@@ -16,7 +16,12 @@ TOL_CONS = 1e-5     # relative on the conserved variables rho, m, E against the 
 #       kappa = (gamma-1) * E / p          (conditioning of p w.r.t. the conserved energy).
 # lam = ln p therefore gets the tolerance 1e-5 * max(1, kappa), i.e. 1e-5 relative to the energy
 # scale it is derived from; e_vib relaxes towards e_eq(T(p)) in the same step
-# (tau_hypersonic_3d_cuda.cu:1290-1292) and inherits the same factor.
+# (tau_hypersonic_3d_cuda.cu:1290-1292) and inherits the same factor — which is why the sixth conserved
+# variable rho*e_v is reported but asserted through zet/kappa, not at a literal 1e-5.  Measured (round 4,
+# tests/test_gpu_ref3d.py: THE REFERENCE'S OWN k_step on the MI355X as the third party): on one step from the same
+# developed state the IEEE host oracle differs from the reference kernel by 1.2e-4 in rho*e_v (32^3; 6e-5 .. 1.1e-4
+# on the other shapes) — exactly what the engine differs from it by (1.2e-4; 4e-5 .. 2.1e-4 up to 512^3) — while
+# rho, m, E agree to 2e-6 and zet/kappa to 6e-6 for both.
 
 
 def decode(st):
@@ -81,3 +86,24 @@ def assert_parity(got, want, mask=None, what=""):
             bad[name + "/kappa"] = r[name + "/kappa"]
     assert not bad, f"{what}: out of tolerance {bad}; all = {r}"
     return r
+
+
+def cells_beyond(got, want, mask=None, tol=TOL_CONS):
+    """how many cells have ANY of xi, phi (absolute), rho, m, E (relative to the cell scale) beyond tol, and the worst value"""
+    bad = np.zeros(np.asarray(got[0]).shape, bool)
+    worst = 0.0
+    for i in range(4):
+        d = np.abs(np.asarray(got[i], np.float64) - np.asarray(want[i], np.float64))
+        if mask is not None:
+            d = np.where(mask, d, 0.0)
+        bad |= ~(d <= tol)
+        worst = max(worst, float(np.nanmax(d)))
+    Ug, _ = conserved(got)
+    Uw, sc = conserved(want)
+    for g, w, s_ in list(zip(Ug, Uw, sc))[:5]:
+        d = np.abs(g - w) / s_
+        if mask is not None:
+            d = np.where(mask, d, 0.0)
+        bad |= ~(d <= tol)
+        worst = max(worst, float(np.nanmax(d)))
+    return int(bad.sum()), worst
