@@ -77,7 +77,7 @@ static int run_rank(const opts_t *o, int rank, const char *rv, uint64_t key) {
     else if (show) TAU_CK(tau3d_step(h, steps_per_frame, &c));
     else TAU_CK(tau3d_step_async(h, steps_per_frame));
     if (show && rank == 0) /* the reference's HUD line, :1762-1771 */
-      printf("frame %d  step %d  t=%.6g  d_tau=%.4g  dt=%.4g  gain=%.3f  maxs=%.6g\n", f, c.step, c.t, c.d_tau, c.dt,
+      printf("frame %d  step %d  t=%.9g  d_tau=%.9g  dt=%.9g  gain=%.3f  maxs=%.9g\n", f, c.step, c.t, c.d_tau, c.dt,
              c.gain, c.maxs);
   }
   if (use_ring) { TAU_CK(tau3d_ring_finish(r)); TAU_CK(tau3d_ring_barrier(r)); }

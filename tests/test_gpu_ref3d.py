@@ -56,13 +56,18 @@ def test_mask_and_init_match_the_reference_kernels(eng, oracle_built, refgpu, sh
     ri.close()
 
 
-@pytest.mark.parametrize("shape,mode,warm,split", [
-    ((32, 32, 32), 0, 0, None), ((32, 32, 32), 1, 30, None), ((48, 40, 24), 1, 25, None), ((64, 64, 64), 1, 40, None),
-    ((96, 64, 32), 1, 40, None), ((96, 64, 32), 1, 40, True), ((160, 128, 96), 1, 40, True), ((256, 192, 128), 1, 40, True)])
-def test_single_step_engine_and_oracle_vs_reference_kernel(eng, oracle_built, refgpu, shape, mode, warm, split):
+# rcp = True forces the reciprocal WENO weights (TAU3D_WENO_RCP, read at tau3d_create): with split = True that is
+# flux_xy_body<false> / update_z_body<false>, the general-form bodies of the benchmarked kernel pair
+@pytest.mark.parametrize("shape,mode,warm,split,rcp", [
+    ((32, 32, 32), 0, 0, None, False), ((32, 32, 32), 1, 30, None, False), ((48, 40, 24), 1, 25, None, False), ((64, 64, 64), 1, 40, None, False),
+    ((96, 64, 32), 1, 40, None, False), ((96, 64, 32), 1, 40, True, False), ((160, 128, 96), 1, 40, True, False), ((256, 192, 128), 1, 40, True, False),
+    ((64, 64, 64), 1, 40, None, True), ((96, 64, 32), 1, 40, True, True), ((160, 128, 96), 1, 40, True, True), ((256, 192, 128), 1, 40, True, True)])
+def test_single_step_engine_and_oracle_vs_reference_kernel(eng, oracle_built, refgpu, shape, mode, warm, split, rcp, monkeypatch):
     """ONE k_step of the reference on the state the engine developed; the engine's step and the oracle's step on the same
     input must both land within 1e-5 of it."""
     nx, ny, nz = shape
+    if rcp:
+        monkeypatch.setenv("TAU3D_WENO_RCP", "1")
     e = eng.Tau3D(nx, ny, nz)
     if split is not None:
         e.set_split(split)
@@ -76,6 +81,8 @@ def test_single_step_engine_and_oracle_vs_reference_kernel(eng, oracle_built, re
     assert all(np.isfinite(a).all() and np.abs(a).max() < 30 for a in state)
     dt = float(np.float32(c.t * np.float32(np.exp(np.float32(c.d_tau)))) * np.float32(c.d_tau))
     gain = 1.0 if mode else 0.0005
+    if warm:
+        assert e.field_range()[2] == (not rcp)       # which weight form the step below takes
     r = refgpu.Ref3D(nx, ny, nz)
     r.upload(state)
     m_ref = r.step(dt, gain)
@@ -139,12 +146,15 @@ def test_reference_kernel_trajectory_reproduces_the_recorded_checkvalues(eng, re
 # developed state that exists is the ramped one: 2500 steps (gain 0.8, bow shock standing, wake formed).
 # At the END of bench.py's window (step 45, ten steps before the run-away) the lee-side cells that are about to go are already
 # ill-conditioned: the engine and the reference kernel differ by up to 4e-5 in phix / m_x in a few of the 118 M fluid cells
-# (everything else <= 6e-6) — that case asserts the count and the bound instead of the literal 1e-5.
-@pytest.mark.parametrize("start,warm,allow", [("impulsive", 25, 0), ("impulsive", 35, 0), ("impulsive", 45, 2000), ("ramped", 2500, 0)])
-def test_full_size_512_cubed_vs_reference_kernel(eng, refgpu, start, warm, allow):
+# (87 cells, everything else <= 6e-6) — that case asserts the count and the bound instead of the literal 1e-5.
+@pytest.mark.parametrize("start,warm,allow,rcp", [("impulsive", 25, 0, False), ("impulsive", 35, 0, False), ("impulsive", 45, 500, False),
+                                                  ("ramped", 2500, 0, False), ("impulsive", 25, 0, True)])
+def test_full_size_512_cubed_vs_reference_kernel(eng, refgpu, start, warm, allow, rcp, monkeypatch):
     """BASELINE.json's size, every cell of the 512^3 domain: one step of the kernel pair bench.py times against one k_step of the
     reference on the same developed state."""
     n = 512
+    if rcp:        # the reciprocal-weight bodies of the kernel pair, at full size
+        monkeypatch.setenv("TAU3D_WENO_RCP", "1")
     e = eng.Tau3D(n)
     assert e.is_split()
     if start == "impulsive":
@@ -157,7 +167,8 @@ def test_full_size_512_cubed_vs_reference_kernel(eng, refgpu, start, warm, allow
     state = e.download()
     dt = float(np.float32(c.t * np.float32(np.exp(np.float32(c.d_tau)))) * np.float32(c.d_tau))
     gain = float(min(max(np.float32(c.t * np.float32(np.exp(np.float32(c.d_tau)))) / np.float32(0.02), 0.0), 1.0))
-    assert e.field_range()[2], "the state must be a sane one (inside the fast WENO window)"
+    fr = e.field_range()
+    assert max(fr[0], fr[1]) <= 6e4 and fr[2] == (not rcp), "the state must be a sane one (inside the fast WENO window)"
     r = refgpu.Ref3D(n)
     r.upload(state)
     m_ref = r.step(dt, gain)

@@ -50,6 +50,25 @@ def test_tau3d_host_ring_is_bit_identical(eng, tmp_path, shape, frames):
         assert got == want, f"world {world}: dump differs from the single-domain run"
 
 
+def test_tau3d_host_ring_at_the_benchmarked_plane_size(eng, tmp_path):
+    """512 x 512 planes, two ranks of 64 planes each — the slab one GPU of the 8-way 512^3 run owns, edges + interior + exchange as
+    there — against the 512 x 512 x 128 single domain: the whole dump (every plane of the six fields and the clock with its max
+    wavespeed) byte for byte.  (Round-3 review: the only 512^2-plane record, taken before the -ffp-contract=on fix, showed a 1-ulp
+    difference in maxs.)"""
+    grid = ["--nx", "512", "--ny", "512", "--nz", "128", "--frames", "3", "--start", "1"]
+    want, out1 = dump_of(tmp_path, "single.bin", *grid)
+    assert len(want) > 6 * 4 * 512 * 512 * 128
+    got, out = dump_of(tmp_path, "w2.bin", *grid, "--gpus", "2", "--transport", "host")
+    assert "ring: 2 ranks, host-staged transport" in out
+    assert got == want, "2 ranks x 64 planes of 512^2: dump differs from the single-domain run"
+    # the same through RCCL talking to itself (one rank owning all 128 planes: slab_begin / edges / interior / all-reduce)
+    got, out = dump_of(tmp_path, "ring1.bin", *grid, "--ring")
+    assert got == want
+    frames = lambda o: [l for l in o.splitlines() if l.startswith("frame ")]
+    assert frames(out) == frames(out1) and len(frames(out1)) >= 1, (frames(out1), frames(out))   # t, d_tau, dt, maxs to 9 digits
+    print("single:", frames(out1)[-1], "| ring:", frames(out)[-1])
+
+
 def test_tau3d_rccl_self_ring_is_bit_identical(eng, tmp_path):
     grid = ["--nx", "64", "--ny", "48", "--nz", "40", "--frames", "5", "--start", "1"]
     want, _ = dump_of(tmp_path, "single.bin", *grid)

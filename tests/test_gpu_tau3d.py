@@ -187,7 +187,7 @@ def test_full_size_slab_vs_oracle(eng, oracle_built, warm, zoff):
 
 # ---- WENO weight form: the step kernel takes the common-denominator weights when the state it reads
 # ---- is within 6e4 in magnitude, the reciprocal form otherwise — both against the same oracle
-def _explicit_vs_oracle(eng, oracle_built, shape, fields, dt, gain=1.0, **par):
+def _explicit_vs_oracle(eng, oracle_built, shape, fields, dt, gain=1.0, split=None, **par):
     import ctypes
     nx, ny, nz = shape
     P = eng.Tau3DParams()
@@ -198,6 +198,9 @@ def _explicit_vs_oracle(eng, oracle_built, shape, fields, dt, gain=1.0, **par):
         setattr(o.p, k, v)
     o = oracle_built.Oracle3D(nx, ny, nz, params=o.p)          # rebuilds the mask with the changed parameters
     e = eng.Tau3D(nx, ny, nz, params=P)
+    if split is not None:           # True: the kernel pair k_flux_xy + k_update_z (bench.py's step) whatever the plane size
+        e.set_split(split)
+        assert e.is_split() == split
     e.init(1)
     e.upload(fields)
     want, m_want = oracle_one_step(oracle_built, o, fields, dt, gain)
@@ -232,14 +235,19 @@ def _forced_reciprocal(fn):
 CONS = ("rho", "mx", "my", "mz", "E")
 
 
-def test_weight_form_follows_the_field_range(eng, oracle_built):
-    shape = (48, 40, 24)
-    st, dt, rng = _developed(eng, shape, 25)
+# split = True runs flux_xy_body<false> / update_z_body<false> — the reciprocal-weight bodies of the benchmarked kernel pair —
+# against the oracle (round-3 review: they had only met it through the fused k_step)
+@pytest.mark.parametrize("shape,split", [((48, 40, 24), None), ((48, 40, 24), True), ((160, 128, 24), True)])
+def test_weight_form_follows_the_field_range(eng, oracle_built, shape, split):
+    _explicit = _explicit_vs_oracle
+    def _explicit_vs_oracle_(*a, **k):
+        return _explicit(*a, split=split, **k)
+    st, dt, rng = _developed(eng, shape, 25 if shape[0] < 100 else 12)
     assert rng[2] and 99.9 <= rng[0] < 6e4 and 99.9 <= rng[1] < 6e4          # Mach-100 run: fast form, |u| = 100 seen
-    got, want, fluid, rng, m = _explicit_vs_oracle(eng, oracle_built, shape, st, dt)
+    got, want, fluid, rng, m = _explicit_vs_oracle_(eng, oracle_built, shape, st, dt)
     assert rng[2]
     assert_parity(got, want, mask=fluid, what="fast form")
-    got2, _, _, rng2, _ = _forced_reciprocal(lambda: _explicit_vs_oracle(eng, oracle_built, shape, st, dt))
+    got2, _, _, rng2, _ = _forced_reciprocal(lambda: _explicit_vs_oracle_(eng, oracle_built, shape, st, dt))
     assert not rng2[2]
     assert_parity(got2, want, mask=fluid, what="reciprocal form, forced")
     # same flow, pressure and vibrational energy lifted by 1e5 (no vibrational relaxation: exp(theta/T) - 1 at that
@@ -249,14 +257,15 @@ def test_weight_form_follows_the_field_range(eng, oracle_built):
     big = [a.copy() for a in st]
     big[4] += np.float32(np.log(1e5))
     big[5] += np.float32(np.log(1e5))
-    got, want, fluid, rng, m = _explicit_vs_oracle(eng, oracle_built, shape, big, dt * 1e-3, tau_vib=1e30)
+    got, want, fluid, rng, m = _explicit_vs_oracle_(eng, oracle_built, shape, big, dt * 1e-3, tau_vib=1e30)
     assert not rng[2] and rng[0] > 6e4
     rep = report(got, want, mask=fluid)
     assert all(rep[k] < 1e-5 for k in CONS) and rep["xi"] < 1e-5 and rep["lam"] < 1e-5, rep
     assert m[0] == pytest.approx(m[1], rel=1e-5)
 
 
-def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built):
+@pytest.mark.parametrize("split", [None, True])
+def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built, split):
     """cell-to-cell jumps of the largest admitted size in u, v, w, p and e_vib at once, in every direction: t^4 is at
     the top of fp32 — finite, within tolerance of the oracle, and next to the reciprocal form"""
     shape = (32, 24, 16)
@@ -269,7 +278,7 @@ def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built):
     u, v, w = (sgn() * mag(1.0) for _ in range(3))
     fields = [np.log(r), np.arcsinh(u / 10.0), np.arcsinh(v / 10.0), np.arcsinh(w / 10.0), np.log(p), np.log(ev)]
     fields = [a.astype(np.float32) for a in fields]
-    run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 1e-8, tau_vib=1e30)
+    run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 1e-8, split=split, tau_vib=1e30)
     got, want, fluid, fr, m = run()
     assert fr[2] and 5e4 < fr[0] <= 6e4, fr
     assert all(np.isfinite(g).all() for g in got) and all(np.isfinite(w_).all() for w_ in want)
@@ -285,7 +294,8 @@ def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built):
     assert worst < 3e-4 and worst < 5 * worst2, (rep, rep2)
 
 
-def test_fast_weights_keep_small_smooth_corrections(eng, oracle_built):
+@pytest.mark.parametrize("split", [None, True])
+def test_fast_weights_keep_small_smooth_corrections(eng, oracle_built, split):
     """the other end of the window: every stencil at the eps floor (t = 1e-6), slopes of 1e-7 — the products
     a_k q_k run through fp32 denormals and must still carry the high-order correction: the error against the oracle
     stays at the rounding level the reciprocal form has"""
@@ -298,7 +308,7 @@ def test_fast_weights_keep_small_smooth_corrections(eng, oracle_built):
     u = 100.0 * (1 + amp * np.roll(wave, 7, 0)); v = 1e-4 * wave; w = -1e-4 * np.roll(wave, 2, 2)
     fields = [np.log(r), np.arcsinh(u / 10.0), np.arcsinh(v / 10.0), np.arcsinh(w / 10.0), np.log(p), np.log(ev)]
     fields = [a.astype(np.float32) for a in fields]
-    run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 2e-6, sdf_r=0.0)
+    run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 2e-6, split=split, sdf_r=0.0)
     got, want, fluid, fr, m = run()
     assert fr[2]
     got2, _, _, fr2, _ = _forced_reciprocal(run)
