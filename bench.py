@@ -262,10 +262,14 @@ def main():
     ap.add_argument("--self-p2p", action="store_true",
                     help="with --force-slab on one GPU: exchange the halos with OURSELVES through RCCL send/recv and all-reduce the "
                          "max words (a communicator of one) instead of device copies")
-    ap.add_argument("--ring-transport", choices=("rccl", "host"), default="rccl",
-                    help="rccl: ncclSend / ncclRecv / ncclAllReduce, one device per rank (the measured configuration); host: halos staged "
-                         "through shared memory so that the ranks may SHARE a device — exercises this script's N > 1 path on a one-GPU box "
-                         "(process group over gloo); not a performance configuration")
+    ap.add_argument("--ring-transport", choices=("auto", "rccl", "ipc", "host", "ipc-host"), default="auto",
+                    help="how the halos travel at N > 1.  ipc: every rank writes its boundary planes straight into its neighbours' halo "
+                         "planes (hipIpc-mapped state, hipMemcpyAsync: SDMA over xGMI, no CU), RCCL only for the 8-byte all-reduce; "
+                         "rccl: ncclSend / ncclRecv of packed buffers + ncclAllReduce; auto (default): both are built and timed over a "
+                         "few untimed warm-up steps, the faster one runs the timed region (a transport that cannot be set up on every "
+                         "rank is skipped).  host / ipc-host: halos (resp. only the all-reduce) staged through shared memory so that "
+                         "the ranks may SHARE a device — this script's N > 1 path on a one-GPU box (process group over gloo); not a "
+                         "performance configuration")
     ap.add_argument("--ring-driver", choices=("c", "python"), default="c",
                     help="c: the library's ring (tau3d_ring_*, librccl called from C); python: fluid-sims_amd/slab.py over torch.distributed")
     args = ap.parse_args()
@@ -287,10 +291,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (libtaueng has no CPU path)")
     ndev = torch.cuda.device_count()
-    shared = args.ring_transport == "host"
+    shared = args.ring_transport in ("host", "ipc-host")
     if ndev < world and not shared:
-        raise SystemExit(f"bench.py --gpus {world}: rank {rank} sees {ndev} device(s); the Z-slab ring needs {world} devices, "
-                         f"one MI355X per rank")
+        if ndev == 1 and os.environ.get("TAU_BENCH_ONE_VISIBLE_DEVICE_PER_RANK"):
+            local = 0    # a launcher that shows every rank exactly its own device; the library compares device identities across ranks
+        else:
+            raise SystemExit(f"bench.py --gpus {world}: rank {rank} sees {ndev} device(s); the Z-slab ring needs {world} devices, "
+                             f"one MI355X per rank")
     if shared:
         local = local % ndev
     torch.cuda.set_device(local)
@@ -346,7 +353,11 @@ def main():
                 info["fallback_from_c_ring"] = why
             return (lambda k: ring.step(k)), ring.finish, be.h.clock, be.h, info, None
 
-        def c_ring():
+        TRANSPORT_NAMES = {f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies", f.RING_IPC: "ipc",
+                           f.RING_HOST: "host-staged (ranks share a device: not a performance configuration)",
+                           f.RING_IPC_HOSTMAX: "ipc-host (direct halos, host all-reduce; ranks share a device: not a performance configuration)"}
+
+        def c_ring(transport):
             # the library's ring: every rank passes the same rendezvous path and job key (agreed through torch.distributed)
             key = torch.randint(1, 2 ** 62, (1,), dtype=torch.int64, device="cpu" if shared else dev)
             if world > 1:
@@ -355,7 +366,6 @@ def main():
             eng = f.Tau3D(n, n, n, params=params, z0=z0, nzl=nzl, device=local)
             eng.init(1)
             eng.set_clock(0.02, 1e-4)
-            transport = f.RING_HOST if (shared and world > 1) else (f.RING_RCCL if (world > 1 or args.self_p2p) else f.RING_LOCAL)
             err = None
             ring = None
             try:
@@ -376,12 +386,49 @@ def main():
                     ring.close()
                 eng.close()
                 return None, err
-            info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)",
-                        transport={f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies",
-                                   f.RING_HOST: "host-staged (ranks share a device: not a performance configuration)"}[transport])
-            return ((lambda k: ring.step(k)), ring.finish, ring.clock, eng, info, ring.close), None
+            info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)", transport=TRANSPORT_NAMES[transport])
 
-        got, why = (None, None) if py_ring else c_ring()
+            def close_all():
+                ring.close()
+                eng.close()
+            return ((lambda k: ring.step(k)), ring.finish, ring.clock, eng, info, close_all), None
+
+        def probe(transport, steps=10):
+            """ms per step of one candidate over `steps` steps after the same warm-up, max over ranks (untimed region of the bench)"""
+            got, why = c_ring(transport)
+            if got is None:
+                return None, why
+            st, sy, _, _, _, cl = got
+            st(args.warmup)
+            sy()
+            barrier()
+            t0 = time.perf_counter()
+            st(steps)
+            sy()
+            barrier()
+            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device="cpu" if shared else dev)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            cl()
+            return float(t.item()), None
+
+        want = args.ring_transport
+        if world == 1:
+            cands = [f.RING_IPC if want == "ipc" else (f.RING_RCCL if args.self_p2p else f.RING_LOCAL)]
+        elif want == "auto":
+            cands = [f.RING_IPC, f.RING_RCCL]
+        else:
+            cands = [{"rccl": f.RING_RCCL, "ipc": f.RING_IPC, "host": f.RING_HOST, "ipc-host": f.RING_IPC_HOSTMAX}[want]]
+        probes = {}
+        if not py_ring and len(cands) > 1:
+            for tr in cands:
+                ms, why_not = probe(tr)
+                probes[TRANSPORT_NAMES[tr]] = round(ms, 4) if ms is not None else f"unavailable: {why_not}"
+            ok = [tr for tr in cands if isinstance(probes[TRANSPORT_NAMES[tr]], float)]
+            cands = [min(ok, key=lambda tr: probes[TRANSPORT_NAMES[tr]])] if ok else [f.RING_RCCL]
+        got, why = (None, None) if py_ring else c_ring(cands[0])
+        if got is not None and probes:
+            got[4]["auto_probe_ms_per_step"] = probes
         if got is None:
             if why and rank == 0:
                 print(f"bench.py: C ring unavailable ({why}); falling back to the torch.distributed ring", file=sys.stderr)

@@ -15,7 +15,10 @@
  *   --gpus N                 Z-slab ring over N GPUs of this node: the program forks one process per device, each
  *                            owns nz/N planes and a tau3d_ring (halo exchange + max all-reduce over RCCL / xGMI,
  *                            issued by the library: include/taueng.h).  The result is bit-identical to --gpus 1.
- *   --transport rccl|host    rccl (default) needs N devices; host stages the halos through shared memory, ranks may
+ *   --transport rccl|ipc|host|ipc-host
+ *                            ipc: neighbours' halo planes written directly (hipIpc-mapped, SDMA copies), RCCL for the 8-byte all-reduce;
+ *                            ipc-host: the same copies with a host all-reduce (ranks may share a device);
+ *                            rccl (default) needs N devices; host stages the halos through shared memory, ranks may
  *                            then share devices (rank r runs on device r mod the device count)
  *   --ring                   with --gpus 1: run the ring anyway (RCCL send / recv to itself)
  */
@@ -35,8 +38,9 @@ static int run_rank(const opts_t *o, int rank, const char *rv, uint64_t key) {
   cli_need_gpu();
   int ndev = 1;
   if (tau_device_count(&ndev) || ndev < 1) { fprintf(stderr, "taueng error: %s\n", tau_last_error()); return 1; }
-  if (world > 1 && o->transport == TAU3D_RING_RCCL && ndev < world) {
-    fprintf(stderr, "tau3d --gpus %d needs %d devices (one per rank over RCCL), this node shows %d; --transport host lets ranks share a device\n",
+  if (world > 1 && (o->transport == TAU3D_RING_RCCL || o->transport == TAU3D_RING_IPC) && ndev < world) {
+    /* this launcher places rank r on device r % ndev itself; the library checks device IDENTITIES across ranks for any other launch */
+    fprintf(stderr, "tau3d --gpus %d needs %d devices (one per rank over RCCL), this node shows %d; --transport host / ipc-host lets ranks share a device\n",
             world, world, ndev);
     return 1;
   }
@@ -57,6 +61,8 @@ static int run_rank(const opts_t *o, int rank, const char *rv, uint64_t key) {
       char lib[256];
       TAU_CK(tau3d_ring_info(r, &ver, &ranks, &edge, lib, sizeof lib));
       if (o->transport == TAU3D_RING_RCCL) printf("ring: %d ranks, RCCL %d (%s), communicator of %d, %d-plane edges\n", world, ver, lib, ranks, edge);
+      else if (o->transport == TAU3D_RING_IPC) printf("ring: %d ranks, direct halos (IPC-mapped neighbours, SDMA copies) + RCCL %d all-reduce, %d-plane edges\n", world, ver, edge);
+      else if (o->transport == TAU3D_RING_IPC_HOSTMAX) printf("ring: %d ranks, direct halos (IPC-mapped neighbours), host all-reduce, %d-plane edges\n", world, edge);
       else printf("ring: %d ranks, host-staged transport, %d-plane edges\n", world, edge);
     }
     TAU_CK(tau3d_ring_finish(r));
@@ -155,7 +161,9 @@ int main(int argc, char **argv) {
       const char *t = argv[++i];
       if (!strcmp(t, "rccl")) o.transport = TAU3D_RING_RCCL;
       else if (!strcmp(t, "host")) o.transport = TAU3D_RING_HOST;
-      else { fprintf(stderr, "Invalid value for --transport: %s (rccl | host)\n", t); return 1; }
+      else if (!strcmp(t, "ipc")) o.transport = TAU3D_RING_IPC;
+      else if (!strcmp(t, "ipc-host")) o.transport = TAU3D_RING_IPC_HOSTMAX;
+      else { fprintf(stderr, "Invalid value for --transport: %s (rccl | ipc | host | ipc-host)\n", t); return 1; }
     }
     else { fprintf(stderr, "Unknown or incomplete argument: %s\n", a); return 1; }
   }

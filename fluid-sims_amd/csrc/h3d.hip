@@ -1667,6 +1667,7 @@ __global__ void k_halo_pack(PackArgs P, int dir) {
 }
 
 __global__ void k_clock_begin(DevClock *c) { clock_begin(c); }
+__global__ void k_clock_turn(DevClock *c, int do_end) { if (do_end) clock_end(c); clock_begin(c); }   // what k_halo_pack's first thread does, alone
 __global__ void k_clock_end(DevClock *c) { clock_end(c); }
 __global__ void k_clock_set_explicit(DevClock *c, float dt, float gain) {
   c->dt = dt; c->gain = gain; c->maxs_bits = 0u;
@@ -1872,6 +1873,7 @@ struct tau3d {
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
   float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
+  bool direct = false;      // Z-slab ring with direct halos (tau3d_set_halo_direct): neighbours write this slab's halo planes themselves
   uint8_t *pidx = nullptr;   // palette indices of the last tau3d_palette_indices
   float *vis;               // nx*ny*nzl scalar field of the last tau3d_vis (lazy)
   uint32_t *rgba;           // one slice of pixels (lazy)
@@ -2272,7 +2274,26 @@ extern "C" int tau3d_step_edges_async(tau3d_t *h, int depth, void *stream) {
 static int halo_pack(tau3d_t *h, int which, int dir, bool with_clock);
 extern "C" int tau3d_slab_begin_async(tau3d_t *h) {
   TAU_HIP(hipSetDevice(h->device));
+  if (h->direct) {   // the halo planes were written in place by the neighbours: only the controller / clock part is left
+    hipLaunchKernelGGL(h3d::k_clock_turn, dim3(1), dim3(1), 0, h->stream, h->clk, h->end_pending ? 1 : 0);
+    TAU_LAUNCH_CHECK("k_clock_turn");
+    h->end_pending = false;
+    return 0;
+  }
   return halo_pack(h, 0, 1, true);   // controller of the step before (if pending) + clock of this one + received halos
+}
+extern "C" int tau3d_set_halo_direct(tau3d_t *h, int on) {
+  if (!h) return tau::fail("tau3d_set_halo_direct: null handle");
+  h->direct = on != 0;
+  return 0;
+}
+extern "C" int tau3d_state_group(tau3d_t *h, int which, void **base, size_t *bytes, size_t *field_stride, int *index) {
+  if (!h || (which | 1) != 1) return tau::fail("tau3d_state_group: bad argument");
+  if (base) *base = h->buf[h->cur ^ which][0];
+  if (bytes) *bytes = 6 * h->field_stride * sizeof(float);
+  if (field_stride) *field_stride = h->field_stride;
+  if (index) *index = h->cur ^ which;
+  return 0;
 }
 // event timing of a slab piece (tau3d_timing_*): the interval covers every launch of the piece
 static int slab_timed(tau3d_t *h, int planes, int (*body)(tau3d_t *, int), int depth) {
@@ -2301,14 +2322,15 @@ static int slab_edges_body(tau3d_t *h, int depth) {
   if (h->split) {
     if (whole || slab_xy_first()) { if (split_xy(h, 0, nzl, 0, 0, h->stream)) return 1; }   // k_flux_xy needs no halo
     else if (split_xy(h, 0, depth, nzl - depth, nzl, h->stream)) return 1;
-    return whole ? split_z(h, 0, nzl, 0, 0, true, h->stream) : split_z(h, 0, depth, nzl - depth, nzl, true, h->stream);
+    const bool pack = !h->direct;   // direct halos: the ring copies the new boundary planes out of the state itself
+    return whole ? split_z(h, 0, nzl, 0, 0, pack, h->stream) : split_z(h, 0, depth, nzl - depth, nzl, pack, h->stream);
   }
   const bool t = h->timing;
   h->timing = false;                                               // (step_ranges would open an interval of its own)
   const int rc = whole ? step_ranges(h, 0, nzl, 0, 0, nullptr) : step_ranges(h, 0, depth, nzl - depth, nzl, nullptr);
   h->timing = t;
   if (rc) return 1;
-  return halo_pack(h, 1, 0, false);
+  return h->direct ? 0 : halo_pack(h, 1, 0, false);
 }
 static int slab_interior_body(tau3d_t *h, int depth) {
   const int nzl = h->nzl;
@@ -2427,6 +2449,11 @@ extern "C" int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, siz
 extern "C" int tau3d_state_written(tau3d_t *h) {
   h->halo_fresh = false;
   TAU_HIP(hipSetDevice(h->device));
+  if (h->xyflag) {   // tau3d_state_ptrs also hands out the solid mask: k_flux_xy's static tile flags are derived from it
+    const int ntx = (h->p.nx + h3d::XT - 1) / h3d::XT, nty = (h->p.ny + h3d::YT - 1) / h3d::YT;
+    hipLaunchKernelGGL(h3d::k_xy_flags, dim3((unsigned)(ntx * nty * h->nzl)), dim3(256), 0, h->stream, h->base, (const uint8_t *)h->solid, h->xyflag);
+    TAU_LAUNCH_CHECK("k_xy_flags");
+  }
   return measure_field(h, -h3d::HALO, h->nzl + h3d::HALO, false);
 }
 extern "C" int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast_form) {

@@ -26,6 +26,18 @@
 //                     exists so that N ranks SHARING one device (RCCL refuses duplicate GPUs) can run the ring's ordering
 //                     — the multi-process tests on a one-GPU box — and as a fallback where RCCL is absent.
 //   TAU3D_RING_LOCAL  world == 1 only: two device copies (periodic self-neighbour), no collective.
+//   TAU3D_RING_IPC    direct halos, no compute unit involved: every rank maps its two neighbours' state allocations
+//                     (hipIpcGetMemHandle / hipIpcOpenMemHandle, handles passed through the rendezvous file) and, once its
+//                     edge planes are done, copies its new boundary planes STRAIGHT INTO THE NEIGHBOURS' HALO PLANES with
+//                     hipMemcpyAsync on X (12 copies of 3 planes: the SDMA engines over xGMI) — no packed buffers, no pack in
+//                     the edge launch, no unpack kernel (slab_begin shrinks to the one-thread clock kernel), and no RCCL
+//                     send/recv kernel taking CUs from the VALU-bound interior launch that runs beside the exchange.  RCCL is
+//                     kept for the 8-byte all-reduce only, and that all-reduce is also what orders the copies: a rank leaves
+//                     all-reduce(n) only after every rank has entered it, i.e. after every neighbour's copies of step n
+//                     (earlier on its X) have landed and every neighbour has finished reading the halo planes step n+1's
+//                     copies will overwrite (its interior launch precedes its all-reduce).
+//   TAU3D_RING_IPC_HOSTMAX  the same copies, all-reduce through the rendezvous file by the host: ranks may share a device
+//                     (RCCL refuses that) — how the direct transport runs with 2-8 processes on a one-GPU test box.
 //
 // Rendezvous: a small file in /dev/shm (or anywhere mmap-able) that rank 0 creates and the others map.  It carries the
 // ncclUniqueId, a barrier with a timeout, one status word per rank (a rank that cannot proceed says so instead of leaving
@@ -134,6 +146,13 @@ struct Shared {
   std::atomic<int32_t> status[MAX_WORLD];   // 0 unknown, 1 ready, 2 failed
   float maxw[MAX_WORLD][2];
   ncclUniqueId id;
+  // per rank: device identity (one device per rank is checked by IDENTITY, not by counting visible devices: the usual
+  // launch shows each rank exactly one device through HIP_VISIBLE_DEVICES) and what the IPC transport maps
+  char busid[MAX_WORLD][32];
+  hipIpcMemHandle_t grp[MAX_WORLD][2];   // the two ping-pong state allocations, by allocation index
+  uint64_t field_stride[MAX_WORLD];      // floats between the six fields of an allocation
+  int32_t nzl[MAX_WORLD];
+  std::atomic<int32_t> cur[MAX_WORLD];   // allocation index of the rank's CURRENT state (published by tau3d_ring_prime)
   // then: world x 2 x slot_bytes of staging (host transport)
 };
 static size_t shared_bytes(int world, size_t slot) { return ((sizeof(Shared) + 4095) & ~(size_t)4095) + (size_t)world * 2 * slot; }
@@ -191,7 +210,35 @@ struct tau3d_ring {
   float *maxw = nullptr;
   bool primed = false;
   long steps = 0;
+  // IPC transport: the neighbours' state allocations in this process's address space, [side 0 lo / 1 hi][allocation index]
+  float *peer_base[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  void *opened[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // what hipIpcCloseMemHandle gets back
+  size_t peer_stride[2] = {0, 0};
+  int peer_nzl[2] = {0, 0}, peer_cur[2] = {0, 0};
+  uint64_t ino = 0, dev = 0;   // identity of the mapped rendezvous file (ranks != 0)
+  uint64_t key = 0;
+  bool published = false, failed = false;
+  bool uses_rccl() const { return transport == TAU3D_RING_RCCL || transport == TAU3D_RING_IPC; }
+  bool direct() const { return transport == TAU3D_RING_IPC || transport == TAU3D_RING_IPC_HOSTMAX; }
 };
+
+// a rank that cannot go on says so in the rendezvous file: its peers leave their barriers with an error instead of waiting
+// out the timeout (or sitting inside a collective for ever)
+static int ring_publish(tau3d_ring *r);
+static void mark_failed(tau3d_ring *r) {
+  if (!r || !r->sh || r->rank < 0 || r->rank >= ring::MAX_WORLD) return;
+  r->failed = true;
+  r->sh->status[r->rank].store(2, std::memory_order_release);
+  // rank 0 failing before its file is public: make it public all the same (saving the message ring_publish might overwrite),
+  // so that the waiting peers find the status word instead of sitting out the timeout; tau3d_ring_destroy then leaves the
+  // file for them (a few KB in /dev/shm under a per-job name; the launcher removes it)
+  if (r->rank == 0 && !r->published) {
+    char keep[512];
+    snprintf(keep, sizeof keep, "%s", tau_last_error());
+    ring_publish(r);
+    tau::fail("%s", keep);
+  }
+}
 
 static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) {
   using namespace ring;
@@ -199,17 +246,21 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
   snprintf(r->path, sizeof r->path, "%s", path);
   int fd = -1;
   if (r->rank == 0) {
-    unlink(path);   // a stale file of an earlier job: rank 0 always starts fresh
-    fd = open(path, O_RDWR | O_CREAT | O_EXCL, 0600);
-    if (fd < 0) return tau::fail("tau3d_ring: cannot create %s: %s", path, strerror(errno));
-    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); return tau::fail("tau3d_ring: ftruncate(%s, %zu): %s", path, bytes, strerror(errno)); }
+    // Rank 0 builds the file under a private name and rename()s it into place once the header is complete: whoever opens
+    // `path` sees either nothing, a file of an EARLIER job (another key: ignored below), or this job's finished header.
+    char tmp[300];
+    snprintf(tmp, sizeof tmp, "%s.%ld.tmp", path, (long)getpid());
+    unlink(tmp);
+    fd = open(tmp, O_RDWR | O_CREAT | O_EXCL, 0600);
+    if (fd < 0) return tau::fail("tau3d_ring: cannot create %s: %s", tmp, strerror(errno));
+    if (ftruncate(fd, (off_t)bytes) != 0) { close(fd); unlink(tmp); return tau::fail("tau3d_ring: ftruncate(%s, %zu): %s", tmp, bytes, strerror(errno)); }
     void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
     close(fd);
-    if (m == MAP_FAILED) return tau::fail("tau3d_ring: mmap(%s): %s", path, strerror(errno));
+    if (m == MAP_FAILED) { unlink(tmp); return tau::fail("tau3d_ring: mmap(%s): %s", tmp, strerror(errno)); }
     Shared *sh = new (m) Shared();   // ftruncate zero-filled it; the atomics start at 0
     sh->world = r->world; sh->transport = r->transport; sh->slot_bytes = slot;
     r->sh = sh; r->sh_bytes = bytes;
-    return 0;   // `ready` is published by the caller once the id is in
+    return 0;   // the caller puts the id in, publishes `ready` and calls ring_publish
   }
   const double t0 = now_s();
   int spins = 0;
@@ -221,17 +272,17 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
         void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (m != MAP_FAILED) {
           Shared *sh = (Shared *)m;
-          const double t1 = now_s();
-          int sp2 = 0;
-          while (sh->ready.load(std::memory_order_acquire) == 0 && now_s() - t1 < 1.0) nap(sp2);   // rank 0 may still be filling it
           if (sh->ready.load(std::memory_order_acquire) == (MAGIC ^ key)) {
             close(fd);
             if (sh->world != r->world || sh->transport != r->transport || sh->slot_bytes != slot) {
+              const int w = sh->world, t = sh->transport;
+              const unsigned long long sb = sh->slot_bytes;
               munmap(m, bytes);
               return tau::fail("tau3d_ring: %s was made for world %d / transport %d / %llu-byte slots, this rank wants %d / %d / %zu",
-                               path, sh->world, sh->transport, (unsigned long long)sh->slot_bytes, r->world, r->transport, slot);
+                               path, w, t, sb, r->world, r->transport, slot);
             }
             r->sh = sh; r->sh_bytes = bytes;
+            r->ino = (uint64_t)st.st_ino; r->dev = (uint64_t)st.st_dev;
             return 0;
           }
           munmap(m, bytes);
@@ -242,6 +293,25 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
     if (now_s() - t0 > timeout_s()) return tau::fail("tau3d_ring: rank %d waited %.0f s for rank 0's rendezvous file %s", r->rank, timeout_s(), path);
     nap(spins);
   }
+}
+// rank 0: the header is complete -> the file appears under its public name
+static int ring_publish(tau3d_ring *r) {
+  char tmp[300];
+  snprintf(tmp, sizeof tmp, "%s.%ld.tmp", r->path, (long)getpid());
+  r->sh->ready.store(ring::MAGIC ^ r->key, std::memory_order_release);
+  if (rename(tmp, r->path) != 0) return tau::fail("tau3d_ring: rename(%s, %s): %s", tmp, r->path, strerror(errno));
+  r->published = true;
+  return 0;
+}
+// after the create barrier: the file this rank mapped must still be the one under `path` (a file left behind by a crashed job
+// with the same path AND key could have been picked up before rank 0 replaced it — then the barrier was someone else's)
+static int ring_check_same_file(tau3d_ring *r) {
+  if (r->rank == 0) return 0;
+  struct stat st;
+  if (stat(r->path, &st) != 0 || (uint64_t)st.st_ino != r->ino || (uint64_t)st.st_dev != r->dev)
+    return tau::fail("tau3d_ring: rank %d mapped a stale rendezvous file at %s (left by an earlier job with the same job key); "
+                     "use a job key that is unique per launch", r->rank, r->path);
+  return 0;
 }
 
 extern "C" int tau3d_slab_bounds(int nz, int world, int rank, int *z0, int *nzl) {
@@ -258,6 +328,10 @@ extern "C" void tau3d_ring_destroy(tau3d_ring_t *r) {
   hipSetDevice(r->device);
   if (r->X) hipStreamSynchronize(r->X);
   if (r->S) hipStreamSynchronize(r->S);
+  if (r->direct() && r->h) tau3d_set_halo_direct(r->h, 0);
+  for (int s = 0; s < 2; s++)
+    for (int g = 0; g < 2; g++)
+      if (r->opened[s][g]) hipIpcCloseMemHandle(r->opened[s][g]);
   if (r->comm) ring::g_rccl.CommDestroy(r->comm);
   if (r->evE) hipEventDestroy(r->evE);
   if (r->evI) hipEventDestroy(r->evI);
@@ -265,22 +339,34 @@ extern "C" void tau3d_ring_destroy(tau3d_ring_t *r) {
   if (r->X) hipStreamDestroy(r->X);
   if (r->sh) {
     munmap(r->sh, r->sh_bytes);
-    if (r->rank == 0 && r->path[0]) unlink(r->path);   // the mappings of the other ranks keep the pages alive
+    if (r->rank == 0 && r->path[0] && !(r->failed && r->world > 1)) {   // the mappings of the other ranks keep the pages alive
+      unlink(r->path);
+      char tmp[300];
+      snprintf(tmp, sizeof tmp, "%s.%ld.tmp", r->path, (long)getpid());
+      unlink(tmp);
+    }
   }
   delete r;
 }
 
-extern "C" int tau3d_ring_create(tau3d_ring_t **out, tau3d_t *h, int rank, int world, int transport, const char *rendezvous,
-                                 uint64_t job_key) {
+static int ring_create_impl(tau3d_ring *r, tau3d_t *h, int rank, int world, int transport, const char *rendezvous, uint64_t job_key) {
   using namespace ring;
-  if (!out || !h) return tau::fail("tau3d_ring_create: null argument");
-  if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world) return tau::fail("tau3d_ring_create: rank %d of %d", rank, world);
-  if (transport < TAU3D_RING_RCCL || transport > TAU3D_RING_LOCAL) return tau::fail("tau3d_ring_create: unknown transport %d", transport);
-  if (transport == TAU3D_RING_LOCAL && world != 1) return tau::fail("tau3d_ring_create: the local transport is for world 1");
-  if (world > 1 && (!rendezvous || !rendezvous[0])) return tau::fail("tau3d_ring_create: world %d needs a rendezvous path", world);
   int z0 = 0, nzl = 0, nz = 0, device = 0;
   void *stream = nullptr;
   if (tau3d_slab_info(h, &z0, &nzl, &nz, &device, &stream)) return 1;
+  r->h = h; r->rank = rank; r->world = world; r->transport = transport; r->nzl = nzl; r->device = device; r->key = job_key;
+  r->lo = (rank + world - 1) % world; r->hi = (rank + 1) % world;
+  r->S = (hipStream_t)stream;
+  for (int k = 0; k < 2; k++)
+    for (int s = 0; s < 2; s++)
+      if (tau3d_halo_buf_ptr(h, k, s, &r->buf[k][s], &r->nfloats)) return 1;
+
+  // the rendezvous file comes FIRST: whatever fails from here on is reported to the peers through it
+  const bool need_file = world > 1 || (transport == TAU3D_RING_HOST && rendezvous && rendezvous[0]);
+  if (need_file) {
+    const size_t slot = transport == TAU3D_RING_HOST ? r->nfloats * sizeof(float) : 0;
+    if (ring_map(r, rendezvous, job_key, slot)) return 1;
+  }
   {
     int ez0, enzl;
     if (tau3d_slab_bounds(nz, world, rank, &ez0, &enzl)) return 1;
@@ -288,67 +374,116 @@ extern "C" int tau3d_ring_create(tau3d_ring_t **out, tau3d_t *h, int rank, int w
       return tau::fail("tau3d_ring_create: rank %d of %d owns planes [%d,%d) of nz=%d, the handle was created for [%d,%d)", rank, world,
                        ez0, ez0 + enzl, nz, z0, z0 + nzl);
   }
-  tau3d_ring *r = new (std::nothrow) tau3d_ring();
-  if (!r) return tau::fail("tau3d_ring_create: out of host memory");
-  tau::HandleGuard<tau3d_ring> guard{r, tau3d_ring_destroy};
-  r->h = h; r->rank = rank; r->world = world; r->transport = transport; r->nzl = nzl; r->device = device;
-  r->lo = (rank + world - 1) % world; r->hi = (rank + 1) % world;
   r->edge = nzl / 2 < 8 ? (nzl / 2 < 3 ? 3 : nzl / 2) : 8;   // planes per edge launch: >= the 3 halo planes, <= half a slab, 8 where they fit
   if (const char *e = getenv("TAU3D_RING_EDGE")) { const int v = atoi(e); if (v >= 3) r->edge = v; }
-  r->S = (hipStream_t)stream;
   TAU_HIP(hipSetDevice(device));
   TAU_HIP(hipStreamCreateWithFlags(&r->X, hipStreamNonBlocking));
   TAU_HIP(hipEventCreateWithFlags(&r->evE, hipEventDisableTiming));
   TAU_HIP(hipEventCreateWithFlags(&r->evI, hipEventDisableTiming));
   TAU_HIP(hipEventCreateWithFlags(&r->evX, hipEventDisableTiming));
-  for (int k = 0; k < 2; k++)
-    for (int s = 0; s < 2; s++)
-      if (tau3d_halo_buf_ptr(h, k, s, &r->buf[k][s], &r->nfloats)) return 1;
   if (tau3d_max_ptr(h, &r->maxw)) return 1;
 
-  const bool need_file = world > 1 || (transport == TAU3D_RING_HOST && rendezvous && rendezvous[0]);
   ncclUniqueId id;
   memset(&id, 0, sizeof id);
-  int my_status = 1;
-  if (transport == TAU3D_RING_RCCL) {
-    if (rccl_load()) my_status = 2;
-    else if (rank == 0 && g_rccl.GetUniqueId(&id) != ncclSuccess) { tau::fail("tau3d_ring_create: ncclGetUniqueId failed"); my_status = 2; }
+  if (r->uses_rccl()) {
+    if (rccl_load()) return 1;
+    if (rank == 0 && g_rccl.GetUniqueId(&id) != ncclSuccess) return tau::fail("tau3d_ring_create: ncclGetUniqueId failed");
   }
-  if (need_file) {
-    const size_t slot = transport == TAU3D_RING_HOST ? r->nfloats * sizeof(float) : 0;
-    if (ring_map(r, rendezvous, job_key, slot)) return 1;
+  // the two state allocations of this slab (by allocation index) for the IPC transport
+  void *my_base[2] = {nullptr, nullptr};
+  size_t my_stride = 0;
+  if (r->direct()) {
+    for (int w = 0; w < 2; w++) {
+      void *b = nullptr;
+      int idx = 0;
+      if (tau3d_state_group(h, w, &b, nullptr, &my_stride, &idx)) return 1;
+      my_base[idx] = b;
+    }
+  }
+  if (r->sh) {
+    Shared *sh = r->sh;
+    char bus[32] = "";
+    TAU_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof bus, device));
+    snprintf(sh->busid[rank], sizeof sh->busid[rank], "%s", bus);
+    sh->nzl[rank] = nzl;
+    sh->field_stride[rank] = my_stride;
+    if (r->direct() && world > 1)
+      for (int g = 0; g < 2; g++) TAU_HIP(hipIpcGetMemHandle(&sh->grp[rank][g], my_base[g]));
     if (rank == 0) {
-      r->sh->id = id;
-      r->sh->ready.store(MAGIC ^ job_key, std::memory_order_release);
+      sh->id = id;
+      if (ring_publish(r)) return 1;
     }
     // every rank says whether it can go on BEFORE anyone enters ncclCommInitRank (which waits for all ranks for ever)
-    r->sh->status[rank].store(my_status, std::memory_order_release);
-    if (my_status == 2) return 1;
-    if (barrier(r->sh, "create")) return 1;
+    sh->status[rank].store(1, std::memory_order_release);
+    if (barrier(sh, "create")) return 1;
+    if (ring_check_same_file(r)) return 1;
     for (int k = 0; k < world; k++)
-      if (r->sh->status[k].load(std::memory_order_acquire) != 1) return tau::fail("tau3d_ring_create: rank %d could not start", k);
-    id = r->sh->id;
-  } else if (my_status == 2) return 1;
-
-  if (transport == TAU3D_RING_RCCL) {
-    // RCCL refuses two ranks on one device with an error deep inside the init; say it here, in the caller's terms
-    int ndev = 0;
-    TAU_HIP(hipGetDeviceCount(&ndev));
-    if (world > ndev && !getenv("TAU3D_RING_NO_DEVICE_CHECK"))
-      return tau::fail("tau3d_ring_create: the RCCL transport needs %d devices (one per rank), this node shows %d", world, ndev);
-    TAU_NCCL(g_rccl.CommInitRank(&r->comm, world, id, rank));
+      if (sh->status[k].load(std::memory_order_acquire) != 1) return tau::fail("tau3d_ring_create: rank %d could not start", k);
+    id = sh->id;
+    if (r->uses_rccl() && !getenv("TAU3D_RING_NO_DEVICE_CHECK"))   // RCCL refuses two ranks on one device deep inside its init: say it here
+      for (int a = 0; a < world; a++)
+        for (int b = a + 1; b < world; b++)
+          if (strncmp(sh->busid[a], sh->busid[b], sizeof sh->busid[a]) == 0)
+            return tau::fail("tau3d_ring_create: this transport needs one device per rank over RCCL, ranks %d and %d both run on %s "
+                             "(the host / ipc-host transports let ranks share a device)", a, b, sh->busid[a]);
   }
-  *out = guard.release();
+  if (r->direct()) {
+    for (int s = 0; s < 2; s++) {
+      const int peer = s == 0 ? r->lo : r->hi;
+      if (peer == rank) {                          // world 1: my own planes are my neighbour's
+        for (int g = 0; g < 2; g++) r->peer_base[s][g] = (float *)my_base[g];
+        r->peer_stride[s] = my_stride; r->peer_nzl[s] = nzl;
+      } else if (s == 1 && r->hi == r->lo) {       // world 2: both neighbours are the same peer, mapped once
+        for (int g = 0; g < 2; g++) r->peer_base[1][g] = r->peer_base[0][g];
+        r->peer_stride[1] = r->peer_stride[0]; r->peer_nzl[1] = r->peer_nzl[0];
+      } else {
+        for (int g = 0; g < 2; g++) {
+          void *p = nullptr;
+          hipError_t e = hipIpcOpenMemHandle(&p, r->sh->grp[peer][g], hipIpcMemLazyEnablePeerAccess);
+          if (e != hipSuccess)
+            return tau::fail("tau3d_ring_create: hipIpcOpenMemHandle of rank %d's state (allocation %d): %s", peer, g, hipGetErrorString(e));
+          r->opened[s][g] = p;
+          r->peer_base[s][g] = (float *)p;
+        }
+        r->peer_stride[s] = (size_t)r->sh->field_stride[peer]; r->peer_nzl[s] = r->sh->nzl[peer];
+      }
+    }
+    if (tau3d_set_halo_direct(h, 1)) return 1;
+    if (r->sh && barrier(r->sh, "peer state mapped")) return 1;
+  }
+  if (r->uses_rccl()) TAU_NCCL(g_rccl.CommInitRank(&r->comm, world, id, rank));
+  return 0;
+}
+
+extern "C" int tau3d_ring_create(tau3d_ring_t **out, tau3d_t *h, int rank, int world, int transport, const char *rendezvous,
+                                 uint64_t job_key) {
+  using namespace ring;
+  if (!out || !h) return tau::fail("tau3d_ring_create: null argument");
+  if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world) return tau::fail("tau3d_ring_create: rank %d of %d", rank, world);
+  if (transport < TAU3D_RING_RCCL || transport > TAU3D_RING_IPC_HOSTMAX) return tau::fail("tau3d_ring_create: unknown transport %d", transport);
+  if (transport == TAU3D_RING_LOCAL && world != 1) return tau::fail("tau3d_ring_create: the local transport is for world 1");
+  if (world > 1 && (!rendezvous || !rendezvous[0])) return tau::fail("tau3d_ring_create: world %d needs a rendezvous path", world);
+  if (world > 1 && job_key == 0)
+    return tau::fail("tau3d_ring_create: world %d needs a non-zero job key, unique per launch (it tells this job's rendezvous file "
+                     "from one an earlier job left under the same path)", world);
+  tau3d_ring *r = new (std::nothrow) tau3d_ring();
+  if (!r) return tau::fail("tau3d_ring_create: out of host memory");
+  if (ring_create_impl(r, h, rank, world, transport, rendezvous, job_key)) {
+    mark_failed(r);
+    tau3d_ring_destroy(r);   // (tau::fail's message survives: destroy reports nothing)
+    return 1;
+  }
+  *out = r;
   return 0;
 }
 
 extern "C" int tau3d_ring_info(tau3d_ring_t *r, int *rccl_version, int *comm_ranks, int *edge_planes, char *lib_path, size_t lib_path_len) {
   if (!r) return tau::fail("tau3d_ring_info: null ring");
   if (rccl_version) *rccl_version = 0;
-  if (comm_ranks) *comm_ranks = r->transport == TAU3D_RING_RCCL ? 0 : r->world;
+  if (comm_ranks) *comm_ranks = r->uses_rccl() ? 0 : r->world;
   if (edge_planes) *edge_planes = r->edge;
   if (lib_path && lib_path_len) lib_path[0] = 0;
-  if (r->transport == TAU3D_RING_RCCL) {
+  if (r->uses_rccl()) {
     if (rccl_version) TAU_NCCL(ring::g_rccl.GetVersion(rccl_version));
     if (comm_ranks) TAU_NCCL(ring::g_rccl.CommCount(r->comm, comm_ranks));
     if (lib_path && lib_path_len) snprintf(lib_path, lib_path_len, "%s", ring::g_rccl.path);
@@ -400,27 +535,48 @@ static int allreduce_host(tau3d_ring *r) {
   if (barrier(r->sh, "max words written")) return 1;
   for (int k = 0; k < r->world; k++) {
     const float a = r->sh->maxw[k][0], c = r->sh->maxw[k][1];
-    if (a > w[0]) w[0] = a;
-    if (c > w[1]) w[1] = c;
+    if (a > w[0] || a != a) w[0] = a;   // NaN propagates, as ncclMax does (a blown-up field must not look bounded)
+    if (c > w[1] || c != c) w[1] = c;
   }
   TAU_HIP(hipMemcpyAsync(r->maxw, w, sizeof w, hipMemcpyHostToDevice, r->X));
   TAU_HIP(hipStreamSynchronize(r->X));
   return barrier(r->sh, "max words read");
 }
 
-// the communication of one step (or of the priming exchange): X waits for `after_send` (send buffers written), exchanges,
-// waits for `after_max` (all launches that raise the max words), reduces them, and records evX
-static int communicate(tau3d_ring *r, bool with_max) {
+// direct halos: my first / last three interior planes of the state `which` (0 current, 1 next) go straight into the
+// neighbours' halo planes of THEIR state `which` — the low neighbour's high halo, the high neighbour's low halo — field by
+// field (a field's three planes are contiguous on both sides): 12 copies of 3 planes, nothing packed, nothing unpacked.
+// peer_cur[] is the allocation index of each neighbour's current state (tau3d_ring_prime publishes it, every step flips it).
+static int exchange_ipc(tau3d_ring *r, int which) {
+  const size_t plane_n = r->nfloats / (6 * 3);
+  const size_t bytes = 3 * plane_n * sizeof(float);
+  void *base = nullptr;
+  size_t stride = 0;
+  if (tau3d_state_group(r->h, which, &base, nullptr, &stride, nullptr)) return 1;
+  const float *me = (const float *)base;
+  float *lo = r->peer_base[0][r->peer_cur[0] ^ which], *hi = r->peer_base[1][r->peer_cur[1] ^ which];
+  for (int f = 0; f < 6; f++) {
+    TAU_HIP(hipMemcpyAsync(lo + f * r->peer_stride[0] + (size_t)(r->peer_nzl[0] + 3) * plane_n, me + f * stride + 3 * plane_n, bytes,
+                           hipMemcpyDeviceToDevice, r->X));
+    TAU_HIP(hipMemcpyAsync(hi + f * r->peer_stride[1], me + f * stride + (size_t)r->nzl * plane_n, bytes, hipMemcpyDeviceToDevice, r->X));
+  }
+  return 0;
+}
+
+// the communication of one step (or of the priming exchange, which = 0): X waits for evE (boundary planes / send buffers
+// written), exchanges, waits for evI (all launches that raise the max words), reduces them, and records evX
+static int communicate(tau3d_ring *r, bool with_max, int which = 1) {
   using namespace ring;
   TAU_HIP(hipStreamWaitEvent(r->X, r->evE, 0));
   switch (r->transport) {
     case TAU3D_RING_RCCL: if (exchange_rccl(r)) return 1; break;
     case TAU3D_RING_HOST: if (exchange_host(r)) return 1; break;
+    case TAU3D_RING_IPC: case TAU3D_RING_IPC_HOSTMAX: if (exchange_ipc(r, which)) return 1; break;
     default: if (exchange_local(r)) return 1; break;
   }
   if (with_max && r->transport != TAU3D_RING_LOCAL) {
     TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
-    if (r->transport == TAU3D_RING_RCCL) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
+    if (r->uses_rccl()) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
     else if (allreduce_host(r)) return 1;
   }
   TAU_HIP(hipEventRecord(r->evX, r->X));
@@ -429,9 +585,30 @@ static int communicate(tau3d_ring *r, bool with_max) {
 
 /* exchange the halos of the CURRENT state and agree on its field range (after init / upload): without it the first step
  * would read undefined halo planes and every slab could pick its own WENO weight form */
-extern "C" int tau3d_ring_prime(tau3d_ring_t *r) {
-  if (!r) return tau::fail("tau3d_ring_prime: null ring");
+static int ring_prime_impl(tau3d_ring *r) {
   TAU_HIP(hipSetDevice(r->device));
+  if (r->direct()) {
+    // Host-synchronous (it runs once after create / init / upload): every rank's state is final and nobody reads halo planes
+    // any more -> tell the neighbours which allocation holds my current state -> copy -> reduce the field range -> all landed.
+    TAU_HIP(hipStreamSynchronize(r->S));
+    TAU_HIP(hipStreamSynchronize(r->X));
+    int idx = 0;
+    if (tau3d_state_group(r->h, 0, nullptr, nullptr, nullptr, &idx)) return 1;
+    r->peer_cur[0] = r->peer_cur[1] = idx;
+    if (r->sh) {
+      r->sh->cur[r->rank].store(idx, std::memory_order_release);
+      if (ring::barrier(r->sh, "prime: states final")) return 1;
+      r->peer_cur[0] = r->sh->cur[r->lo].load(std::memory_order_acquire);
+      r->peer_cur[1] = r->sh->cur[r->hi].load(std::memory_order_acquire);
+    }
+    TAU_HIP(hipEventRecord(r->evE, r->S));
+    TAU_HIP(hipEventRecord(r->evI, r->S));
+    if (communicate(r, true, 0)) return 1;
+    TAU_HIP(hipStreamSynchronize(r->X));
+    if (r->sh && ring::barrier(r->sh, "prime: halos landed")) return 1;
+    r->primed = true;
+    return 0;
+  }
   if (tau3d_pack_halos_async(r->h, 0)) return 1;
   TAU_HIP(hipEventRecord(r->evE, r->S));
   TAU_HIP(hipEventRecord(r->evI, r->S));       // init / upload measured the field range on S: it is in the max words by now
@@ -441,16 +618,28 @@ extern "C" int tau3d_ring_prime(tau3d_ring_t *r) {
   r->primed = true;
   return 0;
 }
+extern "C" int tau3d_ring_prime(tau3d_ring_t *r) {
+  if (!r) return tau::fail("tau3d_ring_prime: null ring");
+  const int rc = ring_prime_impl(r);
+  if (rc) mark_failed(r);
+  return rc;
+}
 extern "C" int tau3d_ring_invalidate(tau3d_ring_t *r) {
   if (!r) return tau::fail("tau3d_ring_invalidate: null ring");
   r->primed = false;
   return 0;
 }
 
+static int ring_step_impl(tau3d_ring *r, int nsteps);
 extern "C" int tau3d_ring_step_async(tau3d_ring_t *r, int nsteps) {
   if (!r) return tau::fail("tau3d_ring_step: null ring");
+  const int rc = ring_step_impl(r, nsteps);
+  if (rc) mark_failed(r);   // peers leave their next barrier with an error instead of waiting for this rank
+  return rc;
+}
+static int ring_step_impl(tau3d_ring *r, int nsteps) {
   TAU_HIP(hipSetDevice(r->device));
-  if (!r->primed && tau3d_ring_prime(r)) return 1;
+  if (!r->primed && ring_prime_impl(r)) return 1;
   const int E = r->edge;
   for (int s = 0; s < nsteps; s++) {
     TAU_HIP(hipStreamWaitEvent(r->S, r->evX, 0));     // halos and max words of the step before have landed
@@ -463,6 +652,7 @@ extern "C" int tau3d_ring_step_async(tau3d_ring_t *r, int nsteps) {
     TAU_HIP(hipEventRecord(r->evI, r->S));
     if (communicate(r, true)) return 1;
     if (tau3d_slab_end_async(r->h)) return 1;
+    r->peer_cur[0] ^= 1; r->peer_cur[1] ^= 1;   // every rank swaps its two allocations with every step
     r->steps++;
   }
   return 0;

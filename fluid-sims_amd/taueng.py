@@ -152,6 +152,8 @@ def load():
         "tau3d_is_split": ([vp], i32), "tau3d_set_split": ([vp, i32], i32),
         "tau3d_slab_bounds": ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
         "tau3d_ring_create": ([C.POINTER(vp), vp, i32, i32, i32, C.c_char_p, C.c_uint64], i32),
+        "tau3d_set_halo_direct": ([vp, i32], i32),
+        "tau3d_state_group": ([vp, i32, C.POINTER(vp), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(i32)], i32),
         "tau3d_ring_destroy": ([vp], None),
         "tau3d_ring_prime": ([vp], i32), "tau3d_ring_invalidate": ([vp], i32),
         "tau3d_ring_step_async": ([vp, i32], i32), "tau3d_ring_finish": ([vp], i32),
@@ -277,7 +279,7 @@ def _f32(a):
     return a
 
 
-RING_RCCL, RING_HOST, RING_LOCAL = 0, 1, 2
+RING_RCCL, RING_HOST, RING_LOCAL, RING_IPC, RING_IPC_HOSTMAX = 0, 1, 2, 3, 4
 
 
 def slab_bounds(nz, world, rank):
@@ -290,13 +292,20 @@ def slab_bounds(nz, world, rank):
 class Tau3DRing:
     """tau3d_ring_*: the Z-slab ring inside the library (csrc/ring.hip) around one slab handle `eng` (a Tau3D created
     with this rank's z0 / nzl).  transport: RING_RCCL (librccl, one device per rank), RING_HOST (staged through the
-    rendezvous file, ranks may share a device), RING_LOCAL (world 1, device copies)."""
+    rendezvous file, ranks may share a device), RING_LOCAL (world 1, device copies), RING_IPC (direct halos: neighbours' halo
+    planes written through hipIpc mappings, RCCL for the 8-byte all-reduce), RING_IPC_HOSTMAX (the same with a host all-reduce).
+    job_key: non-zero and unique per launch when world > 1; None derives one from the launcher's environment (torchrun's
+    MASTER_PORT / TORCHELASTIC_RUN_ID — the same on every rank of a job, different between jobs)."""
 
-    def __init__(self, eng, rank, world, transport=RING_RCCL, rendezvous=None, job_key=0):
+    def __init__(self, eng, rank, world, transport=RING_RCCL, rendezvous=None, job_key=None):
         self._L = eng._L
         self.eng = eng
         self._r = C.c_void_p()
         rv = rendezvous.encode() if rendezvous else None
+        if job_key is None:
+            import zlib
+            tag = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TAU3D_JOB_KEY"))
+            job_key = (zlib.crc32(tag.encode()) << 32 | zlib.crc32((rendezvous or "").encode())) or 1
         _ck(self._L.tau3d_ring_create(C.byref(self._r), eng._h, rank, world, transport, rv, job_key))
 
     def close(self):
@@ -685,6 +694,11 @@ class Sph2D:
         g = np.empty((2 * H, W), np.int32)
         _ck(self._L.tausph_rasterize(self._h, W, H, g.ctypes.data))
         return g
+
+    def state_written(self):
+        """tausph_state_written: positions were written through the device pointers of tausph_state_ptrs — the next sub-step
+        counts the particles into their cells again instead of trusting the count the last force pass made"""
+        _ck(self._L.tausph_state_written(self._h))
 
     def rain_spawned(self):
         return int(self._L.tausph_rain_spawned(self._h))

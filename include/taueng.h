@@ -122,6 +122,14 @@ int tau3d_fill_halo_periodic_async(tau3d_t *h);
 /* (A caller that fills halo planes through tau3d_halo_recv_ptr itself — instead of the packed buffers and
  * tau3d_unpack_halos_async / tau3d_slab_begin_async — must call tau3d_state_written before the next step, so that the
  * field range the WENO weight form depends on covers what it wrote.) */
+/* Direct halos (the ring's IPC transport): with tau3d_set_halo_direct(h, 1) the neighbours' boundary planes are written
+ * straight into this slab's halo planes (tau3d_halo_recv_ptr of the NEXT state) by whoever drives the exchange, so
+ * tau3d_slab_begin_async shrinks to the one-thread controller / clock kernel and tau3d_slab_edges_async fills no packed
+ * send buffer.  tau3d_state_group: base address, size and per-field stride (floats) of the ONE allocation that holds the six
+ * fields of the current (which = 0) / next (1) state — what a peer process maps with hipIpcOpenMemHandle — and which of the
+ * handle's two ping-pong allocations it is (*index 0 / 1; the two swap roles with every step).  Any out pointer may be NULL. */
+int tau3d_set_halo_direct(tau3d_t *h, int on);
+int tau3d_state_group(tau3d_t *h, int which, void **base, size_t *bytes, size_t *field_stride, int *index);
 int tau3d_halo_send_ptr(tau3d_t *h, int which, int field, int side, float **p);
 int tau3d_halo_recv_ptr(tau3d_t *h, int which, int field, int side, float **p);
 /* Packed exchange buffers: 6 fields x 3 planes contiguous, one send and one recv buffer per side, so
@@ -139,8 +147,9 @@ int tau3d_max_ptr(tau3d_t *h, float **p);
  * *written_max = the largest it (or init / upload since) wrote, *fast_form = 1 if that launch took the
  * common-denominator WENO weights, 0 if the reciprocal form (input range above 6e4).  Any pointer may be NULL. */
 int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast_form);
-/* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state through them says so
- * here before the next step (tau3d_init / tau3d_upload_* do it themselves). */
+/* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state (or the solid mask) through them
+ * says so here before the next step (tau3d_init / tau3d_upload_* do it themselves): the field range is measured again and
+ * the static solid-free tile flags of the x/y flux kernel are rebuilt from the mask. */
 int tau3d_state_written(tau3d_t *h);
 int tau3d_sync(tau3d_t *h);
 /* what the handle was created with: its slab [z0, z0+nzl) of the global nz, its device and the stream its work runs on */
@@ -159,9 +168,14 @@ int tau3d_set_split(tau3d_t *h, int on);
  *   transport  TAU3D_RING_RCCL  ncclSend / ncclRecv / ncclAllReduce (librccl bound at run time; world 1 talks to itself)
  *              TAU3D_RING_HOST  staged through the rendezvous file by the host (ranks may share a device; tests, fallback)
  *              TAU3D_RING_LOCAL world 1: device copies, no collective
+ *              TAU3D_RING_IPC   direct halos: each rank maps its neighbours' state (hipIpc*MemHandle) and copies its new boundary
+ *                               planes straight into their halo planes (hipMemcpyAsync: SDMA over xGMI, no CU, no pack / unpack);
+ *                               RCCL only for the 8-byte all-reduce, which also orders the copies (csrc/ring.hip)
+ *              TAU3D_RING_IPC_HOSTMAX  the same copies with the all-reduce staged by the host (ranks may share a device: tests)
+ *   job_key    non-zero and unique per launch when world > 1 (tells this job's rendezvous file from a stale one)
  *   rendezvous path of a file rank 0 creates and the others map (ncclUniqueId, barrier, staging); every rank of a job
  *              passes the same path and job_key, a later job a different key.  May be NULL when world == 1. */
-enum { TAU3D_RING_RCCL = 0, TAU3D_RING_HOST = 1, TAU3D_RING_LOCAL = 2 };
+enum { TAU3D_RING_RCCL = 0, TAU3D_RING_HOST = 1, TAU3D_RING_LOCAL = 2, TAU3D_RING_IPC = 3, TAU3D_RING_IPC_HOSTMAX = 4 };
 typedef struct tau3d_ring tau3d_ring_t;
 /* contiguous split of nz planes over `world` ranks (every slab needs >= 6 planes) */
 int tau3d_slab_bounds(int nz, int world, int rank, int *z0, int *nzl);

@@ -95,7 +95,7 @@ def test_tau3d_multi_rank_refuses_without_gpu(built):
     r = run(os.path.join(built, "tau3d"), "--n", "32", "--frames", "1", "--gpus", "2", "--transport", "host")
     assert r.returncode == 1 and r.stderr.count("no CPU path") == 2 and "rank 1 exited with 1" in r.stderr
     assert run(os.path.join(built, "tau3d"), "--gpus", "0").returncode == 1
-    assert "rccl | host" in run(os.path.join(built, "tau3d"), "--transport", "mpi").stderr
+    assert "rccl | ipc | host | ipc-host" in run(os.path.join(built, "tau3d"), "--transport", "mpi").stderr
 
 
 @pytest.mark.gpu

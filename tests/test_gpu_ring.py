@@ -36,8 +36,13 @@ SHAPES = [((32, 32, 64), 6), ((64, 48, 40), 5),
           ((160, 128, 48), 3)]      # planes >= 128^2: the split step (k_flux_xy + k_update_z), with an interior piece at world 2
 
 
+# host: packed buffers staged through the rendezvous file.  ipc-host: the DIRECT transport — every rank maps its neighbours' state
+# allocations (hipIpcGetMemHandle / hipIpcOpenMemHandle through the rendezvous file) and copies its new boundary planes straight
+# into their halo planes on the exchange stream; only the 8-byte all-reduce is staged by the host here, because RCCL refuses ranks
+# that share a device (with one device per rank the same copies run beside RCCL's all-reduce: --transport ipc).
+@pytest.mark.parametrize("transport,banner", [("host", "host-staged transport"), ("ipc-host", "direct halos (IPC-mapped neighbours), host all-reduce")])
 @pytest.mark.parametrize("shape,frames", SHAPES)
-def test_tau3d_host_ring_is_bit_identical(eng, tmp_path, shape, frames):
+def test_tau3d_host_ring_is_bit_identical(eng, tmp_path, shape, frames, transport, banner):
     nx, ny, nz = shape
     grid = ["--nx", str(nx), "--ny", str(ny), "--nz", str(nz), "--frames", str(frames), "--start", "1"]
     want, _ = dump_of(tmp_path, "single.bin", *grid)
@@ -45,8 +50,8 @@ def test_tau3d_host_ring_is_bit_identical(eng, tmp_path, shape, frames):
     for world in (2, 3, 4, 8):
         if nz // world < 6:
             continue
-        got, out = dump_of(tmp_path, f"w{world}.bin", *grid, "--gpus", str(world), "--transport", "host")
-        assert f"ring: {world} ranks, host-staged transport" in out
+        got, out = dump_of(tmp_path, f"w{world}.bin", *grid, "--gpus", str(world), "--transport", transport)
+        assert f"ring: {world} ranks, {banner}" in out
         assert got == want, f"world {world}: dump differs from the single-domain run"
 
 
@@ -56,15 +61,19 @@ def test_tau3d_host_ring_at_the_benchmarked_plane_size(eng, tmp_path):
     wavespeed) byte for byte.  (Round-3 review: the only 512^2-plane record, taken before the -ffp-contract=on fix, showed a 1-ulp
     difference in maxs.)"""
     grid = ["--nx", "512", "--ny", "512", "--nz", "128", "--frames", "3", "--start", "1"]
+    frames = lambda o: [l for l in o.splitlines() if l.startswith("frame ")]
     want, out1 = dump_of(tmp_path, "single.bin", *grid)
     assert len(want) > 6 * 4 * 512 * 512 * 128
     got, out = dump_of(tmp_path, "w2.bin", *grid, "--gpus", "2", "--transport", "host")
     assert "ring: 2 ranks, host-staged transport" in out
     assert got == want, "2 ranks x 64 planes of 512^2: dump differs from the single-domain run"
+    got, out = dump_of(tmp_path, "w2ipc.bin", *grid, "--gpus", "2", "--transport", "ipc-host")
+    assert "direct halos" in out
+    assert got == want, "2 ranks x 64 planes of 512^2, direct halos: dump differs from the single-domain run"
+    assert frames(out) == frames(out1)
     # the same through RCCL talking to itself (one rank owning all 128 planes: slab_begin / edges / interior / all-reduce)
     got, out = dump_of(tmp_path, "ring1.bin", *grid, "--ring")
     assert got == want
-    frames = lambda o: [l for l in o.splitlines() if l.startswith("frame ")]
     assert frames(out) == frames(out1) and len(frames(out1)) >= 1, (frames(out1), frames(out))   # t, d_tau, dt, maxs to 9 digits
     print("single:", frames(out1)[-1], "| ring:", frames(out)[-1])
 
@@ -74,6 +83,10 @@ def test_tau3d_rccl_self_ring_is_bit_identical(eng, tmp_path):
     want, _ = dump_of(tmp_path, "single.bin", *grid)
     got, out = dump_of(tmp_path, "ring.bin", *grid, "--ring")
     assert "RCCL" in out and "communicator of 1" in out
+    assert got == want
+    # the direct transport with a world of one: own boundary planes into own halo planes, RCCL (communicator of one) all-reduce
+    got, out = dump_of(tmp_path, "ringipc.bin", *grid, "--ring", "--transport", "ipc")
+    assert "direct halos" in out and "RCCL" in out
     assert got == want
 
 
@@ -88,7 +101,7 @@ def test_tau3d_rccl_needs_one_device_per_rank(eng, tmp_path):
     assert "needs 2 devices" in r.stderr
 
 
-@pytest.mark.parametrize("transport", ["rccl", "local"])
+@pytest.mark.parametrize("transport", ["rccl", "local", "ipc"])
 def test_python_binding_ring_world1(eng, transport):
     """Tau3DRing (the ctypes mirror of tau3d_ring_*) with a world of one: RCCL to itself, and plain device copies"""
     nx, ny, nz, steps = 48, 40, 36, 7
@@ -101,7 +114,7 @@ def test_python_binding_ring_world1(eng, transport):
     e = eng.Tau3D(nx, ny, nz)
     e.init(1)
     e.set_clock(0.02, 1e-4)
-    ring = eng.Tau3DRing(e, 0, 1, eng.RING_RCCL if transport == "rccl" else eng.RING_LOCAL)
+    ring = eng.Tau3DRing(e, 0, 1, {"rccl": eng.RING_RCCL, "local": eng.RING_LOCAL, "ipc": eng.RING_IPC}[transport])
     ring.step(steps)
     ring.finish()
     c = ring.clock()
@@ -109,7 +122,7 @@ def test_python_binding_ring_world1(eng, transport):
     info = ring.info()
     ring.close()
     e.close()
-    if transport == "rccl":
+    if transport in ("rccl", "ipc"):
         assert info["rccl_version"] > 0 and info["comm_ranks"] == 1 and "rccl" in info["librccl"]
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
@@ -154,7 +167,8 @@ sys.exit(0)
         assert r.returncode == 7 and words in r.stdout, (rank, r.stdout, r.stderr)
 
 
-def test_bench_two_ranks_end_to_end_on_one_gpu(eng):
+@pytest.mark.parametrize("transport,word", [("host", "host-staged"), ("ipc-host", "direct halos")])
+def test_bench_two_ranks_end_to_end_on_one_gpu(eng, transport, word):
     """`python bench.py --gpus 2` as the driver calls it: bench.py spawns its own ranks under torch.distributed.run, each rank
     builds its slab and the library ring, rank 0 prints ONE JSON line with n_gpus = 2 and the per-rank kernel times.  On this
     one-GPU box the ranks share the device (--ring-transport host, process group over gloo); with RCCL the same command is
@@ -162,14 +176,50 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(eng):
     import json
     import sys
     r = run(sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2",
-            "--ring-transport", "host")
+            "--ring-transport", transport)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["decomposition"] == "z-slab x2" and j["value"] > 0
     assert len(j["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and all(t > 0 for t in j["roofline"]["per_rank_kernel_ms_per_step"])
-    assert "host-staged" in j["ring"]["transport"]
+    assert word in j["ring"]["transport"]
+
+
+def test_ring_refuses_a_zero_job_key_and_reports_a_failed_peer(eng, tmp_path):
+    """world > 1 needs a non-zero job key (it tells this job's rendezvous file from a stale one); and a rank that finds the file
+    of a job whose rank 0 has already given up learns so from the status word at once instead of waiting out a timeout"""
+    import sys
+    code = r"""
+import sys, ctypes
+sys.path.insert(0, %r)
+import fluid_sims_amd as f
+rank, key = int(sys.argv[1]), int(sys.argv[3])
+p = f.Tau3DParams(); f.load().tau3d_params_default(ctypes.byref(p), 32, 32, 32)
+z0, nzl = f.slab_bounds(32, 2, rank)
+e = f.Tau3D(32, 32, 32, params=p, z0=z0, nzl=nzl)
+e.init(1)
+try:
+    f.Tau3DRing(e, rank, 2, f.RING_HOST, rendezvous=sys.argv[2], job_key=key)
+except f.TauError as ex:
+    print("TauError:", ex); sys.exit(7)
+sys.exit(0)
+""" % ROOT
+    env = dict(os.environ, TAU3D_RING_TIMEOUT="3")
+    go = lambda rank, key: subprocess.run([sys.executable, "-c", code, str(rank), str(tmp_path / "rv"), str(key)], capture_output=True,
+                                          text=True, cwd=ROOT, env=env, timeout=120)
+    r = go(0, 0)
+    assert r.returncode == 7 and "non-zero job key" in r.stdout, (r.stdout, r.stderr)
+    r = go(0, 777)                       # rank 0 alone: times out at the start barrier, says so in the file and leaves it for its peers
+    assert r.returncode == 7 and "timed out" in r.stdout, (r.stdout, r.stderr)
+    assert os.path.exists(tmp_path / "rv")
+    import time
+    t0 = time.time()
+    r = go(1, 777)                       # a late rank 1 of that job: no 3-second wait, the status word is there
+    assert r.returncode == 7 and ("rank 0" in r.stdout), (r.stdout, r.stderr)
+    assert "failed" in r.stdout or "could not start" in r.stdout, r.stdout
+    r = go(1, 778)                       # another job's key under the same path: that file is not this job's -> waits, then gives up
+    assert r.returncode == 7 and "waited" in r.stdout, (r.stdout, r.stderr)
 
 
 def test_bench_falls_back_to_the_torch_ring_when_the_c_ring_cannot_be_built(eng):
