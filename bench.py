@@ -112,19 +112,35 @@ def input_variants(f, torch, dev, n, steps=20):
     out = {}
     stream = torch.cuda.Stream(dev)
     sp = ctypes.c_void_p(stream.cuda_stream)
-    for name, mode, warm, body in (("reference_ic_50_warmup", 0, 50, True), ("developed_no_body", 1, 10, False)):
+    # developed_late: the LATE developed state that exists at 512^3 — the reference's own ramped start after 2500 steps (inflow gain
+    # 0.8, bow shock standing, wake formed; the impulsive start of the headline runs away after ~55 steps and the ramped one before
+    # step 3250, in the reference's own kernel as in this engine: profiles/r04/long_run_512_*.txt, tests/test_gpu_ref3d.py).
+    # forced_reciprocal_weights: the headline input with TAU3D_WENO_RCP=1 — the general-form bodies flux_xy_body<false> /
+    # update_z_body<false> a state beyond |primitive| 6e4 would take (no sane 512^3 state does).
+    late_warm = 2500 if n >= 512 else 400
+    for name, mode, warm, body, rcp in (("reference_ic_50_warmup", 0, 50, True, False), ("developed_no_body", 1, 10, False, False),
+                                        ("developed_late", 0, late_warm, True, False), ("forced_reciprocal_weights", 1, 25, True, True)):
         p = f.Tau3DParams()
         f.load().tau3d_params_default(ctypes.byref(p), n, n, n)
         if not body:
             p.sdf_r = -1.0
-        e = f.Tau3D(n, n, n, params=p, stream=sp)
+        if rcp:
+            os.environ["TAU3D_WENO_RCP"] = "1"       # read by tau3d_create
+        try:
+            e = f.Tau3D(n, n, n, params=p, stream=sp)
+        finally:
+            os.environ.pop("TAU3D_WENO_RCP", None)
         e.init(mode)
         if mode:
             e.set_clock(0.02, 1e-4)
         e.step_async(warm)
         ms = _event_timed(torch, stream, lambda: e.step_async(steps), e.sync)
+        c = e.clock()
+        fr = e.field_range()
         out[name] = {"value": round(float(n) ** 3 * steps / ms / 1e6, 3), "unit": "Gcell-updates/s", "steps": steps, "warmup": warm,
-                     "timing": "HIP events on the handle's stream"}
+                     "timing": "HIP events on the handle's stream", "weno_form": "fast (common denominator)" if fr[2] else "reciprocal",
+                     "max_abs_primitive": round(float(max(fr[0], fr[1])), 1) if max(fr[0], fr[1]) < 3e38 else "inf",
+                     "t": c.t, "gain": round(c.gain, 4)}
         e.close()
     return out
 
@@ -141,11 +157,25 @@ def _event_timed(torch, stream, enqueue, sync):
     return e0.elapsed_time(e1)
 
 
-def _roof(kernel, ms_per_launch, units_per_launch, bytes_per_unit, bound, note=None):
+def _profile_traffic(keys):
+    """HBM bytes per launch of the named kernels from the committed PMC profile (profiles/k_step_traffic.json, regenerated from
+    profiles/<round>/secondary_fetch.txt + secondary_write.txt by scripts/make_traffic_json.py) — or None"""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "k_step_traffic.json")))
+        sec = tj["secondary_hbm_bytes_per_launch"]
+        return sum(sec[k] for k in keys), tj.get("secondary_source")
+    except Exception:
+        return None, None
+
+
+def _roof(kernel, ms_per_launch, units_per_launch, bytes_per_unit, bound, note=None, traffic_keys=None):
     gbs = units_per_launch * bytes_per_unit / (ms_per_launch * 1e-3) / 1e9
+    traffic, tsrc = _profile_traffic(traffic_keys) if traffic_keys else (None, None)
     r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-         "traffic": None, "kernel": kernel, "avg_launch_ms": round(ms_per_launch, 5),
+         "traffic": traffic, "kernel": kernel, "avg_launch_ms": round(ms_per_launch, 5),
          "algorithmic_bytes_per_launch": units_per_launch * bytes_per_unit, "binding_bound": bound}
+    if traffic is not None:
+        r["traffic_source"] = f"profile-derived, not this run: {tsrc}"
     if note:
         r["note"] = note
     return r
@@ -166,7 +196,7 @@ def other_configs(f, torch, dev):
     ms = _event_timed(torch, stream, lambda: e.step_async(200), e.sync)
     out.append({"config": f"tau_hypersonic_cuda 2D {n}x{n} fp32 (one fused kernel per step)", "steps": 200, "warmup": 50,
                 "value": round(n * n * 200 / ms / 1e6, 3), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 200, 5),
-                "roofline": _roof("h2d::k_march_lds<1>", ms / 200, n * n, 33, "valu")})
+                "roofline": _roof("h2d::k_march_lds<1>", ms / 200, n * n, 33, "valu", traffic_keys=["h2d::k_march_lds<1>"])})
     e.close()
 
     # ---- C3: tau_gray_scott 8192^2, init_pattern(seed 1337), 1000 steps: four time levels per pass (the default), and the
@@ -180,13 +210,14 @@ def other_configs(f, torch, dev):
                 "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
                 "roofline": _roof("st2::k_fused<GS,4> (one launch = 4 steps)", ms / 250, n * n, 16, "valu + hbm",
                                   "per LAUNCH: the compulsory traffic of a pass is one read and one write of u, v (16 B per cell) "
-                                  "whatever the number of time levels it advances; per cell-update the pass moves a quarter of that")})
+                                  "whatever the number of time levels it advances; per cell-update the pass moves a quarter of that",
+                                  traffic_keys=["st2::k_fused<0, 4>"])})
     g.set_levels(1)                                  # the reference's structure: one launch per step (bit-identical results)
     g.step_async(8)
     ms = _event_timed(torch, stream, lambda: g.step_async(1000), g.sync)   # ONE call: 1000 launches enqueued back to back
     out.append({"config": f"tau_gray_scott {n}x{n}, one step per launch", "steps": 1000, "warmup": 8,
                 "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
-                "roofline": _roof("st2::k_march<GS>", ms / 1000, n * n, 16, "hbm")})
+                "roofline": _roof("st2::k_march<GS>", ms / 1000, n * n, 16, "hbm")})   # (the profile pass runs the fused default)
     g.close()
 
     # ---- C4: tau_sph 4 194 304 particles, reset_particles(seed 69420), rain off, 200 sub-steps: on the lattice start
@@ -210,7 +241,9 @@ def other_configs(f, torch, dev):
                                           "note": "ordered pairs (i, j) within 2h x 2 neighbour passes per sub-step; pair count = mean of the "
                                                   "counts before and after the timed window (tausph_count_pairs)"},
                     "roofline": _roof("sph sub-step (counting-sort cell build + k_density + k_forces)", ms / 200, N, 100,
-                                      "valu (pair evaluation)")})
+                                      "valu (pair evaluation)",
+                                      traffic_keys=(["sph::k_tile_sums", "sph::k_scan", "sph::k_scatter", "sph::k_rank_gather", "sph::k_density<1>",
+                                                     "sph::k_forces<1>"] if not pre else None))})
     s.close()
 
     # ---- C1: tau_hypersonic.c restated (fp64 scalar CPU program), 256^2, 100 steps after init_sim, 1 thread
@@ -445,6 +478,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     k_ms, k_launches, k_cells = h.timing_read()
+    span_ms = h.timing_span()          # HIP events on the launch stream: first launch of the timed region -> end of the last
     xy_ms, z_ms, n_split = h.timing_read_split()
     h.timing_enable(False)
     is_split = h.is_split()
@@ -459,8 +493,12 @@ def main():
         km[rank] = k_ms / max(args.steps, 1)
         dist.all_reduce(km, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(x), 4) for x in km.tolist()]
+        sp = torch.tensor([span_ms], dtype=torch.float64, device=cdev)
+        dist.all_reduce(sp, op=dist.ReduceOp.MAX)
+        span_ms = float(sp.item())
 
     clk = get_clock()
+    frange = h.field_range()
     cells_total = float(n) ** 3 * args.steps
     value = cells_total / el / 1e9
 
@@ -493,6 +531,9 @@ def main():
                         "for it, the VALU block beside it says how close the step is to the bound that binds"}
         if per_rank_ms:
             roof["per_rank_kernel_ms_per_step"] = per_rank_ms
+        # the same K steps as the launch stream's own events saw them (max over ranks): no host clock, no process barrier
+        roof["event_span_ms_per_step"] = round(span_ms / max(args.steps, 1), 4)
+        roof["event_span_gcells"] = round(cells_total / (span_ms * 1e-3) / 1e9, 4) if span_ms > 0 else None
         if valu and n == 512 and k_s > 0:
             # second bound: wave-instructions issued per step (SQ_INSTS_VALU of the committed PMC pass) against what the chip
             # issues in the measured kernel time: 256 CUs x 4 SIMDs, one wave64 FMA-pipe instruction per 2 cycles
@@ -513,7 +554,12 @@ def main():
                "config": {"workload": f"tau_hypersonic_3d {n}^3 fp32, sphere r=0.25, Mach-100 inflow, "
                                       f"developed-flow start (SURVEY 8d input ii)",
                           "grid": [n, n, n], "decomposition": f"z-slab x{world}" if use_ring else "single domain",
-                          "halo_planes": 3, "t": clk.t, "d_tau": clk.d_tau, "maxs": clk.maxs},
+                          "halo_planes": 3, "t": clk.t, "d_tau": clk.d_tau, "maxs": clk.maxs,
+                          # which body of the kernels the timed steps ran (tau3d_field_range): the common-denominator WENO weights
+                          # while every |primitive| <= 6e4, else the reciprocal form
+                          "weno_form": "fast (common denominator)" if frange[2] else "reciprocal",
+                          "max_abs_primitive": round(float(max(frange[0], frange[1])), 1) if max(frange[0], frange[1]) < 3e38 else "inf",
+                          "timed_steps_after_start": [args.warmup, args.warmup + args.steps]},
                "roofline": roof}
         if out_valu:
             out["roofline_valu"] = out_valu

@@ -2530,6 +2530,19 @@ extern "C" int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, do
   if (cells) *cells = h->ev_cells;
   return 0;
 }
+/* device time from the start of the first timed interval to the end of the last one: the whole timed region as the launch
+ * stream saw it (kernels AND the gaps between them), without a host clock or a process barrier in it */
+extern "C" int tau3d_timing_span(tau3d_t *h, double *span_ms) {
+  if (!h || !span_ms) return tau::fail("tau3d_timing_span: null argument");
+  TAU_HIP(hipSetDevice(h->device));
+  *span_ms = 0.0;
+  if (h->n_ev < 1) return 0;
+  float ms = 0.f;
+  TAU_HIP(hipEventSynchronize(h->ev1[h->n_ev - 1]));
+  TAU_HIP(hipEventElapsedTime(&ms, h->ev0[0], h->ev1[h->n_ev - 1]));
+  *span_ms = ms;
+  return 0;
+}
 extern "C" int tau3d_timing_read_split(tau3d_t *h, double *xy_ms, double *z_ms, int *intervals) {
   TAU_HIP(hipSetDevice(h->device));
   double a = 0.0, b = 0.0;

@@ -14,6 +14,8 @@
 //                                                ncclAllReduce(max) on the two words of tau3d_max_ptr, in place
 //                                                record evX(n)
 //   slab_end        swap (host bookkeeping)
+// (TAU3D_RING_IPC: X carries the twelve halo copies only; S waits for them after the interior launch — they are long done —
+//  and runs the all-reduce itself, so nothing hops between streams on the critical path.)
 //
 // No host synchronisation between the pieces: tau3d_ring_step_async(n) only enqueues.  One communicator, used on ONE stream
 // (X), so RCCL sees its operations in one order on every rank.
@@ -574,6 +576,16 @@ static int communicate(tau3d_ring *r, bool with_max, int which = 1) {
     case TAU3D_RING_IPC: case TAU3D_RING_IPC_HOSTMAX: if (exchange_ipc(r, which)) return 1; break;
     default: if (exchange_local(r)) return 1; break;
   }
+  if (r->transport == TAU3D_RING_IPC) {
+    // The copies are the only thing on X; the all-reduce runs on the COMPUTE stream, behind the interior launch and behind the
+    // copies (which are long done by then): no stream hop on either side of it — the all-reduce sits on the critical path of
+    // every step (the next step's clock needs its result), the copies do not.  A rank thus enters all-reduce(n) only after ITS
+    // copies of step n have landed, which is the ordering the direct transport rests on (top of this file).
+    TAU_HIP(hipEventRecord(r->evX, r->X));
+    TAU_HIP(hipStreamWaitEvent(r->S, r->evX, 0));
+    if (with_max) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->S));
+    return 0;
+  }
   if (with_max && r->transport != TAU3D_RING_LOCAL) {
     TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
     if (r->uses_rccl()) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
@@ -605,6 +617,7 @@ static int ring_prime_impl(tau3d_ring *r) {
     TAU_HIP(hipEventRecord(r->evI, r->S));
     if (communicate(r, true, 0)) return 1;
     TAU_HIP(hipStreamSynchronize(r->X));
+    TAU_HIP(hipStreamSynchronize(r->S));
     if (r->sh && ring::barrier(r->sh, "prime: halos landed")) return 1;
     r->primed = true;
     return 0;

@@ -166,6 +166,7 @@ def load():
         "tau3d_timing_enable": ([vp, i32], i32),
         "tau3d_timing_read": ([vp, C.POINTER(C.c_double), C.POINTER(i32), C.POINTER(C.c_double)], i32),
         "tau3d_timing_read_split": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
+        "tau3d_timing_span": ([vp, C.POINTER(C.c_double)], i32),
         "tauh2_params_default": ([C.POINTER(H2Params), i32, i32], None),
         "tauh2_create": ([C.POINTER(vp), C.POINTER(H2Params), i32, vp], i32),
         "tauh2_destroy": ([vp], None),
@@ -533,6 +534,12 @@ class Tau3D:
         ms, n, cells = C.c_double(), C.c_int(), C.c_double()
         _ck(self._L.tau3d_timing_read(self._h, C.byref(ms), C.byref(n), C.byref(cells)))
         return ms.value, n.value, cells.value
+
+    def timing_span(self):
+        """device ms from the start of the first timed interval to the end of the last one (kernels and gaps)"""
+        ms = C.c_double()
+        _ck(self._L.tau3d_timing_span(self._h, C.byref(ms)))
+        return ms.value
 
     def timing_read_split(self):
         """(ms in k_flux_xy, ms in k_update_z, intervals) of the timed single-domain split steps"""

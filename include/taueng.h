@@ -219,6 +219,8 @@ int tau3d_outflow_reflection(tau3d_t *h, int nprobe, float *max_dp);
  * the summed duration in ms, the number of launches and the cells they updated. */
 int tau3d_timing_enable(tau3d_t *h, int on);
 int tau3d_timing_read(tau3d_t *h, double *total_ms, int *launches, double *cells);
+/* device time from the start of the first timed interval to the end of the last (kernels and the gaps between them) */
+int tau3d_timing_span(tau3d_t *h, double *span_ms);
 /* the same intervals split at the point between the two kernels of the split step (single-domain steps only):
  * summed duration of k_flux_xy and of k_update_z, and the number of intervals that had such a point */
 int tau3d_timing_read_split(tau3d_t *h, double *xy_ms, double *z_ms, int *intervals);
