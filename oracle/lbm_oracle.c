@@ -8,9 +8,11 @@
  * solid cell reflects its nine values in place), so a sequential sweep gives the one result any GPU
  * schedule gives.  Only tests/ may load this file.
  *
- * PARITY UNPINNED against reference outputs: SURVEY §8(c) recorded no check-values for tau_lbm.cu and the
- * reference holds no test or fixture for it.  tests/test_vis_oracle.py pins it against closed forms (mass
- * conservation, the equilibrium fixed point, bounce-back symmetry).
+ * Parity pin: the reference's own init_kernel / collide_stream_kernel built for gfx950 (oracle/_ref/tau_lbm.ieee.co,
+ * oracle/build_ref.sh) and run on the MI355X — the engine, which is bit-identical to this file, reproduces them bit
+ * for bit (tests/test_gpu_ref2d.py; the sheared start to 1 ulp: device sinf vs glibc sinf).  On the CPU, where no
+ * reference output exists (SURVEY §8(c) recorded none for tau_lbm.cu), tests/test_vis_oracle.py pins it against
+ * closed forms (mass conservation, the equilibrium fixed point, bounce-back symmetry).
  */
 #include "../include/tau_params.h"
 #include <math.h>

@@ -7,8 +7,10 @@
  * reference's own arithmetic evaluated on the host.  Only tests/,
  * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
  *
- * Parity pin: SURVEY.md §8(c) check-values (outputs of the reference source,
- * 32^3, 4 and 400 steps) — see tests/golden/ref_checkvalues.json and
+ * Parity pin: (GPU box) the reference's own k_build_solid_mask / k_init / k_step, built for gfx950 from th3cs.cu by
+ * oracle/build_ref.sh and run on the MI355X: this file's step lands within 2e-6 (rho, m, E; lam / kappa 7e-7) of them
+ * on developed states, its mask bit for bit (tests/test_gpu_ref3d.py).  (CPU) SURVEY.md §8(c) check-values
+ * (outputs of the reference source, 32^3, 4 and 400 steps) — tests/golden/ref_checkvalues.json,
  * tests/test_oracle_pins.py.
  *
  * Layout (same as the engine): every field is a local Z-slab with a 3-plane
