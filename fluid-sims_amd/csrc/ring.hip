@@ -558,9 +558,10 @@ static int exchange_ipc(tau3d_ring *r, int which) {
   const float *me = (const float *)base;
   float *lo = r->peer_base[0][r->peer_cur[0] ^ which], *hi = r->peer_base[1][r->peer_cur[1] ^ which];
   for (int f = 0; f < 6; f++) {
+    // (hipMemcpyDefault: the destination is another device's memory behind an IPC mapping — the runtime resolves both ends)
     TAU_HIP(hipMemcpyAsync(lo + f * r->peer_stride[0] + (size_t)(r->peer_nzl[0] + 3) * plane_n, me + f * stride + 3 * plane_n, bytes,
-                           hipMemcpyDeviceToDevice, r->X));
-    TAU_HIP(hipMemcpyAsync(hi + f * r->peer_stride[1], me + f * stride + (size_t)r->nzl * plane_n, bytes, hipMemcpyDeviceToDevice, r->X));
+                           hipMemcpyDefault, r->X));
+    TAU_HIP(hipMemcpyAsync(hi + f * r->peer_stride[1], me + f * stride + (size_t)r->nzl * plane_n, bytes, hipMemcpyDefault, r->X));
   }
   return 0;
 }

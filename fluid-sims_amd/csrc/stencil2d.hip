@@ -23,7 +23,13 @@
 
 namespace st2 {
 
-constexpr int ROWS = 8;         // rows marched by one wave (measured best at 8192^2: 32 k waves, halo rows come from L2)
+constexpr int ROWS = 8;         // rows marched by one wave, Burgers (VALU-bound: every fetched row is decoded through sinh, so short
+                                // chunks would decode (r + 2) / r times as much)
+constexpr int ROWS_HBM = 2;     // ... Gray-Scott and the shallow-water pass (HBM-bound).  Round 4, 8192^2, one step per launch, streaming
+                                // stores: 1 row 0.211 ms, 2: 0.187, 3: 0.190, 4: 0.195, 8: 0.203, 16: 0.213, 32: 0.205, 64: 0.212 — 131 k short
+                                // waves keep more loads in flight than 32 k longer ones, and the two rows a chunk shares with its
+                                // neighbours come from the L2 of the same XCD (xcd_swizzle keeps neighbouring chunks together):
+                                // 5.74 TB/s algorithmic = 71.7 % of the 8 TB/s roofline (torch's own copy_ on the same box: 5.2)
 constexpr int WAVES = 4;        // waves per workgroup
 enum { K_GS = 0, K_BURGERS = 1, K_SW = 2 };
 
@@ -304,7 +310,7 @@ static int launch(const Args &Ain, hipStream_t s) {
   if ((A.nx & 3) == 0) {
     static const int env_rows = getenv("TAU_ST2_ROWS") ? atoi(getenv("TAU_ST2_ROWS")) : 0;
     static const int env_nt = getenv("TAU_ST2_NT") ? atoi(getenv("TAU_ST2_NT")) : 1;   // streaming (nt) stores: +2-4 %
-    A.rows = env_rows > 0 ? env_rows : ROWS;
+    A.rows = env_rows > 0 ? env_rows : (KIND == K_BURGERS ? ROWS : ROWS_HBM);
     A.nt = env_nt;
     A.nstrips = (A.nx + 255) / 256;
     A.nchunks = (A.ny + A.rows - 1) / A.rows;
