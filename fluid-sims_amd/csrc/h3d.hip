@@ -594,6 +594,12 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 __device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
   return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
 }
+// (timing experiment only, DESIGN §8: what k_update_z would save if it read decoded primitives instead of decoding — wrong results)
+#ifdef TAU3D_EXP_NODECODE_Z
+#define ZDEC(u, m, e) (e)
+#else
+#define ZDEC(u, m, e) decode_field(u, m, e)
+#endif
 using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::lane_off;   // tau_common.h: scalar base + 32-bit lane offset
 
 // fetch_cell through a scalar plane base.  epl: field 0 of the encoded state at plane zh; fs4: bytes between fields; spl:
@@ -1010,6 +1016,14 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     if (SOLID) { own_solid = osol; sS[lc] = osol ? 1 : 0; }
+#ifdef TAU3D_EXP_XY_STORES   // timing experiment only: what six more stores per cell cost k_flux_xy (a decoded-primitive cache)
+    if (in_xy) {
+      GChar *const opl = (GChar *)(A.out0 + (size_t)zh * plane_n);
+      const unsigned vox = lane_off((unsigned)(yw * A.nx + x) << 2);
+#pragma unroll
+      for (int m = 0; m < 6; m++) gst(opl + m * fs4, vox, q[m]);
+    }
+#endif
     constexpr int NROWS = 2 * HALO * XT;
     constexpr int NHALO = NROWS + YT * 2 * HALO;
     if (tid < NHALO) {
@@ -1166,10 +1180,10 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   }
   C.in_xy = in_xy; C.own_solid = own_solid; C.x = x; C.yw = yw; C.z = z; C.lc = lc;
 }
-template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S) {
+template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S, unsigned bid) {
   XyCell C;
   const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
-  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
+  unsigned b = tau::xcd_swizzle(bid, nb);
   const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
   const int by = (int)(b % (unsigned)A.nty);
   const int bz = (int)(b / (unsigned)A.nty);
@@ -1197,18 +1211,41 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 // both (3.89 -> 3.82 and 2.29 -> 2.26 ms at 512^3, same box, interleaved) within their launch-bound register caps, while it takes
 // the fused k_step — bounded at two waves per SIMD — from 152 to 252 VGPRs and 96^3 from 92 to 105 us.  The option is per module.
 #ifdef TAU3D_SPLIT_TU
-__global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
+// ONE WENO weight form per kernel (round 4).  Which form a step takes is decided on the device (the field range lives in the
+// clock block; the host never waits for it), and rounds 2-3 carried both bodies in one kernel behind a scalar branch.  Measured,
+// same box, interleaved: the fast body alone in its kernel runs k_flux_xy 3.79 -> 3.67 ms and k_update_z 2.37 -> 2.32 (the
+// kernel with both bodies is twice the code, and k_update_z's allocation is the maximum of the two: 96 VGPRs, 33 spilled SGPRs
+// and 16 B of scratch against 94 / 0 / 0).  So each form is its own kernel, and a step launches BOTH for each piece: the one the
+// host expects (its last look at the clock block: tau3d_get_clock, tau3d_field_range, tau3d_step) over the full grid, the other
+// as a safety net — a small resident grid that strides over the tiles.  Each leaves at once when the device's range says the
+// other form is due, so exactly one of the two does the work, whatever the host guessed: a wrong guess costs time (an empty full
+// grid, then the strided kernel), never correctness.  STRIDE = false is the launch of rounds 2-3, one tile per workgroup.
+template <bool FAST, bool STRIDE> __global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyLds S;
-#ifdef TAU3D_FAST_ONLY   // ISA statistics only (scripts/isa_kernel_mix.py): the object then holds the one body that runs
-  flux_xy_body<true>(A, S);
+  if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;
+  if (!STRIDE) { flux_xy_body<FAST>(A, S, blockIdx.x); return; }
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
+    flux_xy_body<FAST>(A, S, b);
+    __syncthreads();   // the next tile's staging overwrites what slow waves of this one still read
+  }
+}
+void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast) {
+  const unsigned net = nwg < 768u ? nwg : 768u;   // three workgroups per CU resident
+#ifdef TAU3D_FAST_ONLY   // ISA statistics only (scripts/isa_kernel_mix.py)
+  hipLaunchKernelGGL((k_flux_xy<true, false>), dim3(nwg), dim3(XNT), 0, s, A);
 #else
-  if (fast_form(A.clk->fmax_in, A.in_fmax)) flux_xy_body<true>(A, S);
-  else flux_xy_body<false>(A, S);
+  if (expect_fast) {
+    hipLaunchKernelGGL((k_flux_xy<true, false>), dim3(nwg), dim3(XNT), 0, s, A);
+    hipLaunchKernelGGL((k_flux_xy<false, true>), dim3(net), dim3(XNT), 0, s, A);
+  } else {
+    hipLaunchKernelGGL((k_flux_xy<false, false>), dim3(nwg), dim3(XNT), 0, s, A);
+    hipLaunchKernelGGL((k_flux_xy<true, true>), dim3(net), dim3(XNT), 0, s, A);
+  }
 #endif
 }
-void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A) { hipLaunchKernelGGL(k_flux_xy, dim3(nwg), dim3(XNT), 0, s, A); }
 #else
-void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A);   // XNT threads per workgroup
+void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // XNT threads per workgroup; both weight forms, see k_flux_xy
 #endif
 
 // The update of one fluid cell, :1266-1358: conservative update from the x/y divergence D and the two z-face fluxes,
@@ -1303,12 +1340,12 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
 // per plane to slide, and pushed the kernel to 148 VGPRs / three waves.
 constexpr int ZT_X = 64, ZT_Y = 4, ZNT = ZT_X * ZT_Y;
 typedef float ZRing[5][6][ZNT];
-template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring) {
+template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring, unsigned bid) {
   const int tid = threadIdx.x;
   const int lx = tid & (ZT_X - 1), ly = tid >> 6;
   const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
   const unsigned nb = (unsigned)(nbx * nby * A.nzc);
-  unsigned b = tau::xcd_swizzle(blockIdx.x, nb);
+  unsigned b = tau::xcd_swizzle(bid, nb);
   const int bx = (int)(b % (unsigned)nbx); b /= (unsigned)nbx;
   const int by = (int)(b % (unsigned)nby);
   const int bz = (int)(b / (unsigned)nby);
@@ -1341,7 +1378,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   auto load_own = [&](int k, float (&dst)[6]) -> unsigned {   // plane zc_lo-3+k
     const unsigned vo = col4 + (unsigned)k * plane4;
 #pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = decode_field(uref, m, *(const GFloat *)(qP + m * fs4 + vo));
+    for (int m = 0; m < 6; m++) dst[m] = ZDEC(uref, m, *(const GFloat *)(qP + m * fs4 + vo));
     return solP[vo >> 2] != 0 ? 1u : 0u;
   };
 
@@ -1401,7 +1438,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     asm volatile("" : "+s"(f4), "+s"(d4));
     if (more) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) Nx[m] = decode_field(uref, m, gld(qN + m * f4, vo));
+      for (int m = 0; m < 6; m++) Nx[m] = ZDEC(uref, m, gld(qN + m * f4, vo));
       nsol = solN[vo >> 2] != 0 ? 1u : 0u;
     }
     const bool own_solid = (ws >> 2) & 1u;
@@ -1531,19 +1568,31 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #ifndef TAU3D_Z_WAVES
 #define TAU3D_Z_WAVES 5
 #endif
-__global__ __launch_bounds__(ZNT, TAU3D_Z_WAVES) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
+template <bool FAST, bool STRIDE> __global__ __launch_bounds__(ZNT, TAU3D_Z_WAVES) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
   __shared__ ZRing ring;
+  if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;   // (one weight form per kernel: comment at k_flux_xy)
+  if (!STRIDE) { update_z_body<FAST>(A, ring, blockIdx.x); return; }
+  const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
+  const unsigned nb = (unsigned)(nbx * nby * A.nzc);
+  for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) update_z_body<FAST>(A, ring, b);   // (a thread reads only its own ring slots: no barrier)
+}
+void launch_update_z(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast) {
+  const unsigned net = nwg < 1280u ? nwg : 1280u;   // five workgroups per CU resident
 #ifdef TAU3D_FAST_ONLY
-  update_z_body<true>(A, ring);
+  hipLaunchKernelGGL((k_update_z<true, false>), dim3(nwg), dim3(ZNT), 0, s, A);
 #else
-  if (fast_form(A.clk->fmax_in, A.in_fmax)) update_z_body<true>(A, ring);
-  else update_z_body<false>(A, ring);
+  if (expect_fast) {
+    hipLaunchKernelGGL((k_update_z<true, false>), dim3(nwg), dim3(ZNT), 0, s, A);
+    hipLaunchKernelGGL((k_update_z<false, true>), dim3(net), dim3(ZNT), 0, s, A);
+  } else {
+    hipLaunchKernelGGL((k_update_z<false, false>), dim3(nwg), dim3(ZNT), 0, s, A);
+    hipLaunchKernelGGL((k_update_z<true, true>), dim3(net), dim3(ZNT), 0, s, A);
+  }
 #endif
 }
-void launch_update_z(unsigned nwg, hipStream_t s, const Args &A) { hipLaunchKernelGGL(k_update_z, dim3(nwg), dim3(ZNT), 0, s, A); }
 }  // namespace h3d — the split-step translation unit ends here
 #else
-void launch_update_z(unsigned nwg, hipStream_t s, const Args &A);   // ZNT threads per workgroup
+void launch_update_z(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // ZNT threads per workgroup
 
 // ---------------------------------------------------------------- small kernels
 __global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes included
@@ -1873,6 +1922,8 @@ struct tau3d {
   h3d::Args base;           // constants, pointers filled per launch
   int zchunk;
   float *xbuf[2][2];        // [kind: 0 send, 1 recv][side]: packed 6 x 3 planes
+  bool expect_fast = true;  // which WENO weight form the host expects the next split step to take (its last look at the clock block;
+                            // both forms are launched, the device decides: k_flux_xy)
   bool direct = false;      // Z-slab ring with direct halos (tau3d_set_halo_direct): neighbours write this slab's halo planes themselves
   uint8_t *pidx = nullptr;   // palette indices of the last tau3d_palette_indices
   float *vis;               // nx*ny*nzl scalar field of the last tau3d_vis (lazy)
@@ -1985,6 +2036,8 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
   fill_consts(h);
+  h->expect_fast = h->base.in_fmax <= 3.0e38f;   // (TAU3D_WENO_RCP=1 or an inflow state beyond the fast window: the reciprocal form for good)
+  if (h->expect_fast) h->expect_fast = h3d::fast_form(0.f, h->base.in_fmax);
   // the solid mask depends on the parameters and the slab only: a caller that goes create -> upload -> step
   // (without tau3d_init) must find it built (and the state buffers defined: zeroed above)
   if (build_solid(h)) return 1;
@@ -2035,6 +2088,8 @@ extern "C" int tau3d_get_clock(tau3d_t *h, tau3d_clock *out) {
   TAU_HIP(hipMemcpyAsync(&c, h->clk, sizeof(c), hipMemcpyDeviceToHost, h->stream));
   TAU_HIP(hipStreamSynchronize(h->stream));
   out->t = c.t; out->d_tau = c.d_tau; out->dt = c.dt; out->gain = c.gain; out->maxs = c.maxs_last; out->step = c.step;
+  // the host's expectation of the next step's WENO form (k_flux_xy): the range the last step read and the one it wrote
+  h->expect_fast = h3d::fast_form(fmaxf(c.fmax_in, __builtin_bit_cast(float, c.fmax_bits)), h->base.in_fmax);
   return 0;
 }
 
@@ -2172,7 +2227,7 @@ static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s)
   const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
   X.zchunk = 1; X.nzc1 = n1; X.nzc = n1 + n2;
   X.ntx = (X.nx + h3d::XT - 1) / h3d::XT; X.nty = (X.ny + h3d::YT - 1) / h3d::YT;
-  h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X);
+  h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X, h->expect_fast);
   TAU_LAUNCH_CHECK("k_flux_xy");
   return 0;
 }
@@ -2196,7 +2251,7 @@ static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipS
   Z.nzc1 = (n1 + Z.zchunk - 1) / Z.zchunk;
   Z.nzc = Z.nzc1 + (n2 ? (n2 + Z.zchunk - 1) / Z.zchunk : 0);
   if (pack) { Z.send[0] = h->xbuf[0][0]; Z.send[1] = h->xbuf[0][1]; }
-  h3d::launch_update_z((unsigned)(tz * Z.nzc), s, Z);
+  h3d::launch_update_z((unsigned)(tz * Z.nzc), s, Z, h->expect_fast);
   TAU_LAUNCH_CHECK("k_update_z");
   return 0;
 }
@@ -2466,6 +2521,7 @@ extern "C" int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max
   if (read_max) *read_max = c.fmax_in;
   if (written_max) *written_max = w;
   if (fast_form) *fast_form = h3d::fast_form(c.fmax_in, h->base.in_fmax) ? 1 : 0;
+  h->expect_fast = h3d::fast_form(fmaxf(c.fmax_in, __builtin_bit_cast(float, c.fmax_bits)), h->base.in_fmax);
   return 0;
 }
 extern "C" int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *device, void **stream) {

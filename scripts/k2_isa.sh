@@ -6,7 +6,7 @@ import re,sys
 sys.path.insert(0,'scripts')
 import isa_mix
 from collections import Counter
-name=sys.argv[1] if len(sys.argv)>1 else '_ZN3h3d10k_update_zENS_4ArgsE'
+name=sys.argv[1] if len(sys.argv)>1 else '_ZN3h3d10k_update_zILb1ELb0EEEvNS_4ArgsE'
 txt=open('/tmp/h3d.s').read()
 lines=txt.split('\n')
 start=next(i for i,l in enumerate(lines) if l.startswith(name+':'))
