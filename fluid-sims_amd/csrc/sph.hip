@@ -828,7 +828,17 @@ extern "C" int tausph_download(tausph_t *h, float *pos_xy, float *vel_xy, float 
   TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
+extern "C" int tausph_state_written(tausph_t *h);
 extern "C" int tausph_state_ptrs(tausph_t *h, float **pos, float **vel, float **acc, float **s, float **press) {
+  // Whoever holds these pointers may move particles behind the engine's back, and the force pass's fused count of the NEXT
+  // build's cells (k_forces, A.countNext) would then scatter by stale cells while the records gather the new positions —
+  // neighbour pairs missed without a word.  From the first hand-out on, this handle counts the cells from the positions at
+  // every sub-step again (k_count: ~28 us of a 1.2 ms sub-step at 4 M particles), as the reference's k_build_cells reads them
+  // every sub-step; tausph_state_written is then only needed for the sub-step already enqueued.
+  if (pos && h->fuse_count) {
+    h->fuse_count = false;
+    if (tausph_state_written(h)) return 1;
+  }
   if (pos) *pos = (float *)h->a.pos;
   if (vel) *vel = (float *)h->a.vel;
   if (acc) *acc = (float *)h->a.acc;

@@ -278,8 +278,9 @@ int tausph_upload(tausph_t *h, const float *pos_xy, const float *vel_xy);
 /* any pointer may be NULL; cellOf = integer cell index gy*Gx+gx of the last sub-step's build */
 int tausph_download(tausph_t *h, float *pos_xy, float *vel_xy, float *acc_xy, float *s, float *press, int32_t *cellOf);
 int tausph_state_ptrs(tausph_t *h, float **pos, float **vel, float **acc, float **s, float **press);
-/* the pointers above are for reading; a caller that does move particles through them says so before the next sub-step (the
- * force pass has already counted the positions it wrote into the cells of the next build) */
+/* Once the position pointer has been handed out the handle counts the cells from the positions at EVERY sub-step (as the
+ * reference's k_build_cells does), instead of trusting the count its force pass made: a caller may move particles through it at
+ * any time.  tausph_state_written is still how a caller says so for a sub-step that is already enqueued. */
 int tausph_state_written(tausph_t *h);
 int tausph_grid(tausph_t *h, int *Gx, int *Gy, float *cell, float *hh, float *mass); /* :512-521, 573-576 */
 float tausph_dt(tausph_t *h);                                               /* :666-669 */
