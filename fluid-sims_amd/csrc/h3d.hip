@@ -1192,8 +1192,12 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   const unsigned tflag = A.xyflag == nullptr ? 1u : A.xyflag[((size_t)z * A.nty + by) * A.ntx + bx];
   if (tflag == 2u) return;   // the tile is inside the body: no cell of it takes a divergence (4 % of the tiles of the 512^3 sphere case)
   const bool any_solid = tflag != 0u;
+#ifdef TAU3D_EXP_NOSOLID   // timing experiment only: the kernel without its solid-aware body, on an input without a body
+  flux_xy_core<FAST, false>(A, S, C, bx, by, z);
+#else
   if (any_solid) flux_xy_core<FAST, true>(A, S, C, bx, by, z);
   else flux_xy_core<FAST, false>(A, S, C, bx, by, z);
+#endif
   if (C.in_xy && !C.own_solid) {
     GChar *const dpl = (GChar *)(A.d0 + (size_t)C.z * ((size_t)A.nx * A.ny));
     const size_t ds4 = (size_t)A.dstride << 2;

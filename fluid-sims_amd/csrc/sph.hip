@@ -52,6 +52,7 @@ struct Args {
   float2 *recB;       // sorted: p / rho^2, rho
   float2 *recP;       // sorted: x, y once more (the scan only needs 8 B per candidate)
   unsigned *nbrMask;  // [NW][N] in-range bitmasks, written by k_density, read by k_forces
+  unsigned *ovfMask;  // [3][OVW][N] the same for the 32-candidate blocks beyond the ROWCAP candidates a row's masks cover (dense states)
   float4 *recA2;      // sorted: x, y, vx, vy AFTER the integrate (only when XSPH is on)
   int *rainWinner;    // per particle: highest drop index that picked it this launch, else -1 (only with rain)
   float xsphEps;
@@ -277,6 +278,8 @@ __device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :1
 constexpr int WPR = 4;              // mask words per row range
 constexpr int ROWCAP = 32 * WPR;    // candidates per row range covered by the mask
 constexpr int NW = 3 * WPR;
+constexpr int OVW = 60;             // overflow blocks per row range whose hit masks the density pass hands to the force pass:
+                                    // (WPR + OVW) * 32 = 2048 candidates per row (the collapsed dam: ~1200); beyond that both scan
 constexpr int CAP = 3 * (256 + 128); // staged records: 3 rows x (the workgroup's run + one cell either side)
 
 // per lanes-per-particle configuration: particles per workgroup and the staged records (LPP = 2: half the run, so half the
@@ -381,16 +384,26 @@ __device__ __forceinline__ void for_each_hit(const unsigned (*sM)[PW], int pl, i
 // evaluated: walking every candidate with an `if (in range)` costs the full evaluation per candidate on a 64-wide wave
 // (some lane is always in range), which is what made the collapsed dam (~1200 candidates per row, ~35 % in range) 2.8x
 // more expensive than its pair count.  `inrange(j)` is the cheap test, `body(j)` the evaluation of a hit.
-template <int LPP, class T, class F>
-__device__ __forceinline__ void for_each_overflow(const Walk &wk, int sub, T &&inrange, F &&body) {
+// MODE 0: scan every block (no mask storage); 1: scan and STORE the block masks (density pass); 2: LOAD them instead of scanning
+// (force pass: positions have not moved since the density pass).  Round 4: on the collapsed dam the force pass spent two thirds
+// of its time re-scanning ~3 600 candidates per particle for the ~350 it then evaluates.
+template <int LPP, int MODE, class T, class F>
+__device__ __forceinline__ void for_each_overflow(const Args &A, int k, const Walk &wk, int sub, T &&inrange, F &&body) {
 #pragma unroll
   for (int r = 0; r < 3; r++)
     for (int blk = WPR + sub; blk * 32 < wk.jn[r]; blk += LPP) {
       const int j0 = wk.jb[r] + blk * 32, cnt = min(32, wk.jn[r] - blk * 32);
+      const int ow = blk - WPR;
+      const bool kept = MODE != 0 && ow < OVW;
       unsigned m = 0u;
+      if (MODE == 2 && kept) {
+        m = A.ovfMask[((size_t)(r * OVW + ow)) * A.N + k];
+      } else {
 #pragma unroll 4
-      for (int b = 0; b < cnt; b++) m = m + m + (inrange(j0 + b) ? 1u : 0u);
-      m = __builtin_bitreverse32(m) >> (32 - cnt);                 // candidate b -> bit b (cnt >= 1 here)
+        for (int b = 0; b < cnt; b++) m = m + m + (inrange(j0 + b) ? 1u : 0u);
+        m = __builtin_bitreverse32(m) >> (32 - cnt);                 // candidate b -> bit b (cnt >= 1 here)
+        if (MODE == 1 && kept) A.ovfMask[((size_t)(r * OVW + ow)) * A.N + k] = m;
+      }
       while (m != 0u) {                                            // two hits per trip, as in for_each_hit
         const int ja = j0 + __builtin_ctz(m);
         m &= m - 1u;
@@ -444,7 +457,12 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[PW], i
     rho += on ? w : 0.f;
   };
   for_each_hit<LPP, TAUSPH_NH_D, PW>(sM, pl, sub, wk, add);
-  for_each_overflow<LPP>(wk, sub, [&](int j) {
+  if (A.ovfMask) for_each_overflow<LPP, 1>(A, k, wk, sub, [&](int j) {
+    const float2 o = P[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    return dx * dx + dy * dy < twoh2;
+  }, add);
+  else for_each_overflow<LPP, 0>(A, k, wk, sub, [&](int j) {
     const float2 o = P[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
     return dx * dx + dy * dy < twoh2;
@@ -490,7 +508,7 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
 
 // acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
 template <int LPP, bool VISC, int PW, class ArrA, class ArrB>
-__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int kk, const Walk &wk,
+__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int kk, int kg, const Walk &wk,
                                            float4 me, float2 meB, ArrA RA, ArrB RB) {
   const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
   const float ih = 1.0f / h;
@@ -528,7 +546,12 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], in
     ay += coef * gwy;
   };
   for_each_hit<LPP, TAUSPH_NH_F, PW>(sM, pl, sub, wk, add);
-  for_each_overflow<LPP>(wk, sub, [&](int j) {
+  if (A.ovfMask) for_each_overflow<LPP, 2>(A, kg, wk, sub, [&](int j) {
+    const float4 o = RA[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    return dx * dx + dy * dy < twoh2;
+  }, add);
+  else for_each_overflow<LPP, 0>(A, kg, wk, sub, [&](int j) {
     const float4 o = RA[j];
     const float dx = me.x - o.x, dy = me.y - o.y;
     return dx * dx + dy * dy < twoh2;
@@ -563,11 +586,11 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
   if (st.on) {
 #pragma unroll
     for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB)
-                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k + st.delta[1], wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB)
+                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB);
   } else {
-    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
-                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
+                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
   }
   if (sub != 0) return;
   float ax = a.x, ay = a.y;
@@ -741,6 +764,9 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipMalloc(&A.recA, N * sizeof(float4))); TAU_HIP(hipMalloc(&A.recB, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.recP, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.nbrMask, N * sizeof(unsigned) * 12));
+  // overflow-block masks (720 B per particle; written and read only where a row holds more than 128 candidates)
+  if (!(getenv("TAU_SPH_OVFMASK") && atoi(getenv("TAU_SPH_OVFMASK")) == 0))
+    TAU_HIP(hipMalloc(&A.ovfMask, N * sizeof(unsigned) * 3 * sph::OVW));
   A.xsphEps = P->xsphEps;
   if (P->useXSPH && P->xsphEps > 0.f) TAU_HIP(hipMalloc(&A.recA2, N * sizeof(float4)));
   if (P->rain) {
@@ -770,7 +796,7 @@ extern "C" void tausph_destroy(tausph_t *h) {
   sph::Args &A = h->a;
   hipFree(A.pos); hipFree(A.vel); hipFree(A.acc); hipFree(A.s); hipFree(A.press); hipFree(A.cellOf);
   hipFree(A.keys); hipFree(A.ids); hipFree(A.keys_s); hipFree(A.ids_s); hipFree(A.cellStart);
-  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(A.recA2); hipFree(A.rainWinner); hipFree(h->raster);
+  hipFree(A.recA); hipFree(A.recB); hipFree(A.recP); hipFree(A.nbrMask); hipFree(A.ovfMask); hipFree(A.recA2); hipFree(A.rainWinner); hipFree(h->raster);
   hipFree(A.tmpKey); hipFree(A.tmpId); hipFree(A.cellCount); hipFree(A.tileSum); hipFree(h->pairs);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
