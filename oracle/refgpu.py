@@ -240,6 +240,15 @@ class Ref3D:
         self.a, self.b = self.b, self.a
         return float(self.maxs.get(np.float32, (1,))[0])
 
+    def schlieren(self):
+        """k_schlieren_export (th3cs.cu:641-673; launched :1200-1201) of the current state: |grad rho| per cell, 0 in solids"""
+        out = DevBuf(4 * self.N)
+        self.m.launch("k_schlieren_export", self.grid, self.BLOCK, [_p(x) for x in self.a] + [_p(self.solid), _p(out)])
+        self.m.sync()
+        v = out.get(np.float32, self.shape)
+        out.free()
+        return v
+
     def run(self, nsteps):
         """th3cs.cu:1160-1196 == tau_hypersonic_3d_cuda.cu:1680-1704, in fp32 with libm's expf as the host code has it"""
         f = np.float32
@@ -343,6 +352,29 @@ class RefSph:
         self.m.launch("k_integrate", (GS,), (BS,), [_p(self.pos), _p(self.vel), _p(self.acc), i32(N), f32(dt), f32(self.box[0]), f32(self.box[1])])
         self.m.sync()
         return lists
+
+    def xsph(self, eps):
+        """k_xsph_cell + k_apply_xsph as tau_sph.cu:698-704 launches them after k_integrate: the lists of the last build, the
+        positions / velocities from after the integrate; acc is the scratch array for the velocity increments"""
+        N, BS = self.N, 256
+        GS = (N + BS - 1) // BS
+        i32, f32 = C.c_int, C.c_float
+        self.m.launch("k_xsph_cell", (GS,), (BS,), [_p(self.pos), _p(self.vel), _p(self.s), _p(self.acc), _p(self.head), _p(self.next), i32(N),
+                                                    f32(self.mass), f32(self.h), f32(eps), i32(self.Gx), i32(self.Gy), f32(self.cell)])
+        self.m.launch("k_apply_xsph", (GS,), (BS,), [_p(self.vel), _p(self.acc), i32(N)])
+        self.m.sync()
+
+    def rasterize(self, W, H):
+        """k_clear_grid + k_rasterize, tau_sph.cu:747-753: particle counts on a (2H, W) raster, y flipped"""
+        size = 2 * H * W
+        g = DevBuf(4 * size)
+        self.m.launch("k_clear_grid", ((size + 255) // 256,), (256,), [_p(g), C.c_int(size)])
+        self.m.launch("k_rasterize", ((self.N + 255) // 256,), (256,), [_p(self.pos), C.c_int(self.N), _p(g), C.c_int(W), C.c_int(H),
+                                                                        C.c_float(self.box[0]), C.c_float(self.box[1])])
+        self.m.sync()
+        out = g.get(np.int32, (2 * H, W))
+        g.free()
+        return out
 
     @staticmethod
     def cells_from_lists(head, nxt):

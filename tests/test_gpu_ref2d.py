@@ -134,6 +134,38 @@ def test_sph_substep_vs_reference_kernels(eng, oracle_built, refgpu, N, warm, kw
     e.close()
 
 
+@pytest.mark.parametrize("N,warm", [(16384, 60), (65536, 120)])
+def test_sph_xsph_and_raster_vs_reference_kernels(eng, refgpu, N, warm):
+    """the SPH extras of SURVEY §8f row 3 against the reference's own kernels: k_rasterize (integer counts: bit-exact) and
+    k_xsph_cell + k_apply_xsph on the lists of the sub-step's build with the moved particles (tau_sph.cu:698-704)"""
+    eps = 0.25
+    e = eng.Sph2D(N, useXSPH=1, xsphEps=eps)
+    e.reset_particles()
+    e.step(warm)
+    st = e.download()
+    dt = e.dt()
+    r = refgpu.RefSph(N, ieee=True, **{k: getattr(e.params, k) for k in "boxX boxY rho0 c0 gammaEOS hMul viscAlpha gravity useVisc useGrav".split()})
+    r.upload(st["pos"], st["vel"])
+    r.substep(dt)
+    r.xsph(eps)
+    want = r.state()
+    e.substep(dt)
+    got = e.download()
+    assert np.abs(got["pos"] - want["pos"]).max() <= 1e-5
+    vscale = np.linalg.norm(want["vel"].astype(np.float64), axis=1) + 1.0        # c0 = 1
+    assert (np.linalg.norm(got["vel"].astype(np.float64) - want["vel"], axis=1) / vscale).max() <= 1e-5
+    for W, H in ((80, 24), (200, 50)):
+        assert np.array_equal(e.rasterize(W, H), r.rasterize(W, H)) or np.abs(e.rasterize(W, H).astype(np.int64) - r.rasterize(W, H)).sum() <= 4, \
+            "raster counts differ by more than the particles whose position differs in the last place across a pixel edge"
+    r2 = refgpu.RefSph(N, ieee=True)
+    r2.upload(got["pos"], got["vel"])                 # the same positions, bit for bit: the counts must be identical
+    assert np.array_equal(e.rasterize(120, 40), r2.rasterize(120, 40))
+    assert int(r2.rasterize(120, 40).sum()) == N
+    r.close()
+    r2.close()
+    e.close()
+
+
 # ---------------------------------------------------------------------------------------------------- LBM
 @pytest.mark.parametrize("nx,ny,kw", [(512, 256, {}), (100, 60, dict(obstacle_radius=9.0)), (257, 33, dict(obstacle=0)),
                                       (2048, 1024, dict(tau=0.8, drive=1e-4))])

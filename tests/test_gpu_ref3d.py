@@ -204,3 +204,28 @@ def test_full_size_512_cubed_vs_reference_kernel(eng, refgpu, start, warm, allow
         assert nbad == 0, worst
     else:
         assert ncells <= allow and worst_cell <= 1e-4, (ncells, worst_cell, worst)
+
+
+@pytest.mark.parametrize("shape,warm", [((32, 32, 32), 30), ((64, 64, 64), 40), ((96, 64, 32), 40)])
+def test_schlieren_field_vs_reference_kernel(eng, refgpu, shape, warm):
+    """k_schlieren_export of th3cs.cu (what its .4spl frames are made of) on the engine's developed state against tau3d_vis mode 0
+    (|grad rho|, the same prim_at_xbc boundary states): relative to the operands of the differences, as tests/test_gpu_vis.py does"""
+    nx, ny, nz = shape
+    e = eng.Tau3D(nx, ny, nz)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(warm)
+    state = e.download()
+    r = refgpu.Ref3D(nx, ny, nz)
+    r.upload(state)
+    want = r.schlieren().astype(np.float64)
+    got = e.vis(0).astype(np.float64)
+    fluid = r.solid_mask() == 0
+    assert (got[~fluid] == 0).all() and (want[~fluid] == 0).all()
+    rho = np.exp(state[0].astype(np.float64))
+    scale = np.maximum(rho.max() / (2.0 / max(nx, ny, nz)), 1e-30)      # (q+ - q-) / (2 dx) of values that agree to rounding: eps (|q+| + |q-|) / (2 dx)
+    err = np.abs(got - want)[fluid].max() / scale
+    print("schlieren vs k_schlieren_export", shape, "max err / scale %.2e" % err, "max field %.3g" % want.max())
+    assert err <= 2e-6 and want.max() > 0
+    e.close()
+    r.close()
