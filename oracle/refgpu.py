@@ -541,3 +541,76 @@ class RefLbm:
     def close(self):
         for b in (self.f0, self.f1, self.solid):
             b.free()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Burgers / shallow water: the convective part of tau_burgers.cu:677-708 and tau_shallow_water.cu:671-700 (the in-place viscosity
+# kernels that follow race — SURVEY §2.1 — and are left out: compare with nu = 0)
+# ------------------------------------------------------------------------------------------------------------------
+class RefFlow:
+    BS = (16, 16)
+
+    def __init__(self, kind, nx, ny, dx, dy, u0=1.0, g=9.81, CFL=0.5, muscl=0, oneD=0, fast=False):
+        self.kind = kind
+        self.m = RefModule({"burgers": "tau_burgers", "sw": "tau_shallow_water"}[kind] + ("" if fast else ".ieee"))
+        self.nx, self.ny, self.dx, self.dy = nx, ny, np.float32(dx), np.float32(dy)
+        self.u0, self.g, self.CFL, self.muscl, self.oneD = np.float32(u0), np.float32(g), np.float32(CFL), int(muscl), int(oneD)
+        n = nx * ny
+        self.nf = 2 if kind == "burgers" else 3
+        self.f = [DevBuf(4 * n) for _ in range(self.nf)]
+        self.flux = [DevBuf(4 * n) for _ in range(2 * self.nf)]
+        self.gs = ((nx + 15) // 16, (ny + 15) // 16)
+        self.blk = DevBuf(4 * self.gs[0] * self.gs[1])
+
+    def upload(self, fields):
+        for b, a in zip(self.f, fields):
+            b.put(np.asarray(a, np.float32))
+
+    def download(self):
+        return [b.get(np.float32, (self.ny, self.nx)) for b in self.f]
+
+    def dt_eff(self, t, dtau):
+        """the CFL part of do_step: wavespeed_block_max + the host max (tau_burgers.cu:678-692 / tau_shallow_water.cu:672-688)"""
+        f = np.float32
+        i32, f32 = C.c_int, C.c_float
+        shm = 16 * 16 * 4
+        if self.kind == "burgers":
+            self.m.launch("wavespeed_block_max", self.gs, self.BS,
+                          [_p(self.f[0]), _p(self.f[1]), f32(self.u0), i32(self.nx), i32(self.ny), f32(f(1.0) / self.dx),
+                           f32((f(1.0) / self.dy) if self.ny > 1 else 0.0), _p(self.blk)], shmem=shm)
+        else:
+            self.m.launch("wavespeed_block_max", self.gs, self.BS,
+                          [_p(self.f[0]), _p(self.f[1]), _p(self.f[2]), f32(self.g), i32(self.nx), i32(self.ny), _p(self.blk)], shmem=shm)
+        self.m.sync()
+        blk = self.blk.get(np.float32, (self.gs[0] * self.gs[1],))
+        if self.kind == "burgers":
+            smax = max(f(1e-12), blk.max())
+            dt_cfl = f(self.CFL / smax)
+        else:
+            cmax = max(blk.max(), f(1e-12))
+            dt_cfl = f(f(self.CFL * min(self.dx, self.dy)) / cmax)
+        return float(min(f(f(t) * f(dtau)), dt_cfl))
+
+    def convect(self, dt):
+        i32, f32 = C.c_int, C.c_float
+        nx, ny = self.nx, self.ny
+        if self.kind == "burgers":
+            pu, pv = self.f
+            Fu, Fv, Gu, Gv = self.flux
+            self.m.launch("flux_x_kernel", self.gs, self.BS, [_p(pu), _p(pv), _p(Fu), _p(Fv), i32(nx), i32(ny), f32(self.u0), i32(self.muscl)])
+            if not self.oneD:
+                self.m.launch("flux_y_kernel", self.gs, self.BS, [_p(pu), _p(pv), _p(Gu), _p(Gv), i32(nx), i32(ny), f32(self.u0), i32(self.muscl)])
+            self.m.launch("update_convective", self.gs, self.BS, [_p(pu), _p(pv), _p(Fu), _p(Fv), _p(Gu), _p(Gv), i32(nx), i32(ny), f32(self.dx),
+                                                                  f32(self.dy), f32(dt), f32(self.u0), i32(self.oneD)])
+        else:
+            sg, u, v = self.f
+            Fh, Fmx, Fmy, Gh, Gmx, Gmy = self.flux
+            self.m.launch("flux_x_kernel", self.gs, self.BS, [_p(sg), _p(u), _p(v), _p(Fh), _p(Fmx), _p(Fmy), i32(nx), i32(ny), f32(self.g)])
+            self.m.launch("flux_y_kernel", self.gs, self.BS, [_p(sg), _p(u), _p(v), _p(Gh), _p(Gmx), _p(Gmy), i32(nx), i32(ny), f32(self.g)])
+            self.m.launch("update_kernel", self.gs, self.BS, [_p(sg), _p(u), _p(v), _p(Fh), _p(Fmx), _p(Fmy), _p(Gh), _p(Gmx), _p(Gmy), i32(nx), i32(ny),
+                                                              f32(self.dx), f32(self.dy), f32(dt), f32(self.g)])
+        self.m.sync()
+
+    def close(self):
+        for b in self.f + self.flux + [self.blk]:
+            b.free()
