@@ -491,6 +491,34 @@ class RefH2:
         self.m.sync()
         return step_dt, maxs
 
+    def render(self, view_mode):
+        """the frame tail of tau_hypersonic_cuda.cu:1892-1921: k_render_vals (+ per-block min / max) -> k_reduce_minmax rounds ->
+        k_compute_inv_range -> k_render_pixels.  Returns (pixels (H, W, 4) u8, values (H, W) f64, min, max)."""
+        N, thr = self.N, self.threads
+        shm = thr * 2 * 8
+        tmp, px = DevBuf(8 * N), DevBuf(4 * N)
+        bmin, bmax, rmin, rmax = (DevBuf(8 * self.blocksN) for _ in range(4))
+        inv = DevBuf(8)
+        self.m.launch("k_render_vals", (self.blocksN,), (thr,), [self.U, _p(self.mask), C.c_int(view_mode), _p(tmp), _p(bmin), _p(bmax)], shmem=shm)
+        cur_min, cur_max, out_min, out_max = bmin, bmax, rmin, rmax
+        cur_n = self.blocksN
+        while cur_n > 1:
+            out_n = (cur_n + 2 * thr - 1) // (2 * thr)
+            self.m.launch("k_reduce_minmax", (out_n,), (thr,), [_p(cur_min), _p(cur_max), _p(out_min), _p(out_max), C.c_int(cur_n)], shmem=shm)
+            cur_n = out_n
+            nxt_min, nxt_max = out_min, out_max
+            out_min = rmin if nxt_min is bmin else bmin
+            out_max = rmax if nxt_max is bmax else bmax
+            cur_min, cur_max = nxt_min, nxt_max
+        self.m.launch("k_compute_inv_range", (1,), (1,), [_p(cur_min), _p(cur_max), _p(inv)])
+        self.m.launch("k_render_pixels", (self.blocksN,), (thr,), [_p(self.mask), _p(tmp), _p(cur_min), _p(inv), _p(px)])
+        self.m.sync()
+        out = (px.get(np.uint8, (self.H, self.W, 4)), tmp.get(np.float64, (self.H, self.W)),
+               float(cur_min.get(np.float64, (1,))[0]), float(cur_max.get(np.float64, (1,))[0]))
+        for b in (tmp, px, bmin, bmax, rmin, rmax, inv):
+            b.free()
+        return out
+
     def close(self):
         for bufs in [self.Ub, self.Tb, self.xflux[0], self.yflux[0]] + [f[0] for f in self.faces]:
             for b in bufs:

@@ -87,6 +87,50 @@ def test_tauh2_init_and_steps_vs_reference_kernels(eng, refgpu):
     r.close()
 
 
+def test_tauh2_render_vs_reference_kernels(eng, refgpu):
+    """the seven view modes and the colour ramp: k_render_vals / k_reduce_minmax / k_compute_inv_range /
+    k_render_pixels of the reference (fp64, 8192 x 1024) against tauh2_render on the same developed state.  Tolerances as in
+    tests/test_gpu_vis.py: the three modes that show p = (g-1)(E - rho q^2/2) carry kappa = E / e_int in fp32."""
+    TOL = 1e-5
+    r = refgpu.RefH2()
+    W, H = r.W, r.H
+    r.init()
+    e = eng.Hypersonic2D(W, H)
+    e.init()
+    e.step(40)
+    state, mask = e.download(with_mask=True)
+    st = [a.astype(np.float64) for a in state]
+    r.upload(st)
+    fluid = mask == 0
+    rho, mx, my, E = st
+    kin = 0.5 * (mx * mx + my * my) / rho
+    kappa = E / np.maximum(E - kin, 1e-25)
+    U = np.sqrt(mx * mx + my * my)[fluid].max() / rho[fluid].min()
+    for mode in range(7):
+        px, val, mn, mxv = e.render(mode)
+        wpx, want, mn_w, mx_w = r.render(mode)
+        err = np.abs(val.astype(np.float64) - want)
+        if mode in (1, 5, 6):
+            tol = TOL * kappa * np.maximum(1.0, np.abs(want))
+        elif mode == 4:
+            tol = 0.1 * TOL * 2 * U / np.sqrt(1 + np.sinh(want) ** 2) + 1e-6
+        else:
+            tol = TOL * np.maximum(1.0, np.abs(want))
+        worst = float((err / tol)[fluid].max())
+        dpx = np.abs(px.astype(np.int16) - wpx.astype(np.int16))
+        print("render mode", mode, e.VIEW_MODES[mode], "reference range [%.5g, %.5g] engine [%.5g, %.5g]" % (mn_w, mx_w, mn, mxv),
+              "worst err/tol %.3f" % worst, "pixels off by > 1:", int((dpx > 1).any(axis=-1).sum()))
+        assert worst <= 1.0, (mode, worst)
+        assert mn == pytest.approx(mn_w, rel=1e-4, abs=1e-6) and mxv == pytest.approx(mx_w, rel=1e-4, abs=1e-6)
+        assert (px[~fluid] == wpx[~fluid]).all()                      # the body's grey
+        # the ramp maps (val - min) / range to 0..255: a value error of `tol` moves a channel by 255 tol / range (+ 1 for the fp32 ramp)
+        span = max(mx_w - mn_w, 1e-30)
+        allow = np.ceil(255.0 * 3.0 * tol / span) + 1
+        assert (dpx.max(axis=-1)[fluid] <= allow[fluid]).all()
+    e.close()
+    r.close()
+
+
 # ---------------------------------------------------------------------------------------------------- SPH
 @pytest.mark.parametrize("N,warm,kw", [(4096, 0, {}), (4096, 40, {}), (16384, 120, {}), (65536, 200, {}), (16384, 80, dict(useVisc=0)),
                                        (4194304, 0, {}), (4194304, 30, {})])
