@@ -482,36 +482,43 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   const bool left = (sM >= 0.f);
   const float sK = left ? sL : sR, unK = left ? unL : unR, rK = left ? rL : rR, pK = left ? pL : pR;
   const float iden = rcp(denom_guard(sK - sM));
-  const float fac = (sK - unK) * iden;
-  const float rStar = rK * fac;
-  Cons US;
-  US.c[0] = rStar;
+  // The star state enters the flux only through dU = U* - U_K (:441-459: F_K + s_K (U* - U_K)).  The reference forms U* and
+  // subtracts; here the DIFFERENCE is formed directly —
+  //     rho* - rho_K = rho_K (s_M - un_K) / (s_K - s_M),     (rho un)* - (rho un)_K = s_K (rho* - rho_K),
+  //     E* - E_K = ((s_M - un_K) E_K - p_K un_K + p* s_M) / (s_K - s_M),      Ev* - Ev_K = Ev_K (s_M - un_K) / (s_K - s_M)
+  // — the same numbers to rounding wherever U* - U_K is well conditioned, and finite where it is not: a WENO state whose
+  // density undershoots below zero is floored at 1e-30 (prim_floor), its sound speed is ~1e15, and s_K (E* - E_K) becomes
+  // 1e15 times the rounding error of E* = ((s_K - un_K) E_K ...) / (s_K - s_M).  The reference survives such a face only when
+  // its IEEE division happens to return (s_K E_K) / s_K = E_K exactly; a reciprocal-multiply never does, and the energy flux
+  // came out at +-1e7 (found by scripts/fuzz_ref3d.py on thin anisotropic grids; round 4).
+  const float g = (sM - unK) * iden;
+  const float dR = rK * g;
+  Cons dU;
+  dU.c[0] = dR;
   const float uK = left ? L.q[IU] : R.q[IU], vK = left ? L.q[IV] : R.q[IV], wK = left ? L.q[IW] : R.q[IW];
-  US.c[1] = rStar * ((axis == 0) ? sM : uK);   // fill_star_momentum, :335-350
-  US.c[2] = rStar * ((axis == 1) ? sM : vK);
-  US.c[3] = rStar * ((axis == 2) ? sM : wK);
+  dU.c[1] = dR * ((axis == 0) ? sK : uK);   // fill_star_momentum, :335-350, as a difference
+  dU.c[2] = dR * ((axis == 1) ? sK : vK);
+  dU.c[3] = dR * ((axis == 2) ? sK : wK);
   const float EK = left ? UL.c[4] : UR.c[4], EvK = left ? UL.c[5] : UR.c[5];
-  US.c[4] = ((sK - unK) * EK - pK * unK + pStar * sM) * iden;
-  US.c[5] = EvK * fac;
-  // The blend  F = (1 - alpha) [F_K + s_K (U* - U_K)] + alpha [s_R F_L - s_L F_R + s_L s_R (U_R - U_L)] / (s_R - s_L)  (:441-459)
-  // as ONE linear combination of F_L, F_R, U*, U_R, U_L: five coefficients picked once (four selects) instead of picking
-  // U_K and F_K per component (twelve half-rate selects and ten operations per component against five).
+  dU.c[4] = ((sM - unK) * EK - pK * unK + pStar * sM) * iden;
+  dU.c[5] = EvK * g;
+  // The blend  F = (1 - alpha) [F_K + s_K dU] + alpha [s_R F_L - s_L F_R + s_L s_R (U_R - U_L)] / (s_R - s_L)  (:441-459)
+  // as ONE linear combination of F_L, F_R, dU and U_R - U_L: the coefficients are picked once (two selects) instead of picking
+  // F_K per component.
   const float wC = 1.f - alpha, wH = alpha * ihll;
   const float aS = wC * sK, cU = wH * sLR;
-  const float lw = left ? wC : 0.f, la = left ? aS : 0.f;
+  const float lw = left ? wC : 0.f;
   const float cFL = wH * sR + lw, cFR = (wC - lw) - wH * sL;
-  const float cUR = cU - (aS - la), cUL = -(cU + la);
-  // explicit fma chain: left to contraction, the five-term sum was fused differently in two inlined copies of this function
-  // (the chunk prologue and the marching loop of the fused kernel), and a Z-slab run — whose chunks start elsewhere — was no
-  // longer bit-identical to the single domain
+  // explicit fma chain: left to contraction, the sum was fused differently in two inlined copies of this function (the chunk
+  // prologue and the marching loop of the fused kernel), and a Z-slab run — whose chunks start elsewhere — was no longer
+  // bit-identical to the single domain
   Cons F;
 #pragma unroll
   for (int k = 0; k < 6; k++) {
     float f = cFL * FL.c[k];
     f = __builtin_fmaf(cFR, FR.c[k], f);
-    f = __builtin_fmaf(aS, US.c[k], f);
-    f = __builtin_fmaf(cUR, UR.c[k], f);
-    F.c[k] = __builtin_fmaf(cUL, UL.c[k], f);
+    f = __builtin_fmaf(aS, dU.c[k], f);
+    F.c[k] = __builtin_fmaf(cU, UR.c[k] - UL.c[k], f);
   }
   return F;
 }

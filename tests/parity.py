@@ -107,3 +107,42 @@ def cells_beyond(got, want, mask=None, tol=TOL_CONS):
         bad |= ~(d <= tol)
         worst = max(worst, float(np.nanmax(d)))
     return int(bad.sum()), worst
+
+
+def _weno5_left(v0, v1, v2, v3, v4):
+    """the reference's weno5_left (tau_hypersonic_3d_cuda.cu:534-558), fp64, vectorised"""
+    p0 = (2 * v0 - 7 * v1 + 11 * v2) / 6
+    p1 = (-v1 + 5 * v2 + 2 * v3) / 6
+    p2 = (2 * v2 + 5 * v3 - v4) / 6
+    b0 = 13 / 12 * (v0 - 2 * v1 + v2) ** 2 + 0.25 * (v0 - 4 * v1 + 3 * v2) ** 2
+    b1 = 13 / 12 * (v1 - 2 * v2 + v3) ** 2 + 0.25 * (v1 - v3) ** 2
+    b2 = 13 / 12 * (v2 - 2 * v3 + v4) ** 2 + 0.25 * (3 * v2 - 4 * v3 + v4) ** 2
+    a0, a1, a2 = 0.1 / (1e-6 + b0) ** 2, 0.6 / (1e-6 + b1) ** 2, 0.3 / (1e-6 + b2) ** 2
+    return (a0 * p0 + a1 * p1 + a2 * p2) / (a0 + a1 + a2)
+
+
+def undershoot_cells(st, solid=None):
+    """Cells next to a face where the scheme's own WENO5 reconstruction of rho or p undershoots to <= 0 (so that prim_floor puts it at
+    1e-30).  There the reference's HLLC runs with a sound speed of ~1e15 and its energy flux is 1e15 times the rounding error of
+    E* - E_K: the result is finite only when the IEEE division (s_K E_K) / s_K happens to be exact, and s_M is the ratio of two
+    numbers below the 1e-12 denominator guard — a 1-ulp asymmetry of the two pressures moves it by 1e4.  Two builds of the
+    REFERENCE disagree there by orders of magnitude; such cells carry no parity information in either direction.
+    Faces whose six-cell stencil holds a solid cell (the scheme overrides WENO there, :1125-1143) and x faces within three cells of
+    the inflow / outflow boundary (ghost states, not the periodic wrap) are not examined."""
+    r, u, v, w, p, ev = decode(st)
+    flag = np.zeros(r.shape, bool)
+    sol = np.zeros(r.shape, bool) if solid is None else (np.asarray(solid) != 0)
+    nx = r.shape[2]
+    for q in (r, p):
+        for ax in range(3):
+            s = [np.roll(q, -k, axis=ax) for k in range(-2, 4)]     # s[j] = q[i + j - 2], the face between cells i | i+1
+            L = _weno5_left(s[0], s[1], s[2], s[3], s[4])
+            R = _weno5_left(s[5], s[4], s[3], s[2], s[1])
+            bad = (L <= 0) | (R <= 0)
+            for k in range(-2, 4):
+                bad &= ~np.roll(sol, -k, axis=ax)
+            if ax == 2:
+                bad[:, :, :2] = False
+                bad[:, :, nx - 3:] = False
+            flag |= bad | np.roll(bad, 1, axis=ax)
+    return flag

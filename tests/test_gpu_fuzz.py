@@ -29,3 +29,15 @@ def test_split_3d_step_on_random_shapes():
                        text=True, cwd=ROOT, env=dict(os.environ, TAU3D_SPLIT="1"))
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "0 failures" in r.stdout
+
+
+def test_3d_step_on_random_shapes_vs_the_reference_kernel():
+    """a short slice of scripts/fuzz_ref3d.py: ragged shapes, fused / split step, fast / FORCED reciprocal WENO weights, against the
+    reference's own k_step running on the same GPU (oracle/_ref/th3cs.co)"""
+    import subprocess
+    import sys
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "th3cs.co")):
+        pytest.skip("oracle/_ref/th3cs.co absent: oracle/build_ref.sh has not run (needs /root/reference)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_ref3d.py"), "11", "25"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1500:]
+    assert "0 failures" in r.stdout and "split/rcp" in r.stdout and "split/fast" in r.stdout

@@ -139,8 +139,10 @@ def test_reference_kernel_trajectory_reproduces_the_recorded_checkvalues(eng, re
     r.close()
 
 
-# Neither 512^3 input of SURVEY §8(d) lives for ever — in the reference's own kernel exactly as in the engine (compared step by
-# step here; lifetimes from scripts/long_run_512.py, profiles/r04/long_run_512.txt).  The impulsive start (bench.py's headline
+# Neither 512^3 input of SURVEY §8(d) lives for ever — in the reference's own kernel exactly as in the engine: the reference's
+# k_step under its own controller from the same impulsive start follows the engine's clock and max wavespeed to six digits for 60
+# steps and overflows at step 65 (scripts/long_run_512_ref.py, profiles/r04/long_run_512_impulsive_reference_vs_engine.txt); the
+# engine's lifetimes of both inputs: scripts/long_run_512.py, profiles/r04/long_run_512_*.txt.  The impulsive start (bench.py's headline
 # input, timed over steps 25..45) runs away on the near-vacuum lee side of the sphere from step ~55 on (|primitive| 4e11 at step
 # 60, max wavespeed 3.4e38 and infinite velocities by step 70, d_tau pinned at its 1e-7 floor).  The reference's own ramped start
 # reaches gain 0.9 (t = 0.018) after ~3000 steps with |primitive| <= 660 and goes the same way before step 3250.  So the late,
