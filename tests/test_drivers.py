@@ -161,7 +161,8 @@ def test_burgers_and_sw_end_to_end(built):
     m = re.search(r"relative L2 error at elapsed t=\S+: (\S+)", r.stdout)
     assert float(m.group(1)) < 6e-5
     r = run(os.path.join(built, "tau_sw"), "--headless", "--nx", "256", "--ny", "256", "--steps", "50", "--dtau", "0.01")
-    assert r.returncode == 0 and "Headless (stride=5):" in r.stdout and "Steps: 50" in r.stdout, r.stdout + r.stderr
+    # the reference's own summary lines (tau_shallow_water.cu:774-780)
+    assert r.returncode == 0 and "Headless benchmark (stride=5):" in r.stdout and "Simulated steps: 50" in r.stdout, r.stdout + r.stderr
 
 
 def read_ppm(path):
