@@ -41,3 +41,15 @@ def test_3d_step_on_random_shapes_vs_the_reference_kernel():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_ref3d.py"), "11", "25"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1500:]
     assert "0 failures" in r.stdout and "split/rcp" in r.stdout and "split/fast" in r.stdout
+
+
+def test_2d_simulators_on_random_cases_vs_the_reference_kernels():
+    """a short slice of scripts/fuzz_ref2d.py: Gray-Scott and LBM on random ragged grids / parameters (bit-exact), SPH with random
+    particle counts and parameters, 2D Euler with random SimConfig values at 8192 x 1024 — against the reference's own kernels"""
+    import subprocess
+    import sys
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "tau_sph.co")):
+        pytest.skip("oracle/_ref absent: oracle/build_ref.sh has not run (needs /root/reference)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_ref2d.py"), "13", "40"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2500:] + r.stderr[-1500:]
+    assert "0 failures" in r.stdout
