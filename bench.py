@@ -324,7 +324,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (libtaueng has no CPU path)")
     ndev = torch.cuda.device_count()
-    shared = args.ring_transport in ("host", "ipc-host")
+    # TAU_BENCH_AUTO_SHARED=1 (tests on a one-GPU box): `auto` probes ipc-host against host instead of ipc against rccl — the same
+    # build / time / close / rebuild sequence with ranks that share the device
+    auto_shared = args.ring_transport == "auto" and bool(os.environ.get("TAU_BENCH_AUTO_SHARED"))
+    shared = args.ring_transport in ("host", "ipc-host") or auto_shared
     if ndev < world and not shared:
         if ndev == 1 and os.environ.get("TAU_BENCH_ONE_VISIBLE_DEVICE_PER_RANK"):
             local = 0    # a launcher that shows every rank exactly its own device; the library compares device identities across ranks
@@ -449,7 +452,7 @@ def main():
         if world == 1:
             cands = [f.RING_IPC if want == "ipc" else (f.RING_RCCL if args.self_p2p else f.RING_LOCAL)]
         elif want == "auto":
-            cands = [f.RING_IPC, f.RING_RCCL]
+            cands = [f.RING_IPC_HOSTMAX, f.RING_HOST] if auto_shared else [f.RING_IPC, f.RING_RCCL]
         else:
             cands = [{"rccl": f.RING_RCCL, "ipc": f.RING_IPC, "host": f.RING_HOST, "ipc-host": f.RING_IPC_HOSTMAX}[want]]
         probes = {}

@@ -186,6 +186,23 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(eng, transport, word):
     assert word in j["ring"]["transport"]
 
 
+def test_bench_auto_transport_probe_on_one_gpu(eng):
+    """`bench.py --gpus 2` with the default --ring-transport auto: both candidate transports are built, timed over a few warm-up
+    steps and closed again, the faster one is rebuilt for the timed region.  On this one-GPU box the candidates are the two that let
+    ranks share a device (TAU_BENCH_AUTO_SHARED: ipc-host against host; with a device per rank: ipc against rccl)."""
+    import json
+    import sys
+    env = dict(os.environ, TAU_BENCH_AUTO_SHARED="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TAU3D_RING_TIMEOUT="60")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    probes = j["ring"]["auto_probe_ms_per_step"]
+    assert j["n_gpus"] == 2 and len(probes) == 2 and all(isinstance(v, float) and v > 0 for v in probes.values()), probes
+    fastest = min(probes, key=probes.get)
+    assert j["ring"]["transport"] == fastest
+
+
 def test_ring_refuses_a_zero_job_key_and_reports_a_failed_peer(eng, tmp_path):
     """world > 1 needs a non-zero job key (it tells this job's rendezvous file from a stale one); and a rank that finds the file
     of a job whose rank 0 has already given up learns so from the status word at once instead of waiting out a timeout"""
