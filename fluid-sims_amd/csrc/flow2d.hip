@@ -324,7 +324,7 @@ __device__ __forceinline__ void march_face(const Args &A, const MRow &L, const M
 }
 
 template <int KIND>
-__global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstrips, int nchunks) {
+__global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstrips, int nchunks, const int *__restrict__ crow) {
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(nstrips * nchunks);
   const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -345,7 +345,8 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
   const int xo = strip * MCOLS + lane - 2;                       // column of this lane, before the periodic wrap
   const int col = ((xo % A.nx) + A.nx) % A.nx;
   const bool own = lane >= 2 && lane < 2 + MCOLS && xo < A.nx;   // the lanes that store
-  const int j0 = chunk * rows, j1 = min(j0 + rows, A.ny);
+  const int j0 = crow ? crow[chunk] : chunk * rows, j1 = crow ? crow[chunk + 1] : min(j0 + rows, A.ny);   // (tau::guided_chunks, or `rows` each)
+  if (j0 >= j1) return;
   const bool oneD = (KIND == K_BURGERS) && A.oneD;
   const float invdy = oneD ? 0.0f : A.invdy;
   const float invdy2 = oneD ? 0.0f : A.invdy2;
@@ -428,7 +429,7 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
 // cross lanes: half the lane shifts per cell, two independent cells of work per lane, float2 loads and stores.
 constexpr int MCOLS2 = 124;
 template <int KIND>
-__global__ __launch_bounds__(256) void k_march2(const Args A, int rows, int nstrips, int nchunks) {
+__global__ __launch_bounds__(256) void k_march2(const Args A, int rows, int nstrips, int nchunks, const int *__restrict__ crow) {
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(nstrips * nchunks);
   const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -448,7 +449,8 @@ __global__ __launch_bounds__(256) void k_march2(const Args A, int rows, int nstr
   const int xo = strip * MCOLS2 + 2 * lane - 2;                  // first of this lane's two columns (even)
   const int col = ((xo % A.nx) + A.nx) % A.nx;                   // nx is even: the pair never straddles the wrap
   const bool own = lane >= 1 && lane < 63 && xo < A.nx;
-  const int j0 = chunk * rows, j1 = min(j0 + rows, A.ny);
+  const int j0 = crow ? crow[chunk] : chunk * rows, j1 = crow ? crow[chunk + 1] : min(j0 + rows, A.ny);   // (tau::guided_chunks, or `rows` each)
+  if (j0 >= j1) return;
   const bool oneD = (KIND == K_BURGERS) && A.oneD;
   const float invdy = oneD ? 0.0f : A.invdy, invdy2 = oneD ? 0.0f : A.invdy2;
   const float nudt = A.nu * (dt * A.visc_frac);
@@ -552,7 +554,7 @@ __global__ __launch_bounds__(256) void k_march2(const Args A, int rows, int nstr
 // decodes the two face states (four sinh per face), so phi is carried raw: a four-row window for the y faces
 // (face a-2 | a-1 needs rows a-3 .. a), lanes l-2 .. l+1 for the x faces, three halo lanes a side (own 58 columns).
 constexpr int MCOLS_M = 58;
-__global__ __launch_bounds__(256) void k_march_muscl(const Args A, int rows, int nstrips, int nchunks) {
+__global__ __launch_bounds__(256) void k_march_muscl(const Args A, int rows, int nstrips, int nchunks, const int *__restrict__ crow) {
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(nstrips * nchunks);
   const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -572,7 +574,8 @@ __global__ __launch_bounds__(256) void k_march_muscl(const Args A, int rows, int
   const int xo = strip * MCOLS_M + lane - 3;
   const int col = ((xo % A.nx) + A.nx) % A.nx;
   const bool own = lane >= 3 && lane < 3 + MCOLS_M && xo < A.nx;
-  const int j0 = chunk * rows, j1 = min(j0 + rows, A.ny);
+  const int j0 = crow ? crow[chunk] : chunk * rows, j1 = crow ? crow[chunk + 1] : min(j0 + rows, A.ny);   // (tau::guided_chunks, or `rows` each)
+  if (j0 >= j1) return;
   const bool oneD = A.oneD != 0;
   const float invdy = oneD ? 0.0f : A.invdy, invdy2 = oneD ? 0.0f : A.invdy2;
   const float nudt = A.nu * (dt * A.visc_frac);
@@ -675,6 +678,8 @@ struct tauflow {
   float t, tau;
   long step;
   taulap_t *visc;   // Burgers: extra viscosity passes (K > 1) through the marching kernel
+  int *crow = nullptr;   // chunk schedule of the march (flow_schedule)
+  int crow_n = 0;
 };
 
 extern "C" void tauflow_params_default(tauflow_params *P, int kind, int nx, int ny) {
@@ -720,7 +725,7 @@ extern "C" void tauflow_destroy(tauflow_t *h) {
   hipStreamSynchronize(h->stream);
   for (int s = 0; s < 2; s++)
     for (int f = 0; f < h->nf; f++) hipFree(h->buf[s][f]);
-  hipFree(h->st);
+  hipFree(h->st); hipFree(h->crow);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -812,6 +817,22 @@ static void flow_args(tauflow *h, fl2::Args &A, float dt_explicit) {
   A.reduce = (K == 1);
 }
 
+// chunk schedule of the marches: tau::guided_chunks over the wave slots the kernel really gets, 12..64 rows.  Against chunks of
+// one length (round 4, Gcell/s): 8192^2 shallow water 162 -> 178, Burgers 243 -> 260, --muscl 111 -> 113; 4096^2 / 2048^2 level
+// (shorter minimum chunks lose there: 8 rows 141 -> 135 at 4096^2).  TAU_FLOW_GUIDED=0 / TAU_FLOW_ROWS=n: uniform chunks.
+static int flow_schedule(tauflow *h, const void *fn, int nstrips, int *nchunks, const int **crow) {
+  static const bool guided = !(getenv("TAU_FLOW_GUIDED") && atoi(getenv("TAU_FLOW_GUIDED")) == 0);
+  if (!guided) return 0;
+  if (!h->crow) {
+    int per_cu = 0;
+    TAU_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0));
+    static const int gmin = getenv("TAU_FLOW_GMIN") ? atoi(getenv("TAU_FLOW_GMIN")) : 12;
+    static const int gmax = getenv("TAU_FLOW_GMAX") ? atoi(getenv("TAU_FLOW_GMAX")) : 64;
+    if (tau::guided_chunks(h->p.ny, nstrips, (per_cu > 0 ? per_cu : 2) * 4 * 32, gmin, gmax, &h->crow, &h->crow_n)) return 1;
+  }
+  *nchunks = h->crow_n; *crow = h->crow;
+  return 0;
+}
 static int flow_step_once(tauflow *h, float dt_explicit) {
   fl2::Args A;
   flow_args(h, A, dt_explicit);
@@ -836,12 +857,16 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
     rows = rows < 8 ? 8 : (rows > 48 ? 48 : rows);                 // rows 184 Gcell/s, 16: 175, 64: 179, 128: 154)
     static const int rows_env = [] { const char *e = getenv("TAU_FLOW_ROWS"); return e ? atoi(e) : 0; }();
     if (rows_env >= 1) rows = rows_env;
-    const int nchunks = (P.ny + rows - 1) / rows;
+    int nchunks = (P.ny + rows - 1) / rows;
+    const int *crow = nullptr;
+    const void *fn = pair ? (h->kind == 0 ? (const void *)fl2::k_march2<fl2::K_BURGERS> : (const void *)fl2::k_march2<fl2::K_SW>)
+                          : (h->kind == 0 ? (const void *)fl2::k_march<fl2::K_BURGERS> : (const void *)fl2::k_march<fl2::K_SW>);
+    if (rows_env < 1 && flow_schedule(h, fn, nstrips, &nchunks, &crow)) return 1;
     const unsigned nwg = (unsigned)((nstrips * nchunks + 3) / 4);
-    if (pair && h->kind == 0) hipLaunchKernelGGL(fl2::k_march2<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
-    else if (pair) hipLaunchKernelGGL(fl2::k_march2<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
-    else if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
-    else hipLaunchKernelGGL(fl2::k_march<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    if (pair && h->kind == 0) hipLaunchKernelGGL(fl2::k_march2<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    else if (pair) hipLaunchKernelGGL(fl2::k_march2<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    else if (h->kind == 0) hipLaunchKernelGGL(fl2::k_march<fl2::K_BURGERS>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    else hipLaunchKernelGGL(fl2::k_march<fl2::K_SW>, dim3(nwg), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
   }
   else if (use_march && h->kind == 0 && A.muscl && P.nx >= 8 && P.ny >= 4 && (use_march > 1 || (long)P.nx * P.ny >= (1L << 21))) {
     const int nstrips = (P.nx + fl2::MCOLS_M - 1) / fl2::MCOLS_M;
@@ -849,8 +874,10 @@ static int flow_step_once(tauflow *h, float dt_explicit) {
     rows = rows < 8 ? 8 : (rows > 48 ? 48 : rows);
     static const int rows_env = [] { const char *e = getenv("TAU_FLOW_ROWS"); return e ? atoi(e) : 0; }();
     if (rows_env >= 1) rows = rows_env;
-    const int nchunks = (P.ny + rows - 1) / rows;
-    hipLaunchKernelGGL(fl2::k_march_muscl, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
+    int nchunks = (P.ny + rows - 1) / rows;
+    const int *crow = nullptr;
+    if (rows_env < 1 && flow_schedule(h, (const void *)fl2::k_march_muscl, nstrips, &nchunks, &crow)) return 1;
+    hipLaunchKernelGGL(fl2::k_march_muscl, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
   }
   else if (h->kind == 0 && A.muscl) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, true>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);
   else if (h->kind == 0) hipLaunchKernelGGL((fl2::k_step<fl2::K_BURGERS, false>), dim3(nb), dim3(fl2::NT), 0, h->stream, A);

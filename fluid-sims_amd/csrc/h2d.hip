@@ -1094,35 +1094,13 @@ extern "C" int tauh2_init(tauh2_t *h) { // k_init, :740-770 (geometry on the hos
   return 0;
 }
 
-// Chunk schedule of the LDS-window march.  The work list is chunk-major and an XCD walks a contiguous eighth of it in dispatch
-// order (tau::xcd_swizzle), i.e. a band of H / 8 rows on its 512 resident wave slots.  Chunks of one length leave the chip
-// draining for the duration of a chunk at the end of the launch (4096^2 in 16-row chunks: 4.3 rounds of the resident waves, 3.2
-// of 4 waves resident on average).  Guided schedule instead: a chunk is as long as the band's REMAINING rows x strips shared out
-// over the 512 slots (at most 56 rows: the 32-bit band offsets; at least 6: a chunk re-does 4 warm-up rows), so the first waves
-// are long and cheap in warm-up and the last ones short.  Measured against the uniform chunks (round 4): 4096^2 54.4 -> 58.8,
-// 8192^2 61.6 -> 64.8, 8192x1024 51.4 -> 53.8, 2048^2 41.0 -> 45.7, 3000^2 49.9 -> 54.8 Gcell/s.  Results are unchanged (a
-// row's arithmetic does not depend on the chunk it is in; the maximum is order-free).  TAU_H2_ROWS=n: uniform chunks of n rows.
+// Chunk schedule of the LDS-window march: tau::guided_chunks over the 512 wave slots of an XCD (120 VGPRs: four waves per
+// SIMD), 6 to 56 rows (a chunk re-does 4 warm-up rows; the band's 32-bit row offsets).  Chunks of one length (4096^2 in 16-row
+// chunks: 4.3 rounds of the resident waves, 3.2 of 4 waves resident on average) against this schedule, round 4: 4096^2 54.4 ->
+// 58.8, 8192^2 61.6 -> 64.8, 8192x1024 51.4 -> 53.8, 2048^2 41.0 -> 45.7, 3000^2 49.9 -> 54.8 Gcell/s.  Results are unchanged
+// (a row's arithmetic does not depend on the chunk it is in; the maximum is order-free).  TAU_H2_ROWS=n: uniform chunks.
 static int h2_schedule(tauh2 *h, int *nchunks, const int **crow) {
-  if (h->crow) { *nchunks = h->crow_n; *crow = h->crow; return 0; }
-  const int H = h->p.H, nstrips = (h->p.W + h2d::MCOLS - 1) / h2d::MCOLS;
-  const int hb = (H + 7) / 8, lmin = 6, lmax = 56;
-  std::vector<int> pat;                                   // chunk lengths of one band, descending
-  for (int R = hb; R > 0;) {
-    int len = (int)((double)R * nstrips / 512.0 + 0.5);
-    len = len < lmin ? lmin : (len > lmax ? lmax : len);
-    if (R - len < lmin / 2) len = R;
-    pat.push_back(len); R -= len;
-  }
-  std::vector<int> start;                                 // every band gets the same number of chunks (clipped to the band)
-  for (int b = 0; b < 8; b++) {
-    const int lo = (int)((long)H * b / 8), hi = (int)((long)H * (b + 1) / 8);
-    int r = lo;
-    for (size_t c = 0; c < pat.size(); c++) { start.push_back(r < hi ? r : hi); r += pat[c]; }
-  }
-  start.push_back(H);
-  TAU_HIP(hipMalloc(&h->crow, start.size() * sizeof(int)));
-  TAU_HIP(hipMemcpy(h->crow, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
-  h->crow_n = (int)start.size() - 1;
+  if (!h->crow && tau::guided_chunks(h->p.H, (h->p.W + h2d::MCOLS - 1) / h2d::MCOLS, 512, 6, 56, &h->crow, &h->crow_n)) return 1;
   *nchunks = h->crow_n; *crow = h->crow;
   return 0;
 }

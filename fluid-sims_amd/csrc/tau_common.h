@@ -57,6 +57,14 @@ __device__ __forceinline__ void atomic_max_float_bits(unsigned *word, float v) {
   atomicMax(word, bits);
 }
 
+// Guided chunk schedule of a row march (host side; tau_common.hip).  A march's work list is chunk-major (work item = chunk *
+// nstrips + strip) and, through xcd_swizzle, each XCD walks a contiguous eighth of it in dispatch order: a band of H / 8 rows on
+// `slots_per_xcd` resident waves.  Chunks of one length leave the chip draining for a chunk's duration at the end of the
+// launch; here a chunk is as long as the band's remaining rows x strips shared out over the slots (clamped to [lmin, lmax]), so
+// the first waves are long — few warm-up rows — and the last ones short.  Returns a device table of nchunks + 1 row starts
+// (chunk c = rows [t[c], t[c + 1]), possibly empty where a band is a row shorter than the pattern); the caller frees it.
+int guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int **table_dev, int *nchunks);
+
 // one Burgers viscosity pass through the row-marching kernel (stencil2d.hip) with the time step read
 // from a device word: nu * (*dt_dev) * frac  (used by flow2d.hip for visc_substeps > 1)
 int st2_burgers_pass(const float *a, const float *b, float *oa, float *ob, int nx, int ny, float dx, float dy, float nu,

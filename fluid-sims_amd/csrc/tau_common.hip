@@ -1,6 +1,7 @@
 // tau_common.hip — error text, device probe, version.
 #include "../../include/taueng.h"
 #include "tau_common.h"
+#include <vector>
 
 namespace tau {
 char *err_buf() {
@@ -13,6 +14,28 @@ int fail(const char *fmt, ...) {
   vsnprintf(err_buf(), 512, fmt, ap);
   va_end(ap);
   return 1;
+}
+int guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int **table_dev, int *nchunks) {
+  const int hb = (H + 7) / 8;
+  std::vector<int> pat;                                   // chunk lengths of one band, descending
+  for (int R = hb; R > 0;) {
+    int len = (int)((double)R * nstrips / (double)slots_per_xcd + 0.5);
+    len = len < lmin ? lmin : (len > lmax ? lmax : len);
+    if (R - len < (lmin + 1) / 2) len = R;
+    pat.push_back(len); R -= len;
+  }
+  std::vector<int> start;                                 // every band gets the same number of chunks, clipped to the band
+  for (int b = 0; b < 8; b++) {
+    const int lo = (int)((long)H * b / 8), hi = (int)((long)H * (b + 1) / 8);
+    int r = lo;
+    for (size_t c = 0; c < pat.size(); c++) { start.push_back(r < hi ? r : hi); r += pat[c]; }
+  }
+  start.push_back(H);
+  *table_dev = nullptr;
+  TAU_HIP(hipMalloc(table_dev, start.size() * sizeof(int)));
+  TAU_HIP(hipMemcpy(*table_dev, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
+  *nchunks = (int)start.size() - 1;
+  return 0;
 }
 } // namespace tau
 
