@@ -310,7 +310,9 @@ __device__ __forceinline__ Walk make_walk(const Args &A, int k) {
 // The three record ranges a workgroup stages, and the shift from sorted index to LDS slot per row.
 struct Stage {
   int base[3], len[3], delta[3];
-  bool on;
+  int spread[3];   // how far the last particle's range starts behind the first one's (records), per row
+  bool on;      // the three ranges fit the stage
+  bool row;     // the workgroup's particles lie in one grid row (the ranges are defined at all)
 };
 __device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw, int cap) {
   Stage st;
@@ -325,10 +327,12 @@ __device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw, int 
     const bool ok = (unsigned)cy < (unsigned)A.Gy && cxb >= cxa;
     st.base[r] = ok ? A.cellStart[cy * A.Gx + cxa] : 0;
     st.len[r] = ok ? A.cellStart[cy * A.Gx + min(cxb, A.Gx - 1) + 1] - st.base[r] : 0;
+    st.spread[r] = ok ? A.cellStart[cy * A.Gx + max(c1 - gy * A.Gx - 1, 0)] - st.base[r] : 0;
     st.delta[r] = total - st.base[r];
     total += st.len[r];
   }
-  st.on = (c1 / A.Gx == gy) && total <= cap;
+  st.row = c1 / A.Gx == gy;
+  st.on = st.row && total <= cap;
   return st;
 }
 
@@ -470,6 +474,95 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[PW], i
   return quad_sum<LPP>(rho);
 }
 
+// entropy variable, pressure and the force pass's record of sorted place k from its summed density (:204-212)
+__device__ __forceinline__ void density_store(const Args &A, int k, float rho) {
+  const float si = logf(fmaxf(rho, 1e-6f));
+  rho = expf(si);
+  const float ratio = rho / A.rho0;
+  float p = (A.c0 * A.c0) * A.rho0 * (powf(ratio, A.gammaEOS) - 1.0f) / A.gammaEOS;
+  p = fmaxf(p, 0.0f);
+  const unsigned id = A.ids_s[k];
+  A.s[id] = si;
+  A.press[id] = p;
+  A.recB[k] = make_float2(p / (rho * rho), rho);
+}
+
+// ---- dense states: a workgroup whose candidate ranges do not fit the stage walks them in ROUNDS through it ------------------
+// (the collapsed dam: 100-400 particles per cell, 1 500-3 600 candidates per particle against the stage's 1 152 — round 3
+// walked those from global memory: every distance test a broadcast load, every hit an L2 gather.)  Round t of a row takes the
+// 32-candidate blocks [t TB, (t + 1) TB) of EVERY lane's own range — the lanes of a workgroup have ranges of similar length, so
+// they all have work in every round but the last — and stages the records those blocks can touch: from the first lane's block
+// t TB to the last lane's block (t + 1) TB, i.e. 32 TB + `spread` records.  A lane scans its blocks into sM (density pass: and
+// into nbrMask / ovfMask) or fetches their masks (force pass), then iterates the set bits on its own, two hits per trip, all
+// from LDS.  One lane per particle only (LPP = 1: the large-N configuration).
+// (Tiles of consecutive records with each lane taking the blocks that START in the tile were measured first: lanes whose range
+// begins mid-tile idle, 51 % of the lanes active per VALU instruction, no faster than the global walk.)
+constexpr int TBLK = NW;   // blocks per lane and round: the mask words sM holds
+__device__ __forceinline__ bool rounds_ok(const Stage &st, int cap) {   // every row gets at least four blocks per round
+  return st.row && !st.on && max(max(st.spread[0], st.spread[1]), st.spread[2]) + 4 * 32 <= cap;
+}
+template <class F>
+__device__ __forceinline__ void tile_hits(const unsigned (*sM)[256], int pl, int nbl, int s0, F &&body) {
+  if (nbl <= 0) return;
+  int w = 0, wbase = s0;
+  unsigned m = sM[0][pl];
+  while (m != 0u || w + 1 < nbl) {
+    if (m == 0u) { w++; m = sM[w][pl]; wbase += 32; }
+    if (m != 0u) {
+      const int ja = wbase + __builtin_ctz(m);
+      m &= m - 1u;
+      const bool two = m != 0u;
+      const int jb = two ? wbase + __builtin_ctz(two ? m : 1u) : ja;
+      m &= m - 1u;
+      body(ja, true);
+      body(jb, two);
+    }
+  }
+}
+template <class PosOf>
+__device__ __forceinline__ unsigned tile_scan(int s, int cnt, float2 me, float twoh2, PosOf &&pos) {
+  unsigned m = 0u;
+#pragma unroll 4
+  for (int b = 0; b < cnt; b++) {
+    const float2 o = pos(s + b);
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    m = m + m + ((dx * dx + dy * dy < twoh2) ? 1u : 0u);
+  }
+  return __builtin_bitreverse32(m) >> (32 - cnt);   // candidate b -> bit b (cnt >= 1)
+}
+__device__ __forceinline__ float density_tiled(const Args &A, const Stage &st, unsigned (*sM)[256], float2 *sP, int cap, int tid,
+                                               int k, bool active, const Walk &wk, float2 me) {
+  const float twoh = 2.f * A.h, twoh2 = twoh * twoh, ih = 1.0f / A.h, alpha = A.alpha;
+  float rho = 0.f;
+  auto add = [&](int j, bool on) {
+    const float2 o = sP[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    const float w = A.mass * W_cubic(__builtin_amdgcn_sqrtf(dx * dx + dy * dy), ih, alpha);
+    rho += on ? w : 0.f;
+  };
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int lo = st.base[r], u1 = lo + st.len[r];
+    const int tb = min(TBLK, (cap - st.spread[r]) >> 5);
+    const int off = wk.jb[r] - lo, jn = active ? wk.jn[r] : 0, nb = (jn + 31) >> 5;
+    for (int t = 0; __syncthreads_or(nb > t * tb); t++) {   // (the barrier also frees the stage of the round before)
+      const int w0 = lo + 32 * tb * t, n = min(u1, w0 + st.spread[r] + 32 * tb) - w0;
+      for (int i = tid; i < n; i += 256) sP[i] = A.recP[w0 + i];
+      __syncthreads();
+      const int nbl = min(nb - t * tb, tb);
+      for (int w = 0; w < nbl; w++) {
+        const int sl = off + 32 * w, blk = t * tb + w;
+        const unsigned m = tile_scan(sl, min(32, jn - 32 * blk), me, twoh2, [&](int j) { return sP[j]; });
+        sM[w][tid] = m;
+        if (blk < WPR) A.nbrMask[(size_t)(r * WPR + blk) * A.N + k] = m;
+        else if (A.ovfMask && blk - WPR < OVW) A.ovfMask[((size_t)(r * OVW + blk - WPR)) * A.N + k] = m;
+      }
+      tile_hits(sM, tid, nbl, off, add);
+    }
+  }
+  return rho;
+}
+
 template <int LPP>
 __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pressure_cell, :178-213
   constexpr int PPW = Cfg<LPP>::PPW;      // particles per workgroup
@@ -483,6 +576,15 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
       for (int i = tid; i < st.len[r]; i += 256) sP[st.base[r] + st.delta[r] + i] = A.recP[st.base[r] + i];
     __syncthreads();
   }
+  if constexpr (LPP == 1) if (rounds_ok(st, Cfg<LPP>::CAPL)) {   // dense state (workgroup-uniform branch)
+    const bool active = k < A.N;
+    const int kc = active ? k : A.N - 1;
+    const float2 me = A.recP[kc];
+    const Walk wk = make_walk(A, kc);
+    const float rho = density_tiled(A, st, sM, sP, Cfg<LPP>::CAPL, tid, kc, active, wk, me);
+    if (active) density_store(A, k, rho);
+    return;
+  }
   if (k >= A.N) return;                // whole quads leave together (k is the same for the LPP lanes)
   const float2 me = A.recP[k];
   Walk wk = make_walk(A, k);
@@ -495,15 +597,7 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
     rho = density_of<LPP, PPW>(A, sM, pl, sub, k, wk, me, (const float2 *)A.recP);
   }
   if (sub != 0) return;
-  const float si = logf(fmaxf(rho, 1e-6f));
-  rho = expf(si);
-  const float ratio = rho / A.rho0;
-  float p = (A.c0 * A.c0) * A.rho0 * (powf(ratio, A.gammaEOS) - 1.0f) / A.gammaEOS;
-  p = fmaxf(p, 0.0f);
-  const unsigned id = A.ids_s[k];
-  A.s[id] = si;
-  A.press[id] = p;
-  A.recB[k] = make_float2(p / (rho * rho), rho);
+  density_store(A, k, rho);
 }
 
 // acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
@@ -559,6 +653,70 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], in
   return make_float2(quad_sum<LPP>(ax), quad_sum<LPP>(ay));
 }
 
+// the force pass in rounds (see density_tiled): the masks come from the density pass — nbrMask, ovfMask — and only blocks
+// beyond what those hold (more than (WPR + OVW) * 32 candidates in a row) are scanned again
+template <bool VISC>
+__device__ __forceinline__ float2 accel_tiled(const Args &A, const Stage &st, unsigned (*sM)[256], float4 *sA, float2 *sB, int cap,
+                                              int tid, int k, bool active, const Walk &wk, float4 me, float2 meB) {
+  const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh, ih = 1.0f / h, alpha = A.alpha, eps2 = 0.01f * h * h;
+  float ax = 0.f, ay = 0.f;
+  int kk = 0;                                            // own stage slot in the round being walked (none outside row 1)
+  auto add = [&](int j, bool on) {                       // accel_of's pair evaluation
+    const float4 o = sA[j];
+    const float2 oB = sB[j];
+    const float dx = me.x - o.x, dy = me.y - o.y;
+    const float r2 = dx * dx + dy * dy;
+    const float ir = rsqf(r2), r = r2 * ir;
+    const bool valid = on & (j != kk) & (r2 > 1e-16f) & (r > 1e-8f);
+    const float q = r * ih, t = 2.0f - q;
+    const float dWa = -3.0f * q + 2.25f * q * q, dWb = -0.75f * t * t;
+    const float dWdq = alpha * ((q < 1.0f) ? dWa : dWb);
+    const float g0 = dWdq * ih * ir;
+    const float g = valid ? g0 : 0.f;
+    const float gwx = g * dx, gwy = g * dy;
+    float coef = -A.mass * (meB.x + oB.x);
+    if (VISC) {
+      const float dvx = me.z - o.z, dvy = me.w - o.w;
+      const float dot = fminf(dvx * dx + dvy * dy, 0.f);
+      const float Pi_ij = (-2.f * A.viscAlpha * A.c0 * h) * dot * rcpf((r2 + eps2) * (meB.y + oB.y));
+      coef += -A.mass * Pi_ij;
+    }
+    ax += coef * gwx;
+    ay += coef * gwy;
+  };
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    const int lo = st.base[r], u1 = lo + st.len[r];
+    const int tb = min(TBLK, (cap - st.spread[r]) >> 5);
+    const int off = wk.jb[r] - lo, jn = active ? wk.jn[r] : 0, nb = (jn + 31) >> 5;
+    for (int t = 0; __syncthreads_or(nb > t * tb); t++) {
+      const int w0 = lo + 32 * tb * t, n = min(u1, w0 + st.spread[r] + 32 * tb) - w0;
+      for (int i = tid; i < n; i += 256) { sA[i] = A.recA[w0 + i]; sB[i] = A.recB[w0 + i]; }
+      const int nbl = min(nb - t * tb, tb);
+      bool rescan = false;
+      for (int w = 0; w < nbl; w++) {                    // (global loads: in flight across the barrier below)
+        const int blk = t * tb + w;
+        unsigned m = 0u;
+        if (blk < WPR) m = A.nbrMask[(size_t)(r * WPR + blk) * A.N + k];
+        else if (A.ovfMask && blk - WPR < OVW) m = A.ovfMask[((size_t)(r * OVW + blk - WPR)) * A.N + k];
+        else rescan = true;
+        sM[w][tid] = m;
+      }
+      __syncthreads();
+      if (rescan)
+        for (int w = 0; w < nbl; w++) {
+          const int blk = t * tb + w;
+          if (blk >= WPR && !(A.ovfMask && blk - WPR < OVW))
+            sM[w][tid] = tile_scan(off + 32 * w, min(32, jn - 32 * blk), make_float2(me.x, me.y), twoh2,
+                                   [&](int j) { const float4 o = sA[j]; return make_float2(o.x, o.y); });
+        }
+      kk = (r == 1) ? k - w0 : -(1 << 30);
+      tile_hits(sM, tid, nbl, off, add);
+    }
+  }
+  return make_float2(ax, ay);
+}
+
 template <int LPP>
 __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell :215-272 + k_integrate :324-355
   constexpr int PPW = Cfg<LPP>::PPW;
@@ -576,21 +734,36 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
       }
     __syncthreads();
   }
-  if (k >= A.N) return;
-#pragma unroll
-  for (int w = sub; w < NW; w += LPP) sM[w][pl] = A.nbrMask[(size_t)w * A.N + k];   // only the words this lane walks
-  const float4 me = A.recA[k];
-  const float2 meB = A.recB[k];
-  Walk wk = make_walk(A, k);
+  float4 me;
   float2 a;
-  if (st.on) {
+  bool tiled = false;
+  if constexpr (LPP == 1) if (rounds_ok(st, Cfg<LPP>::CAPL)) {   // dense state (workgroup-uniform branch)
+    const bool active = k < A.N;
+    const int kc = active ? k : A.N - 1;
+    me = A.recA[kc];
+    const float2 meB = A.recB[kc];
+    const Walk wk = make_walk(A, kc);
+    a = A.useVisc ? accel_tiled<true>(A, st, sM, sA, sB, Cfg<LPP>::CAPL, tid, kc, active, wk, me, meB)
+                  : accel_tiled<false>(A, st, sM, sA, sB, Cfg<LPP>::CAPL, tid, kc, active, wk, me, meB);
+    if (!active) return;
+    tiled = true;
+  }
+  if (!tiled) {
+    if (k >= A.N) return;
 #pragma unroll
-    for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB)
-                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB);
-  } else {
-    a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
-                  : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+    for (int w = sub; w < NW; w += LPP) sM[w][pl] = A.nbrMask[(size_t)w * A.N + k];   // only the words this lane walks
+    me = A.recA[k];
+    const float2 meB = A.recB[k];
+    Walk wk = make_walk(A, k);
+    if (st.on) {
+#pragma unroll
+      for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
+      a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB)
+                    : accel_of<LPP, false, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+    } else {
+      a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
+                    : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+    }
   }
   if (sub != 0) return;
   float ax = a.x, ay = a.y;

@@ -237,6 +237,40 @@ def test_dense_cluster_takes_the_overflow_path(eng, oracle_built):
     e.close()
 
 
+@pytest.mark.parametrize("box,what", [(0.2, "rounds through the stage"), (0.15, "rounds + re-scan beyond the kept masks"),
+                                      (0.1, "spread beyond the stage: global walk")])
+def test_dense_state_one_lane_per_particle(eng, oracle_built, box, what):
+    """140 000 particles (one lane per particle) packed into box x box: ~410 / ~690 / ~1 600 particles per cell, i.e. 1 200 to
+    4 800 candidates per row range — the three candidate ranges of a workgroup no longer fit the LDS stage and are walked in
+    rounds (sph.hip, density_tiled / accel_tiled); at 0.15 a row exceeds the (WPR + OVW) * 32 = 2 048 candidates whose hit masks
+    the density pass hands to the force pass (those blocks are scanned again); at 0.1 the ranges of a workgroup's first and last
+    particle lie further apart than the stage is long and the global walk takes over.  One sub-step against the oracle."""
+    N = 140000
+    rng = np.random.default_rng(11)
+    pos = (0.3 + box * rng.random((N, 2))).astype(np.float32)
+    vel = (0.05 * rng.standard_normal((N, 2))).astype(np.float32)
+    o = oracle_built.OracleSph(N)
+    e = eng.Sph2D(N)
+    e.upload(pos, vel)
+    o.set_state(pos, vel)
+    g = e.grid()
+    cells = (np.floor(pos[:, 1] / np.float32(g["cell"])).astype(int) * g["Gx"] + np.floor(pos[:, 0] / np.float32(g["cell"])).astype(int))
+    per_cell = np.bincount(cells).max()
+    dt = 1e-5
+    o.substep(dt)
+    e.substep(dt)
+    got, want = e.download(), o.state()
+    assert np.array_equal(got["cell"], want["cell"])
+    tol = 1.5 * per_cell * 2.0 ** -24        # ~ (hits per particle = 0.35 x 9 cells) x fp32 eps / 2
+    rho_w, rho_g = np.exp(want["s"].astype(np.float64)), np.exp(got["s"].astype(np.float64))
+    e_rho = float((np.abs(rho_g - rho_w) / rho_w).max())
+    scale = np.maximum(want["acc_abs"].astype(np.float64), 1e-30)
+    e_a = float((np.linalg.norm(got["acc"].astype(np.float64) - want["acc"], axis=1) / scale).max())
+    print("dense %s: %d per cell, parity rho %.2e acc %.2e (tol %.1e)" % (what, per_cell, e_rho, e_a, tol))
+    assert e_rho <= tol and e_a <= tol
+    e.close()
+
+
 @pytest.mark.parametrize("N,warm", [(4096, 40), (65536, 200), (200000, 3)])
 def test_one_and_four_lanes_per_particle_agree(eng, oracle_built, N, warm):
     """the density / force passes exist with one lane per particle and with four (chosen by N): both
