@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <vector>
 
@@ -91,6 +92,21 @@ PK(pk_mul, "v_pk_mul_f32 %0, %0, %1")
 PK(pk_add, "v_pk_add_f32 %0, %0, %2")
 PK(pk_fma_neg, "v_pk_fma_f32 %0, %0, %1, %2 neg_lo:[0,1,0] neg_hi:[0,1,0]")
 PK(pk_fma_sel, "v_pk_fma_f32 %0, %0, %1, %2 op_sel:[0,1,0] op_sel_hi:[1,0,1]")
+// 16-bit packed / dot-product forms (SPH range test on staged int16 or fp16 coordinates), bit scans, add-with-carry
+OP(pk_sub_i16, asm volatile("v_pk_sub_i16 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(dot2_i32_i16, asm volatile("v_dot2_i32_i16 %0, %1, %1, %0" : "+v"(x) : "v"(b)))
+OP(dot2_u32_u16, asm volatile("v_dot2_u32_u16 %0, %1, %1, %0" : "+v"(x) : "v"(b)))
+OP(pk_add_f16, asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(pk_mul_f16, asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(dot2_f32_f16, asm volatile("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(x) : "v"(b)))
+OP(mad_i32_i16, asm volatile("v_mad_i32_i16 %0, %1, %1, %0" : "+v"(x) : "v"(b)))
+OP(addc, asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : : "vcc"))
+OP(ffbl, asm volatile("v_ffbl_b32 %0, %1" : "+v"(x) : "v"(b)))
+OP(bfrev, asm volatile("v_bfrev_b32 %0, %1" : "+v"(x) : "v"(b)))
+OP(mix_scan4, asm volatile("v_pk_sub_i16 %1, %2, %3\n v_dot2_i32_i16 %1, %1, %1, 0\n v_cmp_gt_i32 vcc, %2, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc"
+                           : "+v"(x), "+v"(y) : "v"(a), "v"(b) : "vcc"))
+OP(mix_scan6, asm volatile("v_sub_f32 %1, %2, %3\n v_sub_f32 %4, %3, %2\n v_mul_f32 %1, %1, %1\n v_fma_f32 %1, %4, %4, %1\n v_cmp_gt_f32 vcc, %2, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc"
+                           : "+v"(x), "+v"(y) : "v"(a), "v"(b), "v"(y) : "vcc"))
 }  // namespace op
 using namespace op;
 
@@ -100,6 +116,8 @@ template <> struct per_call<mix_fma7_rcp1> { static constexpr int n = 8; };
 template <> struct per_call<mix_alu5> { static constexpr int n = 5; };
 template <> struct per_call<mix_alu5_sgpr> { static constexpr int n = 5; };
 template <> struct per_call<mix_fma4_dsr1> { static constexpr int n = 4; };   // VALU instructions only
+template <> struct per_call<mix_scan4> { static constexpr int n = 4; };
+template <> struct per_call<mix_scan6> { static constexpr int n = 6; };
 
 struct Stamp { uint64_t cyc, w0, w1; uint32_t hwid, xcc; };
 
@@ -200,6 +218,13 @@ int main(int argc, char **argv) {
   hipMalloc(&g_sink, (size_t)g_cus * 8 * 256 * 4);
   printf("# %s, %d CUs, nominal clock %d MHz; %d x %d instructions per wave; workgroup = 256 threads = 1 wave per SIMD\n",
          p.gcnArchName, g_cus, p.clockRate / 1000, iters, UNROLL);
+  if (argc > 2 && !strcmp(argv[2], "int16")) {   // only the 16-bit / bit-scan additions (round 4)
+    sweep<fma_vvv>(iters);
+    sweep<pk_sub_i16>(iters); sweep<dot2_i32_i16>(iters); sweep<dot2_u32_u16>(iters); sweep<pk_add_f16>(iters); sweep<pk_mul_f16>(iters);
+    sweep<dot2_f32_f16>(iters); sweep<mad_i32_i16>(iters); sweep<addc>(iters); sweep<ffbl>(iters); sweep<bfrev>(iters);
+    sweep<mix_scan4>(iters / 4); sweep<mix_scan6>(iters / 4);
+    return 0;
+  }
   sweep<fma_vvv>(iters);
   sweep<fma_vsv>(iters);
   sweep<fma_vcc>(iters);
