@@ -15,7 +15,7 @@ int fail(const char *fmt, ...) {
   va_end(ap);
   return 1;
 }
-int guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int **table_dev, int *nchunks) {
+static std::vector<int> guided_chunk_starts(int H, int nstrips, int slots_per_xcd, int lmin, int lmax) {
   const int hb = (H + 7) / 8;
   std::vector<int> pat;                                   // chunk lengths of one band, descending
   for (int R = hb; R > 0;) {
@@ -31,6 +31,10 @@ int guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int
     for (size_t c = 0; c < pat.size(); c++) { start.push_back(r < hi ? r : hi); r += pat[c]; }
   }
   start.push_back(H);
+  return start;
+}
+int guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int **table_dev, int *nchunks) {
+  const std::vector<int> start = guided_chunk_starts(H, nstrips, slots_per_xcd, lmin, lmax);
   *table_dev = nullptr;
   TAU_HIP(hipMalloc(table_dev, start.size() * sizeof(int)));
   TAU_HIP(hipMemcpy(*table_dev, start.data(), start.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -47,6 +51,16 @@ extern "C" int tau_device_available(void) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
   return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+extern "C" int tau_guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int *starts, int cap, int *nchunks) {
+  if (!nchunks || H < 1 || nstrips < 1 || slots_per_xcd < 1 || lmin < 1 || lmax < lmin) return tau::fail("tau_guided_chunks: bad argument");
+  const std::vector<int> start = tau::guided_chunk_starts(H, nstrips, slots_per_xcd, lmin, lmax);
+  *nchunks = (int)start.size() - 1;
+  if (starts) {
+    if (cap < (int)start.size()) return tau::fail("tau_guided_chunks: %d entries do not fit %d", (int)start.size(), cap);
+    for (size_t i = 0; i < start.size(); i++) starts[i] = start[i];
+  }
+  return 0;
 }
 extern "C" int tau_device_count(int *n) {
   if (!n) return tau::fail("tau_device_count: null argument");

@@ -148,6 +148,7 @@ def load():
         "tau3d_field_range": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)], i32),
         "tau3d_sync": ([vp], i32),
         "tau_device_count": ([C.POINTER(i32)], i32),
+        "tau_guided_chunks": ([i32, i32, i32, i32, i32, C.POINTER(i32), i32, C.POINTER(i32)], i32),
         "tau3d_slab_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)], i32),
         "tau3d_is_split": ([vp], i32), "tau3d_set_split": ([vp, i32], i32),
         "tau3d_slab_bounds": ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
@@ -288,6 +289,15 @@ def slab_bounds(nz, world, rank):
     z0, nzl = C.c_int(), C.c_int()
     _ck(load().tau3d_slab_bounds(nz, world, rank, C.byref(z0), C.byref(nzl)))
     return z0.value, nzl.value
+
+
+def guided_chunks(H, nstrips, slots_per_xcd, lmin, lmax):
+    """tau_guided_chunks: the row starts of the marches' guided chunk schedule (host only; len = chunks + 1)"""
+    n = C.c_int()
+    _ck(load().tau_guided_chunks(H, nstrips, slots_per_xcd, lmin, lmax, None, 0, C.byref(n)))
+    out = (C.c_int * (n.value + 1))()
+    _ck(load().tau_guided_chunks(H, nstrips, slots_per_xcd, lmin, lmax, out, n.value + 1, C.byref(n)))
+    return list(out)
 
 
 class Tau3DRing:

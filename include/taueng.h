@@ -34,6 +34,11 @@ int tau_device_available(void);
 /* number of devices the HIP runtime shows (0 with an error text when there is no runtime / no device) */
 int tau_device_count(int *n);
 int tau_version(void);
+/* Test seam (host only, no device): the guided chunk schedule of the row marches (2D Euler, Burgers, shallow water;
+ * csrc/tau_common.hip tau::guided_chunks).  H rows in 8 bands, each cut into chunks of descending length: a chunk is the band's
+ * remaining rows x nstrips shared out over slots_per_xcd resident waves, clamped to [lmin, lmax].  Writes *nchunks + 1 row starts
+ * (chunk c = rows [starts[c], starts[c + 1]), possibly empty) if `starts` is non-null and `cap` entries suffice. */
+int tau_guided_chunks(int H, int nstrips, int slots_per_xcd, int lmin, int lmax, int *starts, int cap, int *nchunks);
 
 /* =====================================================================
  * 3D two-temperature hypersonic Euler — replaces the launches in

@@ -57,3 +57,28 @@ def test_slab_bounds_without_gpu():
         assert got[0][0] == 0 and sum(n for _, n in got) == nz and all(a[0] + a[1] == b[0] for a, b in zip(got, got[1:]))
     with pytest.raises(f.TauError, match="need >= 6"):
         f.slab_bounds(40, 8, 0)
+
+
+def test_guided_chunk_schedule_without_gpu():
+    """tau_guided_chunks (host logic of tau::guided_chunks, csrc/tau_common.hip): the chunks tile [0, H) in order, every band of
+    H / 8 rows gets the same number of chunks with lengths descending from `remaining x strips / slots` to the minimum, none
+    beyond the maximum (the 2D march addresses a chunk's band with 32-bit offsets: 56 rows)"""
+    import fluid_sims_amd as f
+    for H, W, slots, lmin, lmax in ((4096, 4096, 512, 6, 56), (8192, 8192, 512, 6, 56), (1024, 8192, 512, 6, 56), (3000, 3000, 512, 6, 56),
+                                    (8192, 8192, 1024, 12, 64), (37, 128, 512, 6, 56), (5, 64, 512, 6, 56), (1, 8, 512, 6, 56)):
+        nstrips = (W + 59) // 60
+        t = f.guided_chunks(H, nstrips, slots, lmin, lmax)
+        assert t[0] == 0 and t[-1] == H and all(a <= b for a, b in zip(t, t[1:]))
+        lens = [b - a for a, b in zip(t, t[1:])]
+        assert max(lens) <= lmax + lmin // 2 + 1 and (len(lens) % 8) == 0
+        per = len(lens) // 8
+        for b in range(8):
+            band = [x for x in lens[b * per:(b + 1) * per] if x > 0]
+            assert sum(lens[b * per:(b + 1) * per]) == H * (b + 1) // 8 - H * b // 8
+            # descending apart from the last chunk of a band (which absorbs a short remainder or is clipped by a shorter band)
+            assert all(x >= y for x, y in zip(band[:-1], band[1:-1])), (H, W, band)
+        if H >= 2048:
+            first = min(lmax, max(lmin, round((H + 7) // 8 * nstrips / slots)))
+            assert lens[0] == first
+    with pytest.raises(f.TauError):
+        f.guided_chunks(0, 4, 512, 6, 56)
