@@ -259,6 +259,64 @@ __device__ __forceinline__ float W_cubic(float r, float ih, float alpha) { // :1
   return alpha * ((q < 2.0f) ? w12 : 0.f);
 }
 
+// Pair evaluations of the two neighbour passes.  The constant factors are taken OUT of the sums — rho = (m alpha) sum s(q),
+// a = (-m alpha / h) sum (p_i/rho_i^2 + p_j/rho_j^2 + Pi_ij) s'(q) / r (x_i - x_j) — and the constants a pair still needs sit
+// in VGPRs: a VALU instruction with an SGPR operand issues at half rate on gfx950 (profiles/r02/valu_calib.txt), and the
+// reference's order (m * (alpha * s) per pair, :105-116, 196-201) spent four such multiplies per density pair.  A reassociation
+// at rounding level (the sums already run in another order than the reference's lists).
+__device__ __forceinline__ float vreg(float s) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+// W_cubic / alpha for a pair the range test admitted (r2 < (2h)^2: q < 2 up to rounding, where the q >= 2 branch of :113-115
+// differs from the cubic by less than 1e-20)
+__device__ __forceinline__ float W_shape(float q) {
+  const float q2 = q * q, t = 2.f - q;
+  const float w1 = 1.f - 1.5f * q2 + 0.75f * q2 * q;
+  const float w2 = 0.25f * t * t * t;
+  return (q < 1.0f) ? w1 : w2;
+}
+struct DensK { float ih; };
+__device__ __forceinline__ DensK dens_k(const Args &A) { return DensK{vreg(1.0f / A.h)}; }
+__device__ __forceinline__ void dens_pair(const DensK &K, float2 me, float2 o, bool on, float &rho) {
+  const float dx = me.x - o.x, dy = me.y - o.y;
+  const float w = W_shape(__builtin_amdgcn_sqrtf(dx * dx + dy * dy) * K.ih);
+  rho += on ? w : 0.f;
+}
+__device__ __forceinline__ float dens_scale(const Args &A) { return A.mass * A.alpha; }
+
+struct ForceK { float ih, eps2, cv; };
+__device__ __forceinline__ ForceK force_k(const Args &A) {
+  return ForceK{vreg(1.0f / A.h), vreg(0.01f * A.h * A.h), vreg(-2.f * A.viscAlpha * A.c0 * A.h)};
+}
+// One neighbour inside the support.  Straight-line on purpose: the reference's skips (self and coincident particles :231-233 —
+// both have r2 = 0 —, gradW's r guard :119, receding pairs :254) become selects that contribute exact zeros: a few VALU ops, no
+// exec-mask juggling inside the hottest loop of the pass.  Two transcendentals per pair instead of four: 1/r from rsq with
+// r = r2 / r, and the two divisions of the viscosity term (:256-258) as one reciprocal of the product.
+template <bool VISC>
+__device__ __forceinline__ void force_pair(const ForceK &K, float4 me, float2 meB, float4 o, float2 oB, bool on, float &ax, float &ay) {
+  const float dx = me.x - o.x, dy = me.y - o.y;
+  const float r2 = dx * dx + dy * dy;
+  const float ir = rsqf(r2), r = r2 * ir;
+  const bool valid = on & (r2 > 1e-16f) & (r > 1e-8f);
+  const float q = r * K.ih, t = 2.0f - q;                // gradW_cubic / alpha, :118-133
+  const float dWa = q * (2.25f * q - 3.0f), dWb = -0.75f * t * t;
+  const float s0 = ((q < 1.0f) ? dWa : dWb) * ir;
+  const float sg = valid ? s0 : 0.f;                     // (a select of two VALUES: `valid ? expr : 0` becomes an exec-mask branch)
+  float pv = meB.x + oB.x;                               // p_i/rho_i^2 + p_j/rho_j^2
+  if (VISC) {   // (A.useVisc, resolved outside the loop: a uniform branch between the two evaluations of a trip would order them)
+    const float dvx = me.z - o.z, dvy = me.w - o.w;
+    const float dot = fminf(dvx * dx + dvy * dy, 0.f);   // receding pairs: mu = 0, Pi = 0
+    // mu = h dot / (r2 + eps2), Pi = -alpha_v c0 mu / (0.5 (rho_i + rho_j))
+    pv = fmaf(K.cv * dot, rcpf((r2 + K.eps2) * (meB.y + oB.y)), pv);
+  }
+  const float gp = sg * pv;
+  ax = fmaf(gp, dx, ax);
+  ay = fmaf(gp, dy, ay);
+}
+__device__ __forceinline__ float force_scale(const Args &A) { return -A.mass * A.alpha * (1.0f / A.h); }
+
 // ---- neighbour passes ------------------------------------------------------------------------------
 // A particle's candidates are the 3 x 3 cells around it = three contiguous record ranges (~96 records
 // each at the dam's packing), of which only the ones inside the 2h disc (~35 %) contribute.  Walking the
@@ -430,8 +488,6 @@ template <int LPP, int PW, class PosArr>
 __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int k, const Walk &wk,
                                             float2 me, PosArr P) {
   const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
-  const float ih = 1.0f / A.h;
-  const float alpha = A.alpha;
   // scan: bit b of word (r, w) <=> candidate jb[r] + 32 w + b is inside the support
 #pragma unroll
   for (int r = 0; r < 3; r++) {
@@ -453,13 +509,8 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[PW], i
     }
   }
   float rho = 0.f;
-  auto add = [&](int j, bool on) {
-    const float2 o = P[j];
-    const float dx = me.x - o.x, dy = me.y - o.y;
-    const float r2 = dx * dx + dy * dy;
-    const float w = A.mass * W_cubic(__builtin_amdgcn_sqrtf(r2), ih, alpha);
-    rho += on ? w : 0.f;
-  };
+  const DensK K = dens_k(A);
+  auto add = [&](int j, bool on) { dens_pair(K, me, P[j], on, rho); };
   for_each_hit<LPP, TAUSPH_NH_D, PW>(sM, pl, sub, wk, add);
   if (A.ovfMask) for_each_overflow<LPP, 1>(A, k, wk, sub, [&](int j) {
     const float2 o = P[j];
@@ -471,7 +522,7 @@ __device__ __forceinline__ float density_of(const Args &A, unsigned (*sM)[PW], i
     const float dx = me.x - o.x, dy = me.y - o.y;
     return dx * dx + dy * dy < twoh2;
   }, add);
-  return quad_sum<LPP>(rho);
+  return dens_scale(A) * quad_sum<LPP>(rho);
 }
 
 // entropy variable, pressure and the force pass's record of sorted place k from its summed density (:204-212)
@@ -532,14 +583,10 @@ __device__ __forceinline__ unsigned tile_scan(int s, int cnt, float2 me, float t
 }
 __device__ __forceinline__ float density_tiled(const Args &A, const Stage &st, unsigned (*sM)[256], float2 *sP, int cap, int tid,
                                                int k, bool active, const Walk &wk, float2 me) {
-  const float twoh = 2.f * A.h, twoh2 = twoh * twoh, ih = 1.0f / A.h, alpha = A.alpha;
+  const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
   float rho = 0.f;
-  auto add = [&](int j, bool on) {
-    const float2 o = sP[j];
-    const float dx = me.x - o.x, dy = me.y - o.y;
-    const float w = A.mass * W_cubic(__builtin_amdgcn_sqrtf(dx * dx + dy * dy), ih, alpha);
-    rho += on ? w : 0.f;
-  };
+  const DensK K = dens_k(A);
+  auto add = [&](int j, bool on) { dens_pair(K, me, sP[j], on, rho); };
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const int lo = st.base[r], u1 = lo + st.len[r];
@@ -560,7 +607,7 @@ __device__ __forceinline__ float density_tiled(const Args &A, const Stage &st, u
       tile_hits(sM, tid, nbl, off, add);
     }
   }
-  return rho;
+  return dens_scale(A) * rho;
 }
 
 template <int LPP>
@@ -600,45 +647,14 @@ __global__ __launch_bounds__(256) void k_density(const Args A) { // k_density_pr
   density_store(A, k, rho);
 }
 
-// acceleration of one particle; RA / RB index the candidates' records in wk's index space, kk = own slot
+// acceleration of one particle; RA / RB index the candidates' records in wk's index space, kg = own sorted place
 template <int LPP, bool VISC, int PW, class ArrA, class ArrB>
-__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int kk, int kg, const Walk &wk,
+__device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], int pl, int sub, int kg, const Walk &wk,
                                            float4 me, float2 meB, ArrA RA, ArrB RB) {
-  const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh;
-  const float ih = 1.0f / h;
-  const float alpha = A.alpha;
-  const float eps2 = 0.01f * h * h;
+  const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
   float ax = 0.f, ay = 0.f;
-  // One neighbour inside the support.  Straight-line on purpose: the reference's skips (self, coincident
-  // particles :231-233, gradW's r guard :119, receding pairs :254) become selects that contribute exact
-  // zeros, which costs a few VALU ops but no exec-mask juggling inside the hottest loop of the pass.
-  auto add = [&](int j, bool on) {
-    const float4 o = RA[j];
-    const float2 oB = RB[j];
-    const float dx = me.x - o.x, dy = me.y - o.y;
-    const float r2 = dx * dx + dy * dy;
-    // two transcendentals per pair instead of four (each is a quarter-rate instruction, and the pass is short of VALU issue):
-    // 1/r from rsq with r = r2 / r, and the two divisions of the viscosity term (:256-258) as one reciprocal of the product
-    const float ir = rsqf(r2), r = r2 * ir;
-    const bool valid = on & (j != kk) & (r2 > 1e-16f) & (r > 1e-8f);
-    // gradW_cubic, :118-133
-    const float q = r * ih, t = 2.0f - q;
-    const float dWa = -3.0f * q + 2.25f * q * q, dWb = -0.75f * t * t;
-    const float dWdq = alpha * ((q < 1.0f) ? dWa : dWb);
-    const float g0 = dWdq * ih * ir;
-    const float g = valid ? g0 : 0.f;               // (a select of two VALUES: `valid ? expr : 0` becomes an exec-mask branch)
-    const float gwx = g * dx, gwy = g * dy;
-    float coef = -A.mass * (meB.x + oB.x);   // -m (p_i/rho_i^2 + p_j/rho_j^2)
-    if (VISC) {   // (A.useVisc, resolved outside the loop: a uniform branch between the two evaluations of a trip would order them)
-      const float dvx = me.z - o.z, dvy = me.w - o.w;
-      const float dot = fminf(dvx * dx + dvy * dy, 0.f);   // receding pairs: mu = 0, Pi = 0, coef unchanged
-      // mu = h dot / (r2 + eps2), Pi = -alpha c0 mu / (0.5 (rho_i + rho_j))
-      const float Pi_ij = (-2.f * A.viscAlpha * A.c0 * h) * dot * rcpf((r2 + eps2) * (meB.y + oB.y));
-      coef += -A.mass * Pi_ij;
-    }
-    ax += coef * gwx;
-    ay += coef * gwy;
-  };
+  const ForceK K = force_k(A);
+  auto add = [&](int j, bool on) { force_pair<VISC>(K, me, meB, RA[j], RB[j], on, ax, ay); };
   for_each_hit<LPP, TAUSPH_NH_F, PW>(sM, pl, sub, wk, add);
   if (A.ovfMask) for_each_overflow<LPP, 2>(A, kg, wk, sub, [&](int j) {
     const float4 o = RA[j];
@@ -650,7 +666,8 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], in
     const float dx = me.x - o.x, dy = me.y - o.y;
     return dx * dx + dy * dy < twoh2;
   }, add);
-  return make_float2(quad_sum<LPP>(ax), quad_sum<LPP>(ay));
+  const float sc = force_scale(A);
+  return make_float2(sc * quad_sum<LPP>(ax), sc * quad_sum<LPP>(ay));
 }
 
 // the force pass in rounds (see density_tiled): the masks come from the density pass — nbrMask, ovfMask — and only blocks
@@ -658,32 +675,10 @@ __device__ __forceinline__ float2 accel_of(const Args &A, unsigned (*sM)[PW], in
 template <bool VISC>
 __device__ __forceinline__ float2 accel_tiled(const Args &A, const Stage &st, unsigned (*sM)[256], float4 *sA, float2 *sB, int cap,
                                               int tid, int k, bool active, const Walk &wk, float4 me, float2 meB) {
-  const float h = A.h, twoh = 2.f * h, twoh2 = twoh * twoh, ih = 1.0f / h, alpha = A.alpha, eps2 = 0.01f * h * h;
+  const float twoh = 2.f * A.h, twoh2 = twoh * twoh;
   float ax = 0.f, ay = 0.f;
-  int kk = 0;                                            // own stage slot in the round being walked (none outside row 1)
-  auto add = [&](int j, bool on) {                       // accel_of's pair evaluation
-    const float4 o = sA[j];
-    const float2 oB = sB[j];
-    const float dx = me.x - o.x, dy = me.y - o.y;
-    const float r2 = dx * dx + dy * dy;
-    const float ir = rsqf(r2), r = r2 * ir;
-    const bool valid = on & (j != kk) & (r2 > 1e-16f) & (r > 1e-8f);
-    const float q = r * ih, t = 2.0f - q;
-    const float dWa = -3.0f * q + 2.25f * q * q, dWb = -0.75f * t * t;
-    const float dWdq = alpha * ((q < 1.0f) ? dWa : dWb);
-    const float g0 = dWdq * ih * ir;
-    const float g = valid ? g0 : 0.f;
-    const float gwx = g * dx, gwy = g * dy;
-    float coef = -A.mass * (meB.x + oB.x);
-    if (VISC) {
-      const float dvx = me.z - o.z, dvy = me.w - o.w;
-      const float dot = fminf(dvx * dx + dvy * dy, 0.f);
-      const float Pi_ij = (-2.f * A.viscAlpha * A.c0 * h) * dot * rcpf((r2 + eps2) * (meB.y + oB.y));
-      coef += -A.mass * Pi_ij;
-    }
-    ax += coef * gwx;
-    ay += coef * gwy;
-  };
+  const ForceK K = force_k(A);
+  auto add = [&](int j, bool on) { force_pair<VISC>(K, me, meB, sA[j], sB[j], on, ax, ay); };
 #pragma unroll
   for (int r = 0; r < 3; r++) {
     const int lo = st.base[r], u1 = lo + st.len[r];
@@ -710,11 +705,11 @@ __device__ __forceinline__ float2 accel_tiled(const Args &A, const Stage &st, un
             sM[w][tid] = tile_scan(off + 32 * w, min(32, jn - 32 * blk), make_float2(me.x, me.y), twoh2,
                                    [&](int j) { const float4 o = sA[j]; return make_float2(o.x, o.y); });
         }
-      kk = (r == 1) ? k - w0 : -(1 << 30);
       tile_hits(sM, tid, nbl, off, add);
     }
   }
-  return make_float2(ax, ay);
+  const float sc = force_scale(A);
+  return make_float2(sc * ax, sc * ay);
 }
 
 template <int LPP>
@@ -758,11 +753,11 @@ __global__ __launch_bounds__(256) void k_forces(const Args A) { // k_forces_cell
     if (st.on) {
 #pragma unroll
       for (int r = 0; r < 3; r++) wk.jb[r] += st.delta[r];
-      a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB)
-                    : accel_of<LPP, false, PPW>(A, sM, pl, sub, k + st.delta[1], k, wk, me, meB, (const float4 *)sA, (const float2 *)sB);
+      a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)sA, (const float2 *)sB)
+                    : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)sA, (const float2 *)sB);
     } else {
-      a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
-                    : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
+      a = A.useVisc ? accel_of<LPP, true, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB)
+                    : accel_of<LPP, false, PPW>(A, sM, pl, sub, k, wk, me, meB, (const float4 *)A.recA, (const float2 *)A.recB);
     }
   }
   if (sub != 0) return;
