@@ -58,6 +58,11 @@ struct Args {
   C4 in_c;
 };
 
+__device__ __forceinline__ float vreg(float s) {   // a wave-uniform value moved into a VGPR
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }   // 1 ulp; the tolerance is 1e-5
 __device__ __forceinline__ float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 
@@ -433,6 +438,9 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
 // (columns left of x = 0 hold the inflow state, columns right of W-1 a copy of cell W-1, rows are clamped, all
 // with the mask cleared / taken from the clamped cell), applied where a row is loaded.
 constexpr int MCOLS = 60;
+#ifndef TAU_H2_VREG_CONSTS
+#define TAU_H2_VREG_CONSTS 2   // gas constants (1) and dt (2) of the LDS-window march in VGPRs: +0.5 % (round 4; 0 = SGPR operands)
+#endif
 #ifndef TAU_H2_LDS_WAVES
 #define TAU_H2_LDS_WAVES 4
 #endif
@@ -639,8 +647,14 @@ struct MRing {
   __device__ __forceinline__ float fld(int slot, int f, int ln, int d) const { return w[slot][f][min(max(ln - d, 0), 63)]; }
 };
 template <int WPB>   // waves per workgroup: the waves of a workgroup share nothing, WPB only sets the granularity of dispatch
-__global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const Args A, int rows, int nstrips, int nchunks, const int *__restrict__ crow) {
+__global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const Args A0, int rows, int nstrips, int nchunks, const int *__restrict__ crow) {
   __shared__ float sW[WPB][5][5][64];
+#if TAU_H2_VREG_CONSTS >= 1
+  Args A = A0;   // the gas constants in VGPRs: a VALU instruction with an SGPR operand issues at half rate (profiles/r02/valu_calib.txt)
+  A.gamma = vreg(A0.gamma); A.gm1 = vreg(A0.gm1); A.inv_gm1 = vreg(A0.inv_gm1);
+#else
+  const Args &A = A0;
+#endif
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(nstrips * nchunks);
   const unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * WPB + (threadIdx.x >> 6);
@@ -651,6 +665,9 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
     if (!isfinite(maxs) || maxs < 1e-12f) maxs = 1e-12f;
     dt = fminf(A.cfl / maxs, A.dt_diff);
   }
+#if TAU_H2_VREG_CONSTS >= 2
+  dt = vreg(dt);
+#endif
   const float half = 0.5f * dt;
   if (blockIdx.x == 0 && threadIdx.x == 0) { // the step's bookkeeping: sim_t += dt, :1888
     A.st->t += (double)dt;
