@@ -48,6 +48,28 @@ struct Args {
   int burgers_fast;      // fused Burgers passes keep u decoded between their levels (TAU_ST2_BURGERS_FAST=1; default 0)
 };
 
+// The per-cell coefficients as VGPR values: a VALU instruction with an SGPR operand issues at half rate on gfx950
+// (profiles/r02/valu_calib.txt) and the Gray-Scott cell has seven such operands among its ~22 instructions.  Same arithmetic.
+#ifndef TAU_ST2_VREG
+#define TAU_ST2_VREG 1
+#endif
+__device__ __forceinline__ float vreg(float s) {
+  float v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+  return v;
+}
+__device__ __forceinline__ Args coeffs_in_vgprs(const Args &A0) {
+  Args A = A0;
+#if TAU_ST2_VREG
+  A.dt = vreg(A0.dt); A.Du = vreg(A0.Du); A.Dv = vreg(A0.Dv); A.feed = vreg(A0.feed); A.kill = vreg(A0.kill);
+  A.inv_dx2 = vreg(A0.inv_dx2); A.dx2 = vreg(A0.dx2);
+  A.invdx2 = vreg(A0.invdx2); A.invdy2 = vreg(A0.invdy2); A.u0 = vreg(A0.u0); A.inv_u0 = vreg(A0.inv_u0);
+  A.nudt = vreg(A0.dt_dev ? A0.nudt * (*A0.dt_dev) : A0.nudt);
+  A.dt_dev = nullptr;
+#endif
+  return A;
+}
+
 // -------- transcendental pair for the Burgers encoding, accurate to ~1e-7 relative
 __device__ __forceinline__ float fsinh(float x) {
   float ax = fabsf(x);
@@ -127,7 +149,8 @@ __device__ __forceinline__ void cell(const Args &A, float uc, float ul, float ur
 
 // "ud" above is the row j+1 (the reference's jp), "uu" the row j-1 (jm).
 template <int KIND>
-__global__ __launch_bounds__(64 * WAVES) void k_march(const Args A) {
+__global__ __launch_bounds__(64 * WAVES) void k_march(const Args A0) {
+  const Args A = coeffs_in_vgprs(A0);
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
   unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * WAVES + (threadIdx.x >> 6);
@@ -210,7 +233,8 @@ __device__ __forceinline__ void row_step(const Args &A, const Lvl &up, const Lvl
 // The march starts K rows early with zeroed stages: whatever the upper stages compute before real data reaches
 // them is overwritten 2 trips later and never stored.
 template <int KIND, int K>
-__global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A) {
+__global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A0) {
+  const Args A = coeffs_in_vgprs(A0);
   static_assert(K >= 2 && K <= 4, "a 4-cell halo lane covers at most 4 levels");
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
