@@ -103,6 +103,12 @@ OP(mad_i32_i16, asm volatile("v_mad_i32_i16 %0, %1, %1, %0" : "+v"(x) : "v"(b)))
 OP(addc, asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(x) : : "vcc"))
 OP(ffbl, asm volatile("v_ffbl_b32 %0, %1" : "+v"(x) : "v"(b)))
 OP(bfrev, asm volatile("v_bfrev_b32 %0, %1" : "+v"(x) : "v"(b)))
+OP(cnd_vcc_e64, asm volatile("v_cndmask_b32_e64 %0, %0, %1, vcc" : "+v"(x) : "v"(b)))
+OP(cnd_vcc_set, asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(x) : "v"(b) : ))   // (run after vcc was written once: see k)
+OP(mix_cmp_cnd_vcc, asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n v_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(x), "+v"(y) : "v"(b) : "vcc"))
+OP(mix_cmp_cnd_sgpr, asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %2\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]" : "+v"(x), "+v"(y) : "v"(b) : "s20", "s21"))
+OP(mix_cmp_fma_cnd_vcc, asm volatile("v_cmp_lt_f32_e32 vcc, %0, %2\n v_fma_f32 %0, %0, %2, %2\n v_fma_f32 %0, %0, %2, %2\n v_cndmask_b32_e32 %1, %1, %2, vcc" : "+v"(x), "+v"(y) : "v"(b) : "vcc"))
+OP(mix_cmp_fma_cnd_sgpr, asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %2\n v_fma_f32 %0, %0, %2, %2\n v_fma_f32 %0, %0, %2, %2\n v_cndmask_b32_e64 %1, %1, %2, s[20:21]" : "+v"(x), "+v"(y) : "v"(b) : "s20", "s21"))
 OP(mix_scan4, asm volatile("v_pk_sub_i16 %1, %2, %3\n v_dot2_i32_i16 %1, %1, %1, 0\n v_cmp_gt_i32 vcc, %2, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc"
                            : "+v"(x), "+v"(y) : "v"(a), "v"(b) : "vcc"))
 OP(mix_scan6, asm volatile("v_sub_f32 %1, %2, %3\n v_sub_f32 %4, %3, %2\n v_mul_f32 %1, %1, %1\n v_fma_f32 %1, %4, %4, %1\n v_cmp_gt_f32 vcc, %2, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc"
@@ -117,6 +123,10 @@ template <> struct per_call<mix_alu5> { static constexpr int n = 5; };
 template <> struct per_call<mix_alu5_sgpr> { static constexpr int n = 5; };
 template <> struct per_call<mix_fma4_dsr1> { static constexpr int n = 4; };   // VALU instructions only
 template <> struct per_call<mix_scan4> { static constexpr int n = 4; };
+template <> struct per_call<mix_cmp_cnd_vcc> { static constexpr int n = 2; };
+template <> struct per_call<mix_cmp_cnd_sgpr> { static constexpr int n = 2; };
+template <> struct per_call<mix_cmp_fma_cnd_vcc> { static constexpr int n = 4; };
+template <> struct per_call<mix_cmp_fma_cnd_sgpr> { static constexpr int n = 4; };
 template <> struct per_call<mix_scan6> { static constexpr int n = 6; };
 
 struct Stamp { uint64_t cyc, w0, w1; uint32_t hwid, xcc; };
@@ -223,6 +233,11 @@ int main(int argc, char **argv) {
     sweep<pk_sub_i16>(iters); sweep<dot2_i32_i16>(iters); sweep<dot2_u32_u16>(iters); sweep<pk_add_f16>(iters); sweep<pk_mul_f16>(iters);
     sweep<dot2_f32_f16>(iters); sweep<mad_i32_i16>(iters); sweep<addc>(iters); sweep<ffbl>(iters); sweep<bfrev>(iters);
     sweep<mix_scan4>(iters / 4); sweep<mix_scan6>(iters / 4);
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "cnd")) {     // v_cndmask reading vcc (VOP2) against an SGPR pair (VOP3), alone and behind its compare
+    sweep<cnd_vcc>(iters / 4); sweep<cnd_vcc_e64>(iters / 4); sweep<cnd_sgpr>(iters); sweep<mix_cmp_cnd_vcc>(iters / 2); sweep<mix_cmp_cnd_sgpr>(iters / 2);
+    sweep<mix_cmp_fma_cnd_vcc>(iters / 4); sweep<mix_cmp_fma_cnd_sgpr>(iters / 4);
     return 0;
   }
   sweep<fma_vvv>(iters);
