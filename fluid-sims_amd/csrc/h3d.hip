@@ -2420,6 +2420,33 @@ extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
   TAU_HIP(hipSetDevice(h->device));
   return slab_timed(h, h->nzl - 2 * depth, slab_interior_body, depth);
 }
+// The whole slab in two pieces for the direct-halo ring's pipelined step: the x/y fluxes of every plane read no halo plane, so
+// they run while the halos of the step before are still arriving; the z kernel (fused kernel on small planes: the whole step)
+// follows once those have landed.  One timing interval spans both.
+extern "C" int tau3d_slab_xy_async(tau3d_t *h) {
+  if (!h) return tau::fail("tau3d_slab_xy: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  h->halo_fresh = false;
+  if (!h->split) return 0;                               // fused kernel: everything happens in tau3d_slab_z_async
+  const bool tm = h->timing && h->n_ev < 4096;
+  if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream)); h->evm_set[h->n_ev] = false; }
+  if (split_xy(h, 0, h->nzl, 0, 0, h->stream)) return 1;
+  if (tm) { TAU_HIP(hipEventRecord(h->evm[h->n_ev], h->stream)); h->evm_set[h->n_ev] = true; }
+  return 0;
+}
+extern "C" int tau3d_slab_z_async(tau3d_t *h) {
+  if (!h) return tau::fail("tau3d_slab_z: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  if (!h->split) return slab_timed(h, h->nzl, slab_edges_body, h->nzl);
+  const bool tm = h->timing && h->n_ev < 4096;
+  if (split_z(h, 0, h->nzl, 0, 0, !h->direct, h->stream)) return 1;
+  if (tm) {
+    TAU_HIP(hipEventRecord(h->ev1[h->n_ev], h->stream));
+    h->n_ev++;
+    h->ev_cells += (double)h->nzl * (double)h->plane_n;
+  }
+  return 0;
+}
 extern "C" int tau3d_slab_end_async(tau3d_t *h) {
   h->halo_fresh = false;
   h->cur ^= 1;             // std::swap x6, :1706-1711

@@ -120,6 +120,11 @@ int tau3d_slab_begin_async(tau3d_t *h);
 int tau3d_slab_edges_async(tau3d_t *h, int depth);
 int tau3d_slab_interior_async(tau3d_t *h, int depth);
 int tau3d_slab_end_async(tau3d_t *h);
+/* The pipelined step of the direct-halo ring (csrc/ring.hip): begin, tau3d_slab_xy_async (x/y fluxes of ALL planes: they read
+ * no halo plane, so the halos of the step before may still be arriving), <halos landed>, tau3d_slab_z_async (z fluxes + update
+ * of all planes; with the fused small-plane kernel: the whole step), <all-reduce(max); copy the boundary planes out>, end. */
+int tau3d_slab_xy_async(tau3d_t *h);
+int tau3d_slab_z_async(tau3d_t *h);
 /* fill own halos from own interior (periodic single domain) */
 int tau3d_fill_halo_periodic_async(tau3d_t *h);
 /* side 0 = low-z, 1 = high-z; which = 0 current (input) state, 1 = next (output) state.
