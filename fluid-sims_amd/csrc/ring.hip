@@ -14,8 +14,9 @@
 //                                                ncclAllReduce(max) on the two words of tau3d_max_ptr, in place
 //                                                record evX(n)
 //   slab_end        swap (host bookkeeping)
-// (TAU3D_RING_IPC: X carries the twelve halo copies only; S waits for them after the interior launch — they are long done —
-//  and runs the all-reduce itself, so nothing hops between streams on the critical path.)
+// (The direct transports, TAU3D_RING_IPC / _IPC_HOSTMAX, run another schedule by default — ring_step_pipelined below: x/y fluxes
+//  of ALL planes first, beside the halo copies of the step before, no edge / interior split.  TAU3D_RING_PIPELINE=0 gives them
+//  the table above, with X carrying the twelve halo copies only and the all-reduce on S behind the interior launch.)
 //
 // No host synchronisation between the pieces: tau3d_ring_step_async(n) only enqueues.  One communicator, used on ONE stream
 // (X), so RCCL sees its operations in one order on every rank.

@@ -12,7 +12,9 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 n = 512
 
 
-def run(nzl, transport):
+def run(nzl, transport, pipeline=True):
+    import os
+    os.environ["TAU3D_RING_PIPELINE"] = "1" if pipeline else "0"   # (read at tau3d_ring_create)
     best = 1e9
     for _ in range(reps):
         e = f.Tau3D(n, n, nzl)
@@ -50,6 +52,7 @@ print(f"512^3 single domain: {full:.3f} ms/step")
 for world in (2, 4, 8):
     nzl = n // world
     row = {"plain periodic slab": run(nzl, None), "ring local copies": run(nzl, f.RING_LOCAL), "ring rccl-to-self": run(nzl, f.RING_RCCL),
-           "ring ipc (direct halos) + rccl all-reduce": run(nzl, f.RING_IPC)}
+           "ring ipc (direct halos) + rccl all-reduce, edge / interior launches": run(nzl, f.RING_IPC, pipeline=False),
+           "ring ipc, pipelined step (default)": run(nzl, f.RING_IPC)}
     print(f"world {world}: {nzl} planes, share of the full step {full / world:.3f} ms | " +
           " | ".join(f"{k} {v:.3f} ms -> x{full / v:.2f}" for k, v in row.items()), flush=True)
