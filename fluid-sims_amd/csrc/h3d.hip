@@ -2348,6 +2348,15 @@ extern "C" int tau3d_slab_begin_async(tau3d_t *h) {
   }
   return halo_pack(h, 0, 1, true);   // controller of the step before (if pending) + clock of this one + received halos
 }
+// the controller / clock part alone (the pipelined ring step of the packed transports unpacks the halos later, before its z kernel)
+extern "C" int tau3d_slab_clock_async(tau3d_t *h) {
+  if (!h) return tau::fail("tau3d_slab_clock: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  hipLaunchKernelGGL(h3d::k_clock_turn, dim3(1), dim3(1), 0, h->stream, h->clk, h->end_pending ? 1 : 0);
+  TAU_LAUNCH_CHECK("k_clock_turn");
+  h->end_pending = false;
+  return 0;
+}
 extern "C" int tau3d_set_halo_direct(tau3d_t *h, int on) {
   if (!h) return tau::fail("tau3d_set_halo_direct: null handle");
   h->direct = on != 0;

@@ -389,9 +389,8 @@ static int ring_create_impl(tau3d_ring *r, tau3d_t *h, int rank, int world, int 
   TAU_HIP(hipEventCreateWithFlags(&r->evI, hipEventDisableTiming));
   TAU_HIP(hipEventCreateWithFlags(&r->evX, hipEventDisableTiming));
   TAU_HIP(hipEventCreateWithFlags(&r->evH, hipEventDisableTiming));
+  { const char *e = getenv("TAU3D_RING_PIPELINE"); r->pipelined = !(e && atoi(e) == 0); }
   if (r->direct()) {
-    const char *e = getenv("TAU3D_RING_PIPELINE");
-    r->pipelined = !(e && atoi(e) == 0);
     TAU_HIP(hipMalloc(&r->syncw, sizeof(float)));
     TAU_HIP(hipMemset(r->syncw, 0, sizeof(float)));
   }
@@ -702,12 +701,42 @@ static int ring_step_pipelined(tau3d_ring *r) {
   r->steps++;
   return 0;
 }
+// The same pipelining for the packed transports (rccl, host, local): the all-reduce goes FIRST on X (the next step's clock waits
+// for it alone), the send / recv group behind it runs beside the next step's x/y flux launch, and the received planes are
+// unpacked just before the z kernel.
+//   S: wait evX(n-1) [all-reduce]   clock   xy fluxes, ALL planes   wait evH(n-1) [exchange]   unpack   z + update + pack   record evI
+//   X: wait evI   all-reduce(max)(n)   record evX(n)   send / recv (n)   record evH(n)
+// Receive buffers: Recv(n) follows z(n), which follows unpack of what Recv(n-1) brought.  Send buffers: z(n+1) packs them after
+// evH(n), i.e. after this rank's sends of step n completed.
+static int ring_step_pipelined_packed(tau3d_ring *r) {
+  using namespace ring;
+  TAU_HIP(hipStreamWaitEvent(r->S, r->evX, 0));
+  if (tau3d_slab_clock_async(r->h)) return 1;
+  if (tau3d_slab_xy_async(r->h)) return 1;
+  TAU_HIP(hipStreamWaitEvent(r->S, r->evH, 0));
+  if (tau3d_unpack_halos_async(r->h, 0)) return 1;
+  if (tau3d_slab_z_async(r->h)) return 1;
+  TAU_HIP(hipEventRecord(r->evI, r->S));
+  TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
+  if (r->transport == TAU3D_RING_RCCL) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
+  else if (r->transport == TAU3D_RING_HOST && allreduce_host(r)) return 1;
+  TAU_HIP(hipEventRecord(r->evX, r->X));
+  switch (r->transport) {
+    case TAU3D_RING_RCCL: if (exchange_rccl(r)) return 1; break;
+    case TAU3D_RING_HOST: if (exchange_host(r)) return 1; break;
+    default: if (exchange_local(r)) return 1; break;
+  }
+  TAU_HIP(hipEventRecord(r->evH, r->X));
+  if (tau3d_slab_end_async(r->h)) return 1;
+  r->steps++;
+  return 0;
+}
 static int ring_step_impl(tau3d_ring *r, int nsteps) {
   TAU_HIP(hipSetDevice(r->device));
   if (!r->primed && ring_prime_impl(r)) return 1;
   if (r->pipelined) {
     for (int s = 0; s < nsteps; s++)
-      if (ring_step_pipelined(r)) return 1;
+      if (r->direct() ? ring_step_pipelined(r) : ring_step_pipelined_packed(r)) return 1;
     return 0;
   }
   const int E = r->edge;

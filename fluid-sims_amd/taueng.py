@@ -135,7 +135,7 @@ def load():
         "tau3d_step_edges_async": ([vp, i32, vp], i32),
         "tau3d_clock_end_async": ([vp], i32),
         "tau3d_slab_begin_async": ([vp], i32), "tau3d_slab_edges_async": ([vp, i32], i32),
-        "tau3d_slab_xy_async": ([vp], i32), "tau3d_slab_z_async": ([vp], i32),
+        "tau3d_slab_xy_async": ([vp], i32), "tau3d_slab_z_async": ([vp], i32), "tau3d_slab_clock_async": ([vp], i32),
         "tau3d_slab_interior_async": ([vp, i32], i32), "tau3d_slab_end_async": ([vp], i32),
         "tau3d_fill_halo_periodic_async": ([vp], i32),
         "tau3d_halo_send_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),

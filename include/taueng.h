@@ -123,6 +123,7 @@ int tau3d_slab_end_async(tau3d_t *h);
 /* The pipelined step of the direct-halo ring (csrc/ring.hip): begin, tau3d_slab_xy_async (x/y fluxes of ALL planes: they read
  * no halo plane, so the halos of the step before may still be arriving), <halos landed>, tau3d_slab_z_async (z fluxes + update
  * of all planes; with the fused small-plane kernel: the whole step), <all-reduce(max); copy the boundary planes out>, end. */
+int tau3d_slab_clock_async(tau3d_t *h);   /* tau3d_slab_begin_async without the unpack (packed transports: tau3d_unpack_halos_async follows before the z piece) */
 int tau3d_slab_xy_async(tau3d_t *h);
 int tau3d_slab_z_async(tau3d_t *h);
 /* fill own halos from own interior (periodic single domain) */
