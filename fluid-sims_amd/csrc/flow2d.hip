@@ -73,7 +73,7 @@ __device__ __forceinline__ float fasinh(float x) {
   return r;
 }
 __device__ __forceinline__ float minmodf(float a, float b) { // tau_burgers.cu:332-334
-  return (a * b <= 0.0f) ? 0.0f : copysignf(fminf(fabsf(a), fabsf(b)), a);
+  return __builtin_amdgcn_fmed3f(a, b, 0.0f);   // the median of (a, b, 0): one v_med3_f32 (differs only where a * b underflows to 0)
 }
 __device__ __forceinline__ int wrapi(int i, int n) { i %= n; return i < 0 ? i + n : i; }
 // periodic wrap of an index known to lie in [-n, 2n): two selects instead of an integer modulo
