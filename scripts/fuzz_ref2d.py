@@ -98,10 +98,10 @@ def sph():
         # An fp32 sum of n terms taken in arbitrary order is only defined to ~n eps / 2: 1e-5 is n = 335.  With hMul = 2.5 and a
         # compressed state a particle has 500-750 neighbours, and measured against the fp64 sum of the same pairs the REFERENCE is
         # then 1.0e-5 off and the engine 2.6e-6 (scratch check of round 4; the engine adds cell by cell in ascending order).  Past
-        # 300 neighbours per particle the density is therefore compared with the exact sum instead: the engine must be at least as
+        # 150 neighbours per particle on average the density is therefore compared with the exact sum instead: the engine must be at least as
         # close to it as the reference is, and within 1e-5.
         nb = e_pairs / N
-        if nb <= 300:
+        if nb <= 150:   # (the MEAN count: the worst particles of a compressed state hold twice as many)
             raise AssertionError(f"N={N} warm={warm} {kw} ({nb:.0f} neighbours per particle): {ex}")
         pos = st["pos"].astype(np.float64)
         h, m = float(np.float32(g_["h"])), float(np.float32(g_["mass"]))
