@@ -685,7 +685,14 @@ static int ring_step_pipelined(tau3d_ring *r) {
   TAU_HIP(hipEventRecord(r->evI, r->S));
   TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
   if (r->transport == TAU3D_RING_IPC) {
-    TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->S));
+    // Both all-reduces on X by default: ONE communicator used on ONE stream, the plainest contract RCCL offers (the max on S
+    // itself saves the S -> X -> S hop, ~1 % of a 64-plane step, but has RCCL order two user streams: TAU3D_RING_AR_ON_S=1).
+    static const bool ar_on_s = [] { const char *e = getenv("TAU3D_RING_AR_ON_S"); return e && atoi(e) != 0; }();
+    if (ar_on_s) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->S));
+    else {
+      TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
+      TAU_HIP(hipEventRecord(r->evX, r->X));   // (the next step's clock waits for it: top of this function)
+    }
     if (exchange_ipc(r, 1)) return 1;
     TAU_NCCL(g_rccl.AllReduce(r->syncw, r->syncw, 1, ncclFloat, ncclMax, r->comm, r->X));
     TAU_HIP(hipEventRecord(r->evH, r->X));
