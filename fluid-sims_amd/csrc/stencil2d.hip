@@ -49,7 +49,7 @@ struct Args {
 };
 
 // The per-cell coefficients as VGPR values: a VALU instruction with an SGPR operand issues at half rate on gfx950
-// (profiles/r02/valu_calib.txt) and the Gray-Scott cell has seven such operands among its ~22 instructions.  Same arithmetic.
+// (profiles/r02/valu_calib.txt); the viscosity cells have four to six such operands among their ~20 instructions.  Same arithmetic.
 #ifndef TAU_ST2_VREG
 #define TAU_ST2_VREG 1
 #endif
@@ -58,8 +58,10 @@ __device__ __forceinline__ float vreg(float s) {
   asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
   return v;
 }
+template <int KIND>
 __device__ __forceinline__ Args coeffs_in_vgprs(const Args &A0) {
   Args A = A0;
+  if (KIND == K_GS) return A;   // Gray-Scott is bandwidth bound: no gain, and the single-step kernel would drop from 6 to 5 waves per SIMD
 #if TAU_ST2_VREG
   A.dt = vreg(A0.dt); A.Du = vreg(A0.Du); A.Dv = vreg(A0.Dv); A.feed = vreg(A0.feed); A.kill = vreg(A0.kill);
   A.inv_dx2 = vreg(A0.inv_dx2); A.dx2 = vreg(A0.dx2);
@@ -150,7 +152,7 @@ __device__ __forceinline__ void cell(const Args &A, float uc, float ul, float ur
 // "ud" above is the row j+1 (the reference's jp), "uu" the row j-1 (jm).
 template <int KIND>
 __global__ __launch_bounds__(64 * WAVES) void k_march(const Args A0) {
-  const Args A = coeffs_in_vgprs(A0);
+  const Args A = coeffs_in_vgprs<KIND>(A0);
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
   unsigned wid = tau::xcd_swizzle(blockIdx.x, gridDim.x) * WAVES + (threadIdx.x >> 6);
@@ -234,7 +236,7 @@ __device__ __forceinline__ void row_step(const Args &A, const Lvl &up, const Lvl
 // them is overwritten 2 trips later and never stored.
 template <int KIND, int K>
 __global__ __launch_bounds__(64 * WAVES) void k_fused(const Args A0) {
-  const Args A = coeffs_in_vgprs(A0);
+  const Args A = coeffs_in_vgprs<KIND>(A0);
   static_assert(K >= 2 && K <= 4, "a 4-cell halo lane covers at most 4 levels");
   const int lane = threadIdx.x & 63;
   const unsigned nwork = (unsigned)(A.nstrips * A.nchunks);
