@@ -674,7 +674,7 @@ extern "C" int tau3d_ring_step_async(tau3d_ring_t *r, int nsteps) {
 // operations in issue order, and the issue order (max(n) on S, landed(n) on X, max(n+1) on S ...) is the same on every rank.
 // Writes into a neighbour's halo planes cannot overtake its reads: copies(n+2) — the next ones into the same allocation —
 // follow this rank's z(n+2), hence all-reduce(n+1), hence the neighbour's z(n+1), the last reader.
-// IPC_HOSTMAX (ranks sharing a device, tests): the same order with host all-reduce and host barrier, synchronously.
+// IPC_HOSTMAX (ranks sharing a device, tests): copies, then the host all-reduce whose barriers also say "copies landed".
 static int ring_step_pipelined(tau3d_ring *r) {
   using namespace ring;
   TAU_HIP(hipStreamWaitEvent(r->S, r->evX, 0));      // (HOSTMAX: the host all-reduce + copies of the step before, on X)
@@ -697,10 +697,10 @@ static int ring_step_pipelined(tau3d_ring *r) {
     TAU_NCCL(g_rccl.AllReduce(r->syncw, r->syncw, 1, ncclFloat, ncclMax, r->comm, r->X));
     TAU_HIP(hipEventRecord(r->evH, r->X));
   } else {
-    if (allreduce_host(r)) return 1;
+    // copies first: the host all-reduce behind them synchronises X (so this rank's copies have landed) before its first
+    // barrier — past that barrier every rank's copies have landed, and the reduced max follows two barriers later
     if (exchange_ipc(r, 1)) return 1;
-    TAU_HIP(hipStreamSynchronize(r->X));
-    if (r->sh && barrier(r->sh, "halo copies landed")) return 1;
+    if (allreduce_host(r)) return 1;
     TAU_HIP(hipEventRecord(r->evX, r->X));
   }
   if (tau3d_slab_end_async(r->h)) return 1;
