@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/../fluid-sims_amd"
 for f in h3d h2d sph flow2d stencil2d lbm; do
   EXTRA=$(make -pn 2>/dev/null | grep "^EXTRA_$f" | sed 's/^[^=]*= *//' | sed 's/\$(H3D_DEFS)//')
-  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 $EXTRA -S --cuda-device-only csrc/$f.hip -o /tmp/audit_$f.s 2>/dev/null
+  /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fno-slp-vectorize $EXTRA -S --cuda-device-only csrc/$f.hip -o /tmp/audit_$f.s 2>/dev/null
   python3 - /tmp/audit_$f.s $f <<'PY'
 import re,sys
 txt=open(sys.argv[1]).read(); lines=txt.split('\n')

@@ -237,20 +237,23 @@ def test_dense_cluster_takes_the_overflow_path(eng, oracle_built):
     e.close()
 
 
-@pytest.mark.parametrize("box,what", [(0.2, "rounds through the stage"), (0.15, "rounds + re-scan beyond the kept masks"),
-                                      (0.1, "spread beyond the stage: global walk")])
-def test_dense_state_one_lane_per_particle(eng, oracle_built, box, what):
-    """140 000 particles (one lane per particle) packed into box x box: ~410 / ~690 / ~1 600 particles per cell, i.e. 1 200 to
+@pytest.mark.parametrize("N,box,what", [(140000, 0.2, "rounds through the stage"), (140000, 0.15, "rounds + re-scan beyond the kept masks"),
+                                        (40000, 0.1, "spread beyond the stage: global walk")])
+def test_dense_state_one_lane_per_particle(eng, oracle_built, N, box, what):
+    """140 000 / 40 000 particles (one lane per particle) packed into box x box: ~470 / ~790 / ~1 700 particles per cell, i.e. 1 200 to
     4 800 candidates per row range — the three candidate ranges of a workgroup no longer fit the LDS stage and are walked in
     rounds (sph.hip, density_tiled / accel_tiled); at 0.15 a row exceeds the (WPR + OVW) * 32 = 2 048 candidates whose hit masks
     the density pass hands to the force pass (those blocks are scanned again); at 0.1 the ranges of a workgroup's first and last
     particle lie further apart than the stage is long and the global walk takes over.  One sub-step against the oracle."""
-    N = 140000
     rng = np.random.default_rng(11)
     pos = (0.3 + box * rng.random((N, 2))).astype(np.float32)
     vel = (0.05 * rng.standard_normal((N, 2))).astype(np.float32)
     o = oracle_built.OracleSph(N)
-    e = eng.Sph2D(N)
+    os.environ["TAU_SPH_LPP"] = "1"          # (the default from 131 072 particles on; the third case is smaller to keep the oracle short)
+    try:
+        e = eng.Sph2D(N)
+    finally:
+        del os.environ["TAU_SPH_LPP"]
     e.upload(pos, vel)
     o.set_state(pos, vel)
     g = e.grid()
