@@ -422,7 +422,9 @@ def main():
                     ring.close()
                 eng.close()
                 return None, err
-            info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)", transport=TRANSPORT_NAMES[transport])
+            info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)", transport=TRANSPORT_NAMES[transport],
+                        step_schedule=("edge / interior launches (TAU3D_RING_PIPELINE=0)" if os.environ.get("TAU3D_RING_PIPELINE", "1") == "0"
+                                       else "pipelined: x/y fluxes of all planes overlap the halo transfer of the step before"))
 
             def close_all():
                 ring.close()
