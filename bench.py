@@ -116,7 +116,7 @@ def input_variants(f, torch, dev, n, steps=20):
     # 0.8, bow shock standing, wake formed; the impulsive start of the headline runs away after ~55 steps and the ramped one before
     # step 3250, in the reference's own kernel as in this engine: profiles/r04/long_run_512_*.txt, tests/test_gpu_ref3d.py).
     # forced_reciprocal_weights: the headline input with TAU3D_WENO_RCP=1 — the general-form bodies flux_xy_body<false> /
-    # update_z_body<false> a state beyond |primitive| 6e4 would take (no sane 512^3 state does).
+    # update_z_body<false> a state beyond |primitive| 2.5e3 would take (no sane 512^3 state does).
     late_warm = 2500 if n >= 512 else 400
     for name, mode, warm, body, rcp in (("reference_ic_50_warmup", 0, 50, True, False), ("developed_no_body", 1, 10, False, False),
                                         ("developed_late", 0, late_warm, True, False), ("forced_reciprocal_weights", 1, 25, True, True)):
@@ -561,7 +561,7 @@ def main():
                           "grid": [n, n, n], "decomposition": f"z-slab x{world}" if use_ring else "single domain",
                           "halo_planes": 3, "t": clk.t, "d_tau": clk.d_tau, "maxs": clk.maxs,
                           # which body of the kernels the timed steps ran (tau3d_field_range): the common-denominator WENO weights
-                          # while every |primitive| <= 6e4, else the reciprocal form
+                          # while every |primitive| <= 2.5e3, else the reciprocal form
                           "weno_form": "fast (common denominator)" if frange[2] else "reciprocal",
                           "max_abs_primitive": round(float(max(frange[0], frange[1])), 1) if max(frange[0], frange[1]) < 3e38 else "inf",
                           "timed_steps_after_start": [args.warmup, args.warmup + args.steps]},

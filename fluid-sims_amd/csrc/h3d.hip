@@ -251,8 +251,11 @@ __device__ __forceinline__ int wrap_near(int i, int n, bool nearby) {
 // takes the FAST body only when that and the inflow state are within W_FLIM; otherwise the reciprocal form.  The
 // choice is one scalar branch at the top of the kernel, identical for every workgroup and every slab of a step.
 // Mach-100 flow (stagnation pressure 1.3e4) runs FAST.
+// Round 5: the kernel pair's weno_cell carries t unscaled (one multiply less per measure; derivation at weno_cell), which
+// closes its fast window at 2 760 — W_FLIM is the one window every kernel uses, so the fused kernel's scaled forms, good to
+// 6e4, switch at 2.5e3 as well.  Mach-100 runs stay below 700 until the reference scheme itself runs away.
 constexpr float WLAM = 0x1p-10f;
-constexpr float W_FLIM = 6.0e4f;
+constexpr float W_FLIM = 2.5e3f;
 // Both operands are tested on their own: fmaxf(NaN, x) returns x, so a NaN range (nothing known about the input) would
 // otherwise select the fast form — the one case where t^4 may overflow.  A NaN comparison is false: reciprocal form.
 __host__ __device__ __forceinline__ bool fast_form(float fmax_in, float in_fmax) { return (fmax_in <= W_FLIM) && (in_fmax <= W_FLIM); }
@@ -281,31 +284,63 @@ __device__ __forceinline__ float lane_below(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
 }
 
-// cell-centred: m2,m1,c,p1,p2 around a cell -> Lhi = left state at its high face, Rlo = right state at its low face
+// cell-centred: m2,m1,c,p1,p2 around a cell -> Lhi = left state at its high face, Rlo = right state at its low face.
+// Round 5: the weighted sum is taken around the CENTRAL candidate.  With i_k = 1 / t_k^2 (up to a common factor) and the
+// candidates q_k (in sixths, relative to the cell): q0 - q1 = 2 (E0 - E1), q2 - q1 = E1 - E2, so
+//     Lhi = c + [ (2 D2 + D1) + (2 P + 3 Q) / (i0 + 6 i1 + 3 i2) ] / 6,      P = i0 (E0 - E1),  Q = i2 (E1 - E2)
+//     Rlo = c - [ (2 D1 + D2) + (3 P + 2 Q) / (3 i0 + 6 i1 + i2) ] / 6
+// — the linear weights 0.1 / 0.6 / 0.3 have become the integers of the two sums (6 is the only one that is not an inline
+// constant), P and Q serve both states, and the smoothness measures carry the common factor 12/13:
+//     t_k = E_k^2 + (3/13) e_k^2 + (12/13) eps        (two fma and one multiply; the round-2 form took four instructions)
+// 44 VALU instructions + 2 reciprocals per cell and variable (round 4: 53 + 2; the reference: ~150 + 6 divisions).
+// Fast form: i_k = (t_i t_j)^2 — t is NOT scaled any more (the scale cost a multiply per measure): with every primitive
+// <= F, |D| <= 2F, |E| <= 4F, |e| <= 8F, t <= 30.8 F^2, i <= 9.0e5 F^8, |2P + 3Q| <= 5 * 8F * i = 3.6e7 F^9 < FLT_MAX for
+// F < 2760 (W_FLIM = 2.5e3); the all-smooth stencil sits at t = 9.2e-7, i = 7e-25: no denormals anywhere.
+constexpr float WENO_TE = (12.f / 13.f) * WENO_EPS, WENO_TC = 3.f / 13.f;
+__device__ __forceinline__ float smooth_m(float E, float e) { return __builtin_fmaf(WENO_TC * e, e, __builtin_fmaf(E, E, WENO_TE)); }
+template <bool FAST>
+__device__ __forceinline__ void weno_inv(float t0, float t1, float t2, float &i0, float &i1, float &i2) {
+  if (FAST) {
+    const float u0 = t1 * t2, u1 = t0 * t2, u2 = t0 * t1;
+    i0 = u0 * u0; i1 = u1 * u1; i2 = u2 * u2;
+  } else {
+    i0 = rcp(t0 * t0); i1 = rcp(t1 * t1); i2 = rcp(t2 * t2);
+  }
+}
 template <bool FAST>
 __device__ __forceinline__ void weno_cell(float m2, float m1, float c0, float p1, float p2, float &Lhi, float &Rlo) {
   const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
   const float E0 = D1 - D0, E1 = D2 - D1, E2 = D3 - D2;
-  // The one-sided slopes 3 D_a - D_b and the candidates 5 D_a - 2 D_b are written on the SECOND differences and with the
-  // factors 2 and 4 only: 3.0 and 5.0 are not inline constants, a VOP3 v_fma cannot carry a literal on gfx950, so hipcc
-  // parks them in SGPRs — and an SGPR source halves the issue rate (profiles/r02/valu_calib.txt: 4.3 against 2.3 cycles).
-  // 3 D1 - D0 = 2 D1 + (D1 - D0);  5 D1 - 2 D0 = 2 (3 D1 - D0) - D1.
-  const float eL = 2.f * D1 + E0, eR = 2.f * D2 - E2;   // 3 D1 - D0, 3 D2 - D3
-  float w0, w1, w2; // 0.1 i0, 0.6 i1, 0.3 i2 with i_k = 1 / t_k^2 up to a common factor
-  weno_weights<FAST>(smooth_t<FAST>(sd_term<FAST>(E0), eL), smooth_t<FAST>(sd_term<FAST>(E1), D1 + D2),
-                     smooth_t<FAST>(sd_term<FAST>(E2), eR), w0, w1, w2);
-  float sumL, sumR;
-  {
-    float num = w0 * (2.f * eL - D1) + w1 * (2.f * D2 + D1) + w2 * (4.f * D2 - D3);
-    sumL = w0 + w1 + w2;
-    Lhi = c0 + num * (rcp(sumL) * (1.f / 6.f));
-  }
-  { // mirrored roles: a0 = 0.1 i2, a1 = 0.6 i1, a2 = 0.3 i0
-    float a0 = (1.f / 3.f) * w2, a2 = 3.f * w0;
-    float num = a0 * (D2 - 2.f * eR) - w1 * (2.f * D1 + D2) + a2 * (D0 - 4.f * D1);
-    sumR = a0 + w1 + a2;
-    Rlo = c0 + num * (rcp(sumR) * (1.f / 6.f));
-  }
+  // one-sided slopes 3 D1 - D0 = 2 D1 + E0 and 3 D2 - D3 = 2 D2 - E2: the factor 2 is an inline constant, 3.0 is not (a VOP3
+  // v_fma cannot carry a literal on gfx950: hipcc parks it in an SGPR, and an SGPR source halves the issue rate)
+  const float eL = __builtin_fmaf(2.f, D1, E0), eR = __builtin_fmaf(2.f, D2, -E2);
+  float i0, i1, i2;
+  weno_inv<FAST>(smooth_m(E0, eL), smooth_m(E1, D1 + D2), smooth_m(E2, eR), i0, i1, i2);
+  const float P = i0 * (E0 - E1), Q = i2 * (E1 - E2);
+  const float S = P + Q;
+  const float M = __builtin_fmaf(i1, 6.f, i0 + i2);
+  const float sumL = __builtin_fmaf(2.f, i2, M), sumR = __builtin_fmaf(2.f, i0, M);
+  const float numL = __builtin_fmaf(2.f, S, Q), numR = __builtin_fmaf(2.f, S, P);
+  Lhi = __builtin_fmaf(__builtin_fmaf(numL, rcp(sumL), __builtin_fmaf(2.f, D2, D1)), 1.f / 6.f, c0);
+  Rlo = __builtin_fmaf(__builtin_fmaf(numR, rcp(sumR), __builtin_fmaf(2.f, D1, D2)), -1.f / 6.f, c0);
+}
+// Lhi alone: the same arithmetic, instruction for instruction (the ring cells around a k_flux_xy tile, whose other state
+// nobody reads).  Rlo of a cell is Lhi of the mirrored stencil — every difference changes sign exactly, the measures and
+// the sums are symmetric — so the ring's high side calls this with its five cells in reverse order and the face it feeds
+// gets bit for bit the state the neighbouring tile's own cell computes with weno_cell.
+template <bool FAST>
+__device__ __forceinline__ float weno_cell_hi(float m2, float m1, float c0, float p1, float p2) {
+  const float D0 = m1 - m2, D1 = c0 - m1, D2 = p1 - c0, D3 = p2 - p1;
+  const float E0 = D1 - D0, E1 = D2 - D1, E2 = D3 - D2;
+  const float eL = __builtin_fmaf(2.f, D1, E0), eR = __builtin_fmaf(2.f, D2, -E2);
+  float i0, i1, i2;
+  weno_inv<FAST>(smooth_m(E0, eL), smooth_m(E1, D1 + D2), smooth_m(E2, eR), i0, i1, i2);
+  const float P = i0 * (E0 - E1), Q = i2 * (E1 - E2);
+  const float S = P + Q;
+  const float M = __builtin_fmaf(i1, 6.f, i0 + i2);
+  const float sumL = __builtin_fmaf(2.f, i2, M);
+  const float numL = __builtin_fmaf(2.f, S, Q);
+  return __builtin_fmaf(__builtin_fmaf(numL, rcp(sumL), __builtin_fmaf(2.f, D2, D1)), 1.f / 6.f, c0);
 }
 
 // ---- the r01 forms of the three reconstructions (3.0 / 5.0 factors, SGPR-resident): the fused k_step keeps them — with
@@ -383,13 +418,11 @@ __device__ __forceinline__ void weno_cell_r01(float m2, float m1, float c0, floa
   }
 }
 
-// one edge state of a cell only (HI: left state at its high face, else right state at its low face): the same
-// arithmetic as weno_cell, for the ring cells around a tile whose other state nobody reads
+// one edge state of a cell only (HI: left state at its high face, else right state at its low face): bit for bit what
+// weno_cell returns for that side
 template <bool FAST, bool HI>
 __device__ __forceinline__ float weno_cell_side(float m2, float m1, float c0, float p1, float p2) {
-  float Lhi, Rlo;
-  weno_cell<FAST>(m2, m1, c0, p1, p2, Lhi, Rlo);
-  return HI ? Lhi : Rlo;
+  return HI ? weno_cell_hi<FAST>(m2, m1, c0, p1, p2) : weno_cell_hi<FAST>(p2, p1, c0, m1, m2);
 }
 
 __device__ __forceinline__ void prim_floor(Prim &q) { // :565-571
@@ -491,7 +524,15 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   // 1e15 times the rounding error of E* = ((s_K - un_K) E_K ...) / (s_K - s_M).  The reference survives such a face only when
   // its IEEE division happens to return (s_K E_K) / s_K = E_K exactly; a reciprocal-multiply never does, and the energy flux
   // came out at +-1e7 (found by scripts/fuzz_ref3d.py on thin anisotropic grids; round 4).
-  const float g = (sM - unK) * iden;
+  // Round 5: the increments are then rounded to what the reference's own formulation resolves.  It forms U* = U_K (s_K - un_K) /
+  // (s_K - s_M) and E* = (...) / (s_K - s_M) and subtracts U_K: the ratio is fl(1 + g), the energy fl(E_K + dE).  Between two
+  // floored densities (1e-30 either side of the face, sound speeds of 1e15) s_M is a ratio below its denominator guard — a
+  // one-ulp difference of the two WENO pressures makes it 3e4 — and the reference never sees it: g = 1e-10 vanishes in fl(1 + g).
+  // Formed directly and unrounded, s_K dU carried that s_M into an energy flux of 4e4 as soon as the two pressures differed in
+  // the last bit (tests/golden/weno_undershoot_yline.json with round 5's WENO rounding; round 4's happened to give equal
+  // pressures).  (x + 1) - 1 and (E + d) - E: four full-rate adds; elsewhere g = O(0.01 .. 1) and the rounding is the
+  // reference's own 6e-8 of the conserved state.
+  const float g = ((sM - unK) * iden + 1.f) - 1.f;
   const float dR = rK * g;
   Cons dU;
   dU.c[0] = dR;
@@ -500,7 +541,7 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   dU.c[2] = dR * ((axis == 1) ? sK : vK);
   dU.c[3] = dR * ((axis == 2) ? sK : wK);
   const float EK = left ? UL.c[4] : UR.c[4], EvK = left ? UL.c[5] : UR.c[5];
-  dU.c[4] = ((sM - unK) * EK - pK * unK + pStar * sM) * iden;
+  dU.c[4] = (EK + ((sM - unK) * EK - pK * unK + pStar * sM) * iden) - EK;
   dU.c[5] = EvK * g;
   // The blend  F = (1 - alpha) [F_K + s_K dU] + alpha [s_R F_L - s_L F_R + s_L s_R (U_R - U_L)] / (s_R - s_L)  (:441-459)
   // as ONE linear combination of F_L, F_R, dU and U_R - U_L: the coefficients are picked once (two selects) instead of picking
@@ -1089,13 +1130,13 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
     const int m = r / RING, ln = r - m * RING;
     const bool isx = ln < YT;
     const int c0 = isx ? (ln + HALO) * XPXS + (side ? XT + HALO : HALO - 1) : (side ? YT + HALO : HALO - 1) * XPXS + (ln - YT + HALO);
-    const int st = isx ? 1 : XPXS;
+    // one-sided (round 5): the high ring walks its five cells in reverse — Rlo of a cell is Lhi of the mirrored stencil, bit
+    // for bit (weno_cell_hi) — so a ring task pays for the one state that is read
+    const int st0 = isx ? 1 : XPXS, st = side ? -st0 : st0;
     const float *p = &sP[0][0] + m * XPLANE + c0;
-    float Lhi, Rlo;
-    weno_cell<FAST>(p[-2 * st], p[-st], p[0], p[st], p[2 * st], Lhi, Rlo);
     float *dst = side ? (isx ? &S.sRxT[0][0] + m * YT + ln : &S.sRyT[0][0] + m * XT + (ln - YT))
                       : (isx ? &S.sLx0[0][0] + m * YT + ln : &S.sLy[0][0][0] + m * ((YT + 1) * XT) + (ln - YT));
-    *dst = side ? Rlo : Lhi;
+    *dst = weno_cell_hi<FAST>(p[-2 * st], p[-st], p[0], p[st], p[2 * st]);
   };
   if (RTASKS >= XNT || tid < RTASKS) ring_task(tid);
   if (RTASKS > XNT && wave == wA) ring_task(XNT + lane);

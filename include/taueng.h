@@ -156,7 +156,7 @@ int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, size_t *nfloat
 int tau3d_max_ptr(tau3d_t *h, float **p);
 /* Diagnostics (synchronises): *read_max = the largest |primitive| the last launched step was told its input holds,
  * *written_max = the largest it (or init / upload since) wrote, *fast_form = 1 if that launch took the
- * common-denominator WENO weights, 0 if the reciprocal form (input range above 6e4).  Any pointer may be NULL. */
+ * common-denominator WENO weights, 0 if the reciprocal form (input range above 2.5e3).  Any pointer may be NULL. */
 int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast_form);
 /* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state (or the solid mask) through them
  * says so here before the next step (tau3d_init / tau3d_upload_* do it themselves): the field range is measured again and

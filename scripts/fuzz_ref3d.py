@@ -62,8 +62,16 @@ while time.time() < t_end:
         # the reference's own result is an accident of rounding there); they appear on thin anisotropic grids a step or two
         # before the state leaves the sane range
         us = undershoot_cells(st, r.solid_mask())
+        want = r.download()
+        if not all(np.isfinite(a[r.solid_mask() == 0]).all() for a in want):
+            # the REFERENCE's own step returns inf / nan from this input (a thin anisotropic grid a step before its blow-up: encoded
+            # values below 30 are still velocities of 1e7): nothing to compare with (round 5: seed 11, 224 x 88 x 46 after 23 steps —
+            # four cells non-finite in the reference kernel's output and in the engine's alike)
+            r.close()
+            skipped += 1
+            continue
         degenerate += int(us.any())
-        assert_parity(e.download(), r.download(), mask=(r.solid_mask() == 0) & ~us, what=f"{(nx, ny, nz)} split={split} rcp={rcp} mode={mode} warm={warm}")
+        assert_parity(e.download(), want, mask=(r.solid_mask() == 0) & ~us, what=f"{(nx, ny, nz)} split={split} rcp={rcp} mode={mode} warm={warm}")
         assert us.any() or abs(m - m_ref) <= 1e-5 * max(m_ref, 1e-30), f"max wavespeed {m} vs {m_ref}"
         r.close()
         n += 1

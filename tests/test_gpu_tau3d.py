@@ -139,15 +139,17 @@ def test_deterministic(eng):
     assert outs[0][1] == outs[1][1]
 
 
-@pytest.mark.parametrize("warm,zoff", [(12, -40), (100, -4), (60, -4), (60, -40)])
+@pytest.mark.parametrize("warm,zoff", [(12, -40), (40, -4), (50, -4), (50, -40)])
 def test_full_size_slab_vs_oracle(eng, oracle_built, warm, zoff):
     """BASELINE size 512^3 (the kernel pair bench.py times): after an impulsive warm-up, one step on the GPU; an 8-plane
     slab is recomputed by the oracle from the same input planes.  (12, -40): off-centre cut through sphere and shock;
-    (100, -4): the planes through the sphere's centre — stagnation line and bow-shock stand-off — after 100 steps.
-    After 60 steps the impulsive start has just evacuated the lee side of the sphere: the first fluid cells behind the wall
-    sit at rho = 3e-5 (1/600 of the free stream) between a 0.1-density wall state and a 60-unit velocity jump, and one or
-    two of the 1.7 M cells of a slab land at 1.2 - 1.5e-5 against the oracle — the round-2 kernels too (scratch measurement
-    in DESIGN §2).  Those two cases assert exactly that: at most 3 cells beyond 1e-5, none beyond 2.5e-5."""
+    (40, -4): the planes through the sphere's centre — stagnation line and bow-shock stand-off.
+    After 50 steps — the last sane state of this start: it runs away after ~55, in the reference's own kernel too
+    (profiles/r04/long_run_512_*.txt; rounds 2-4 ran these cases after 60 and 100 steps, i.e. on states between 4e11 and
+    3e38) — the impulsive start has evacuated the lee side of the sphere: the first fluid cells behind the wall sit at
+    rho = 3e-5 (1/600 of the free stream) between a 0.1-density wall state and a 60-unit velocity jump, and a few of the
+    1.7 M cells of a slab land at 1.2 - 1.5e-5 against the oracle.  Those two cases assert exactly that: at most 3 cells
+    beyond 1e-5, none beyond 2.5e-5."""
     n = 512
     e = eng.Tau3D(n)
     assert e.is_split()
@@ -167,7 +169,7 @@ def test_full_size_slab_vs_oracle(eng, oracle_built, warm, zoff):
     want = o.interior(out)
     fluid = o.interior([o.solid])[0] == 0
     assert fluid.sum() < fluid.size, "slab should intersect the body"
-    if warm == 60:
+    if warm == 50:
         from tests.parity import conserved
         worst = np.zeros(fluid.shape)
         for g, w in zip(got[:4], want[:4]):
@@ -177,6 +179,7 @@ def test_full_size_slab_vs_oracle(eng, oracle_built, warm, zoff):
         for g, w, s in zip(Ug[:5], Uw[:5], sc[:5]):
             worst = np.maximum(worst, np.abs(g - w) / s)
         worst = worst[fluid]
+        print('cells beyond 1e-5:', int((worst > 1e-5).sum()), 'worst', worst.max())
         assert int((worst > 1e-5).sum()) <= 3 and worst.max() <= 2.5e-5, (int((worst > 1e-5).sum()), worst.max())
         e.close()
         return
@@ -186,7 +189,7 @@ def test_full_size_slab_vs_oracle(eng, oracle_built, warm, zoff):
 
 
 # ---- WENO weight form: the step kernel takes the common-denominator weights when the state it reads
-# ---- is within 6e4 in magnitude, the reciprocal form otherwise — both against the same oracle
+# ---- is within 2.5e3 in magnitude (W_FLIM, h3d.hip), the reciprocal form otherwise — both against the same oracle
 def _explicit_vs_oracle(eng, oracle_built, shape, fields, dt, gain=1.0, split=None, **par):
     import ctypes
     nx, ny, nz = shape
@@ -243,7 +246,7 @@ def test_weight_form_follows_the_field_range(eng, oracle_built, shape, split):
     def _explicit_vs_oracle_(*a, **k):
         return _explicit(*a, split=split, **k)
     st, dt, rng = _developed(eng, shape, 25 if shape[0] < 100 else 12)
-    assert rng[2] and 99.9 <= rng[0] < 6e4 and 99.9 <= rng[1] < 6e4          # Mach-100 run: fast form, |u| = 100 seen
+    assert rng[2] and 99.9 <= rng[0] < 2.5e3 and 99.9 <= rng[1] < 2.5e3          # Mach-100 run: fast form, |u| = 100 seen
     got, want, fluid, rng, m = _explicit_vs_oracle_(eng, oracle_built, shape, st, dt)
     assert rng[2]
     assert_parity(got, want, mask=fluid, what="fast form")
@@ -258,7 +261,7 @@ def test_weight_form_follows_the_field_range(eng, oracle_built, shape, split):
     big[4] += np.float32(np.log(1e5))
     big[5] += np.float32(np.log(1e5))
     got, want, fluid, rng, m = _explicit_vs_oracle_(eng, oracle_built, shape, big, dt * 1e-3, tau_vib=1e30)
-    assert not rng[2] and rng[0] > 6e4
+    assert not rng[2] and rng[0] > 2.5e3
     rep = report(got, want, mask=fluid)
     assert all(rep[k] < 1e-5 for k in CONS) and rep["xi"] < 1e-5 and rep["lam"] < 1e-5, rep
     assert m[0] == pytest.approx(m[1], rel=1e-5)
@@ -271,7 +274,7 @@ def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built, split):
     shape = (32, 24, 16)
     nx, ny, nz = shape
     rng = np.random.default_rng(5)
-    F = 5.5e4
+    F = 2.3e3
     sgn = lambda: rng.choice([-1.0, 1.0], size=(nz, ny, nx))
     mag = lambda lo: np.where(rng.random((nz, ny, nx)) < 0.5, lo, F)
     r, p, ev = 1.0 + rng.random((nz, ny, nx)), mag(1.0), mag(1e-3)
@@ -280,14 +283,14 @@ def test_fast_weights_at_the_edge_of_their_window(eng, oracle_built, split):
     fields = [a.astype(np.float32) for a in fields]
     run = lambda: _explicit_vs_oracle(eng, oracle_built, shape, fields, 1e-8, split=split, tau_vib=1e30)
     got, want, fluid, fr, m = run()
-    assert fr[2] and 5e4 < fr[0] <= 6e4, fr
+    assert fr[2] and 2e3 < fr[0] <= 2.5e3, fr
     assert all(np.isfinite(g).all() for g in got) and all(np.isfinite(w_).all() for w_ in want)
     rep = report(got, want, mask=fluid)
     got2, _, _, fr2, _ = _forced_reciprocal(run)
     assert not fr2[2]
     rep2 = report(got2, want, mask=fluid)
     print("edge", {k: (f"{rep[k]:.1e}", f"{rep2[k]:.1e}") for k in CONS})
-    # input this wild (every face a 1e5 jump) is ill-conditioned for any fp32 evaluation — the reciprocal form, whose
+    # input this wild (every face a 5e3 jump) is ill-conditioned for any fp32 evaluation — the reciprocal form, whose
     # arithmetic is the reference's, is itself 3e-5 from the oracle, and re-associating one product moves either
     # form by that much: the bar is the same order of magnitude, and no overflow
     worst, worst2 = max(rep[k] for k in CONS), max(rep2[k] for k in CONS)
