@@ -1117,7 +1117,15 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
 #pragma unroll
     for (int m = 0; m < 6; m++) S.sLxT[m][ty] = Lxo[m];
   }
-  const int wA = (int)((unsigned)z % (unsigned)XNW), wC = (wA + 2) % XNW;
+#ifndef TAU3D_XY_ROT
+#define TAU3D_XY_ROT 0
+#endif
+#ifndef TAU3D_XY_WC
+#define TAU3D_XY_WC 2
+#endif
+  // the waves that take the extra rounds rotate with the plane AND (TAU3D_XY_ROT) with the tile: the workgroups resident on a CU
+  // at one time are tiles of one or two planes, and the extra rounds of all of them sat on the same two SIMDs
+  const int wA = (int)((unsigned)(z + TAU3D_XY_ROT * (bx + 3 * by)) % (unsigned)XNW), wC = (wA + TAU3D_XY_WC) % XNW;
   // The ring: the cells at x = -1 and y = -1 give their LEFT states (of the tile's low faces), those at x = XT and y = YT
   // their RIGHT states (of the far faces).  One lane per (ring cell, variable) — 2 x 48 cells x 6 variables = 576 tasks,
   // one round of all eight waves and a 64-task remainder on one wave (rotating with the plane).  With one lane per ring

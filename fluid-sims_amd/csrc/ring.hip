@@ -145,6 +145,7 @@ struct Shared {
   std::atomic<uint64_t> ready;      // MAGIC ^ job_key once rank 0 has filled the header
   int32_t world, transport;
   uint64_t slot_bytes;              // host transport: bytes of ONE packed buffer (a side); 0 otherwise
+  uint64_t created_ns;              // CLOCK_REALTIME when rank 0 made the file: tells a failed rank 0 of THIS launch from a leftover
   std::atomic<int32_t> bar_count, bar_gen;
   std::atomic<int32_t> status[MAX_WORLD];   // 0 unknown, 1 ready, 2 failed
   float maxw[MAX_WORLD][2];
@@ -161,6 +162,11 @@ struct Shared {
 static size_t shared_bytes(int world, size_t slot) { return ((sizeof(Shared) + 4095) & ~(size_t)4095) + (size_t)world * 2 * slot; }
 static char *slot_ptr(Shared *sh, int rank, int side) {
   return (char *)sh + ((sizeof(Shared) + 4095) & ~(size_t)4095) + ((size_t)rank * 2 + side) * sh->slot_bytes;
+}
+static uint64_t realtime_ns() {
+  timespec ts;
+  clock_gettime(CLOCK_REALTIME, &ts);
+  return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
 }
 static double now_s() {
   timespec ts;
@@ -253,6 +259,10 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
   if (r->rank == 0) {
     // Rank 0 builds the file under a private name and rename()s it into place once the header is complete: whoever opens
     // `path` sees either nothing, a file of an EARLIER job (another key: ignored below), or this job's finished header.
+    // First thing, before streams / RCCL / IPC handles are made: whatever an earlier job left under this name goes (a failed
+    // job leaves its file for its own waiting peers, tau3d_ring_destroy) — the window in which a peer of THIS launch can pick
+    // up a stale same-key file is then the start-up skew of the ranks, and what it may still find there is refused below.
+    unlink(path);
     char tmp[300];
     snprintf(tmp, sizeof tmp, "%s.%ld.tmp", path, (long)getpid());
     unlink(tmp);
@@ -264,10 +274,12 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
     if (m == MAP_FAILED) { unlink(tmp); return tau::fail("tau3d_ring: mmap(%s): %s", tmp, strerror(errno)); }
     Shared *sh = new (m) Shared();   // ftruncate zero-filled it; the atomics start at 0
     sh->world = r->world; sh->transport = r->transport; sh->slot_bytes = slot;
+    sh->created_ns = realtime_ns();
     r->sh = sh; r->sh_bytes = bytes;
     return 0;   // the caller puts the id in, publishes `ready` and calls ring_publish
   }
   const double t0 = now_s();
+  const uint64_t entered_ns = realtime_ns();
   int spins = 0;
   for (;;) {   // wait for THIS job's file: an older one under the same name carries another key
     fd = open(path, O_RDWR);
@@ -277,7 +289,19 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
         void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
         if (m != MAP_FAILED) {
           Shared *sh = (Shared *)m;
-          if (sh->ready.load(std::memory_order_acquire) == (MAGIC ^ key)) {
+          // A file of THIS launch cannot have passed a barrier (this rank has not arrived at one), cannot hold a failed rank 0
+          // that this rank should follow into a fresh start, and cannot have this rank's slot taken: any of the three says
+          // "left behind by an earlier job with the same key" — keep waiting for rank 0 to replace it.
+          const bool mine = sh->ready.load(std::memory_order_acquire) == (MAGIC ^ key);
+          const bool rank0_failed = sh->status[0].load(std::memory_order_acquire) == 2;
+          if (mine && rank0_failed && sh->created_ns >= entered_ns) {   // made after this rank started waiting: this launch's rank 0
+            munmap(m, bytes);
+            close(fd);
+            return tau::fail("tau3d_ring: rank 0 failed before the ring was set up (rendezvous file %s)", path);
+          }
+          const bool stale = sh->bar_gen.load(std::memory_order_acquire) != 0 || rank0_failed ||
+                             sh->status[r->rank].load(std::memory_order_acquire) != 0;
+          if (!stale && mine) {
             close(fd);
             if (sh->world != r->world || sh->transport != r->transport || sh->slot_bytes != slot) {
               const int w = sh->world, t = sh->transport;

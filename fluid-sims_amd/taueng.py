@@ -317,6 +317,9 @@ class Tau3DRing:
         if job_key is None:
             import zlib
             tag = "|".join(os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TAU3D_JOB_KEY"))
+            if world > 1 and tag == "|||":
+                raise ValueError("Tau3DRing: world > 1 without a launcher environment (MASTER_PORT / TORCHELASTIC_RUN_ID / "
+                                 "TAU3D_JOB_KEY): pass job_key=, unique per launch and the same on every rank")
             job_key = (zlib.crc32(tag.encode()) << 32 | zlib.crc32((rendezvous or "").encode())) or 1
         _ck(self._L.tau3d_ring_create(C.byref(self._r), eng._h, rank, world, transport, rv, job_key))
 
