@@ -426,7 +426,9 @@ def main():
                 return None, err
             info = dict(ring.info(), driver="c (tau3d_ring_*: librccl from libtaueng)", transport=TRANSPORT_NAMES[transport],
                         step_schedule=("edge / interior launches (TAU3D_RING_PIPELINE=0)" if os.environ.get("TAU3D_RING_PIPELINE", "1") == "0"
-                                       else "pipelined: x/y fluxes of all planes overlap the halo transfer of the step before"))
+                                       else "pipelined, all-reduce first, two all-reduces on the direct transports (TAU3D_RING_SPEC=0)"
+                                       if os.environ.get("TAU3D_RING_SPEC", "1") == "0"
+                                       else "x/y fluxes of all planes ahead of the all-reduce; exchange, then ONE all-reduce, beside them"))
 
             def close_all():
                 ring.close()

@@ -78,6 +78,9 @@ struct DevClock {
   unsigned fmax_bits;   // largest |primitive| written by the step in flight (same encoding).  The word after
                         // maxs_bits: tau3d_max_ptr hands out both and a slab ring all-reduces them together
   float fmax_in;        // largest |primitive| in the state the next k_step reads (committed by clock_begin)
+  unsigned form_flip;   // 1 when that commit moved fmax_in across the WENO weight-form limit: an x/y flux launch that ran AHEAD of
+                        // the commit (the ring's speculative launch, tau3d_slab_xy_async before the clock) took the other form and
+                        // is repeated (k_flux_xy_fix)
 };
 
 static_assert(offsetof(DevClock, maxs_bits) % 32 == 0 && offsetof(DevClock, fmax_bits) == offsetof(DevClock, maxs_bits) + 4,
@@ -1290,6 +1293,23 @@ template <bool FAST, bool STRIDE> __global__ __launch_bounds__(XNT, TAU3D_XY_WAV
     __syncthreads();   // the next tile's staging overwrites what slow waves of this one still read
   }
 }
+// The repeat of a launch that ran ahead of the clock (Z-slab ring: the x/y fluxes of step n+1 start before the all-reduced
+// field range of step n is in).  It read the range of the step BEFORE; the commit says whether that put it on the wrong weight
+// form (DevClock::form_flip) — if not, which is every step of a sane run, each workgroup of this small resident grid leaves after
+// one scalar load.  Both bodies behind a branch: the register allocation of the pair does not matter for a launch that never runs.
+__global__ __launch_bounds__(XNT, TAU3D_XY_WAVES) void k_flux_xy_fix(const Args A) {
+  __shared__ XyLds S;
+  if (A.clk->form_flip == 0u) return;
+  const bool fast = fast_form(A.clk->fmax_in, A.in_fmax);
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
+    if (fast) flux_xy_body<true>(A, S, b); else flux_xy_body<false>(A, S, b);
+    __syncthreads();
+  }
+}
+void launch_flux_xy_fix(unsigned nwg, hipStream_t s, const Args &A) {
+  hipLaunchKernelGGL(k_flux_xy_fix, dim3(nwg < 768u ? nwg : 768u), dim3(XNT), 0, s, A);
+}
 void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast) {
   const unsigned net = nwg < 768u ? nwg : 768u;   // three workgroups per CU resident
 #ifdef TAU3D_FAST_ONLY   // ISA statistics only (scripts/isa_kernel_mix.py)
@@ -1306,6 +1326,7 @@ void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast
 }
 #else
 void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // XNT threads per workgroup; both weight forms, see k_flux_xy
+void launch_flux_xy_fix(unsigned nwg, hipStream_t s, const Args &A);                 // the repeat of a launch that ran ahead of the clock
 #endif
 
 // The update of one fluid cell, :1266-1358: conservative update from the x/y divergence D and the two z-face fluxes,
@@ -1709,7 +1730,9 @@ __global__ void k_init(Args A, float *const st0, float *const st1, float *const 
 // periodic halo of a single domain: planes [nzl, nzl+3) -> low halo, planes [3, 6) -> high halo
 // what the step about to run reads is what the last one wrote (or what init / upload measured, k_field_max)
 __device__ __forceinline__ void field_max_commit(DevClock *c) {
-  c->fmax_in = __uint_as_float(c->fmax_bits);
+  const float was = c->fmax_in, now = __uint_as_float(c->fmax_bits);
+  c->form_flip = ((was <= W_FLIM) != (now <= W_FLIM)) ? 1u : 0u;   // (!(NaN <= x): a NaN range is "beyond the limit" on both sides)
+  c->fmax_in = now;
   c->fmax_bits = 0u;
 }
 __device__ __forceinline__ void clock_begin(DevClock *c) { // log-time clock, :1680-1683 — before the step
@@ -2281,13 +2304,14 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.xyflag = h->xyflag;
   A.wrap_halo = (h->wrap_now && lo == 0 && hi == h->nzl && lo2 >= hi2) ? 1 : 0;
 }
-static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s) {   // x/y faces: one plane per workgroup
+static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s, bool fix = false) {   // x/y faces: one plane per workgroup
   h3d::Args X;
   split_args(h, X, lo, hi, lo2, hi2);
   const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
   X.zchunk = 1; X.nzc1 = n1; X.nzc = n1 + n2;
   X.ntx = (X.nx + h3d::XT - 1) / h3d::XT; X.nty = (X.ny + h3d::YT - 1) / h3d::YT;
-  h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X, h->expect_fast);
+  if (fix) h3d::launch_flux_xy_fix((unsigned)(X.ntx * X.nty * X.nzc), s, X);
+  else h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X, h->expect_fast);
   TAU_LAUNCH_CHECK("k_flux_xy");
   return 0;
 }
@@ -2490,6 +2514,23 @@ extern "C" int tau3d_slab_xy_async(tau3d_t *h) {
   if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream)); h->evm_set[h->n_ev] = false; }
   if (split_xy(h, 0, h->nzl, 0, 0, h->stream)) return 1;
   if (tm) { TAU_HIP(hipEventRecord(h->evm[h->n_ev], h->stream)); h->evm_set[h->n_ev] = true; }
+  return 0;
+}
+// after a tau3d_slab_xy_async that was issued BEFORE this step's tau3d_slab_begin_async / tau3d_slab_clock_async (the ring's
+// speculative launch): repeats the x/y fluxes if the clock's commit says they took the wrong WENO weight form — else nothing
+extern "C" int tau3d_slab_xy_fix_async(tau3d_t *h) {
+  if (!h) return tau::fail("tau3d_slab_xy_fix: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  if (!h->split) return 0;
+  if (getenv("TAU3D_DEBUG_NO_XY_FIX")) return 0;   // tests only: the control run that shows a wrong-form launch is visible
+  return split_xy(h, 0, h->nzl, 0, 0, h->stream, true);
+}
+/* test hook: the range word an x/y flux launch ahead of the clock reads (the next commit overwrites it) */
+extern "C" int tau3d_debug_set_fmax_in(tau3d_t *h, float v) {
+  if (!h) return tau::fail("tau3d_debug_set_fmax_in: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipMemcpyAsync(&h->clk->fmax_in, &v, sizeof v, hipMemcpyHostToDevice, h->stream));
+  TAU_HIP(hipStreamSynchronize(h->stream));
   return 0;
 }
 extern "C" int tau3d_slab_z_async(tau3d_t *h) {

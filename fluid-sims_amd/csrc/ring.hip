@@ -14,12 +14,15 @@
 //                                                ncclAllReduce(max) on the two words of tau3d_max_ptr, in place
 //                                                record evX(n)
 //   slab_end        swap (host bookkeeping)
-// (The direct transports, TAU3D_RING_IPC / _IPC_HOSTMAX, run another schedule by default — ring_step_pipelined below: x/y fluxes
-//  of ALL planes first, beside the halo copies of the step before, no edge / interior split.  TAU3D_RING_PIPELINE=0 gives them
-//  the table above, with X carrying the twelve halo copies only and the all-reduce on S behind the interior launch.)
+// That table is the round-2 schedule, kept behind TAU3D_RING_PIPELINE=0 (the edge depth TAU3D_RING_EDGE applies to it alone;
+// the direct transports then put the twelve halo copies on X and the all-reduce on S behind the interior launch).  What runs
+// by default, on EVERY transport, is ring_step_spec below (round 5): no edge / interior split, the x/y fluxes of all planes
+// issued ahead of the all-reduce of the step before, exchange and ONE all-reduce per step beside them on X.  TAU3D_RING_SPEC=0
+// selects the round-4 pipelined schedules (ring_step_pipelined / _packed: all-reduce first, then the exchange beside the x/y launch).
 //
 // No host synchronisation between the pieces: tau3d_ring_step_async(n) only enqueues.  One communicator, used on ONE stream
-// (X), so RCCL sees its operations in one order on every rank.
+// (X) in the default schedule — tau3d_ring_prime's all-reduce on the direct transports is issued on S, once, between two host
+// synchronisations of both streams — so RCCL sees its operations in one order on every rank.
 //
 // Transports:
 //   TAU3D_RING_RCCL   ncclSend / ncclRecv / ncclAllReduce over xGMI.  librccl is bound at run time (dlopen) — the copy the
@@ -211,7 +214,9 @@ struct tau3d_ring {
   hipStream_t S = nullptr, X = nullptr;
   hipEvent_t evE = nullptr, evI = nullptr, evX = nullptr, evH = nullptr;
   float *syncw = nullptr;        // one device word: the all-reduce that says "my halo copies have landed" (pipelined direct step)
-  bool pipelined = false;        // direct transports: x/y fluxes of step n+1 overlap the halo copies of step n (ring_step_pipelined)
+  bool pipelined = false;        // x/y fluxes of step n+1 overlap the exchange of step n (ring_step_pipelined*; every transport)
+  bool spec = false;             // ... and start AHEAD of all-reduce(n) (ring_step_spec): one all-reduce per step, off the critical path
+  int inject_us = 0;             // TAU3D_RING_INJECT_AR_US: a spin kernel of that many us behind every all-reduce (latency pricing on one GPU)
   ncclComm_t comm = nullptr;
   ring::Shared *sh = nullptr;
   size_t sh_bytes = 0;
@@ -280,6 +285,7 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
   }
   const double t0 = now_s();
   const uint64_t entered_ns = realtime_ns();
+  bool saw_failed = false;
   int spins = 0;
   for (;;) {   // wait for THIS job's file: an older one under the same name carries another key
     fd = open(path, O_RDWR);
@@ -299,6 +305,7 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
             close(fd);
             return tau::fail("tau3d_ring: rank 0 failed before the ring was set up (rendezvous file %s)", path);
           }
+          if (mine && rank0_failed) saw_failed = true;
           const bool stale = sh->bar_gen.load(std::memory_order_acquire) != 0 || rank0_failed ||
                              sh->status[r->rank].load(std::memory_order_acquire) != 0;
           if (!stale && mine) {
@@ -319,7 +326,10 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
       }
       close(fd);
     }
-    if (now_s() - t0 > timeout_s()) return tau::fail("tau3d_ring: rank %d waited %.0f s for rank 0's rendezvous file %s", r->rank, timeout_s(), path);
+    if (now_s() - t0 > timeout_s())
+      return tau::fail("tau3d_ring: rank %d waited %.0f s for rank 0's rendezvous file %s%s", r->rank, timeout_s(), path,
+                       saw_failed ? " — a file with this job key whose rank 0 had failed was there all along: left by an earlier launch, or "
+                                    "rank 0 of this launch failed before this rank started" : "");
     nap(spins);
   }
 }
@@ -414,6 +424,8 @@ static int ring_create_impl(tau3d_ring *r, tau3d_t *h, int rank, int world, int 
   TAU_HIP(hipEventCreateWithFlags(&r->evX, hipEventDisableTiming));
   TAU_HIP(hipEventCreateWithFlags(&r->evH, hipEventDisableTiming));
   { const char *e = getenv("TAU3D_RING_PIPELINE"); r->pipelined = !(e && atoi(e) == 0); }
+  { const char *e = getenv("TAU3D_RING_SPEC"); r->spec = r->pipelined && !(e && atoi(e) == 0); }
+  if (const char *e = getenv("TAU3D_RING_INJECT_AR_US")) { const int v = atoi(e); r->inject_us = v > 0 ? v : 0; }
   if (r->direct()) {
     TAU_HIP(hipMalloc(&r->syncw, sizeof(float)));
     TAU_HIP(hipMemset(r->syncw, 0, sizeof(float)));
@@ -528,6 +540,30 @@ extern "C" int tau3d_ring_info(tau3d_ring_t *r, int *rccl_version, int *comm_ran
   return 0;
 }
 
+// Latency pricing on a one-GPU box (scripts/ring_rank_emulation.py --inject-allreduce-us): a world of one prices an all-reduce at
+// the ~10 us of its launch; eight ranks over xGMI are plausibly 20-80 us.  One wave spinning on the realtime counter (100 MHz),
+// enqueued right behind the collective on its stream, makes the step see that latency where it would sit.
+__global__ void k_ring_spin(unsigned ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static int ring_allreduce(tau3d_ring *r, hipStream_t st) {
+  using namespace ring;
+  TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, st));
+  if (r->inject_us > 0) {
+    hipLaunchKernelGGL(k_ring_spin, dim3(1), dim3(64), 0, st, (unsigned)r->inject_us * 100u);
+    TAU_HIP(hipGetLastError());
+  }
+  return 0;
+}
+static int ring_inject(tau3d_ring *r, hipStream_t st) {   // (transports whose all-reduce is not RCCL's: local, host)
+  if (r->inject_us > 0) {
+    hipLaunchKernelGGL(k_ring_spin, dim3(1), dim3(64), 0, st, (unsigned)r->inject_us * 100u);
+    TAU_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
 // halos of step n: my low boundary planes are the low neighbour's HIGH halo, my high planes the high neighbour's LOW halo.
 // Between one pair of ranks RCCL matches sends and receives in issue order; with world == 2 both neighbours are the same
 // peer, so sends go (side 0, side 1) and receives (side 1, side 0): the peer's first send (its low planes) is my high halo.
@@ -619,12 +655,12 @@ static int communicate(tau3d_ring *r, bool with_max, int which = 1) {
     // copies of step n have landed, which is the ordering the direct transport rests on (top of this file).
     TAU_HIP(hipEventRecord(r->evX, r->X));
     TAU_HIP(hipStreamWaitEvent(r->S, r->evX, 0));
-    if (with_max) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->S));
+    if (with_max && ring_allreduce(r, r->S)) return 1;
     return 0;
   }
   if (with_max && r->transport != TAU3D_RING_LOCAL) {
     TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
-    if (r->uses_rccl()) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
+    if (r->uses_rccl()) { if (ring_allreduce(r, r->X)) return 1; }
     else if (allreduce_host(r)) return 1;
   }
   TAU_HIP(hipEventRecord(r->evX, r->X));
@@ -712,13 +748,14 @@ static int ring_step_pipelined(tau3d_ring *r) {
     // Both all-reduces on X by default: ONE communicator used on ONE stream, the plainest contract RCCL offers (the max on S
     // itself saves the S -> X -> S hop, ~1 % of a 64-plane step, but has RCCL order two user streams: TAU3D_RING_AR_ON_S=1).
     static const bool ar_on_s = [] { const char *e = getenv("TAU3D_RING_AR_ON_S"); return e && atoi(e) != 0; }();
-    if (ar_on_s) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->S));
+    if (ar_on_s) { if (ring_allreduce(r, r->S)) return 1; }
     else {
-      TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
+      if (ring_allreduce(r, r->X)) return 1;
       TAU_HIP(hipEventRecord(r->evX, r->X));   // (the next step's clock waits for it: top of this function)
     }
     if (exchange_ipc(r, 1)) return 1;
     TAU_NCCL(g_rccl.AllReduce(r->syncw, r->syncw, 1, ncclFloat, ncclMax, r->comm, r->X));
+    if (ring_inject(r, r->X)) return 1;
     TAU_HIP(hipEventRecord(r->evH, r->X));
   } else {
     // copies first: the host all-reduce behind them synchronises X (so this rank's copies have landed) before its first
@@ -749,8 +786,9 @@ static int ring_step_pipelined_packed(tau3d_ring *r) {
   if (tau3d_slab_z_async(r->h)) return 1;
   TAU_HIP(hipEventRecord(r->evI, r->S));
   TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
-  if (r->transport == TAU3D_RING_RCCL) TAU_NCCL(g_rccl.AllReduce(r->maxw, r->maxw, 2, ncclFloat, ncclMax, r->comm, r->X));
-  else if (r->transport == TAU3D_RING_HOST && allreduce_host(r)) return 1;
+  if (r->transport == TAU3D_RING_RCCL) { if (ring_allreduce(r, r->X)) return 1; }
+  else if (r->transport == TAU3D_RING_HOST) { if (allreduce_host(r)) return 1; }
+  else if (ring_inject(r, r->X)) return 1;
   TAU_HIP(hipEventRecord(r->evX, r->X));
   switch (r->transport) {
     case TAU3D_RING_RCCL: if (exchange_rccl(r)) return 1; break;
@@ -762,9 +800,52 @@ static int ring_step_pipelined_packed(tau3d_ring *r) {
   r->steps++;
   return 0;
 }
+// Round 5 — the default: the x/y fluxes run AHEAD of the all-reduce.  What k_flux_xy(n+1) takes from all-reduce(n) is one bit:
+// on which side of the WENO weight-form limit the global field range lies (the inflow gain and dt enter in the z kernel only).
+// That bit flips once in a run, if ever, so the launch goes ahead with the range of the step before; the clock kernel — which
+// commits the all-reduced range — records whether the bit moved, and a near-empty second launch repeats the fluxes if it did
+// (tau3d_slab_xy_fix_async): results do not depend on the speculation, only the timing does.  With nothing waiting for the
+// all-reduce until the z kernel, ONE all-reduce per step is enough for every transport — issued BEHIND the exchange on X, so its
+// completion also says "every rank's halos of this step have landed" (what the second, one-word all-reduce of the round-4
+// schedule was for) — and exchange + all-reduce run beside the x/y launch, 57 % of a step:
+//   S: xy fluxes (n+1), ALL planes   wait evX(n)   clock (controller n, clock n+1, range commit)   xy repeat (empty)
+//      [packed: unpack]   z + update (n+1) [packed: + pack]   record evI
+//   X: wait evI   halo copies | send / recv (n+1)   all-reduce(max)(n+1)   record evX
+// Hazards (direct copies): copies(n+1) overwrite halo planes the neighbour's z(n) read; they follow this rank's z(n+1), hence
+// all-reduce(n) complete, hence the neighbour's all-reduce(n) issued — behind its z(n).  The speculative launch reads interior
+// planes and the divergence buffer only: neither is written by a neighbour, and stream order keeps it behind this rank's z(n).
+// (TAU3D_RING_SPEC=0: the round-4 schedules below, all-reduce first.)
+static int ring_step_spec(tau3d_ring *r) {
+  using namespace ring;
+  if (tau3d_slab_xy_async(r->h)) return 1;               // ahead of the clock: reads the range word of the step before
+  TAU_HIP(hipStreamWaitEvent(r->S, r->evX, 0));          // exchange + all-reduce of the step before
+  if (tau3d_slab_clock_async(r->h)) return 1;
+  if (tau3d_slab_xy_fix_async(r->h)) return 1;
+  if (!r->direct() && tau3d_unpack_halos_async(r->h, 0)) return 1;
+  if (tau3d_slab_z_async(r->h)) return 1;
+  TAU_HIP(hipEventRecord(r->evI, r->S));
+  TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
+  switch (r->transport) {
+    case TAU3D_RING_RCCL: if (exchange_rccl(r) || ring_allreduce(r, r->X)) return 1; break;
+    case TAU3D_RING_IPC: if (exchange_ipc(r, 1) || ring_allreduce(r, r->X)) return 1; break;
+    case TAU3D_RING_HOST: if (exchange_host(r) || allreduce_host(r)) return 1; break;
+    case TAU3D_RING_IPC_HOSTMAX: if (exchange_ipc(r, 1) || allreduce_host(r)) return 1; break;   // (its first barrier follows a sync of X: copies landed)
+    default: if (exchange_local(r) || ring_inject(r, r->X)) return 1; break;
+  }
+  TAU_HIP(hipEventRecord(r->evX, r->X));
+  if (tau3d_slab_end_async(r->h)) return 1;
+  r->peer_cur[0] ^= 1; r->peer_cur[1] ^= 1;
+  r->steps++;
+  return 0;
+}
 static int ring_step_impl(tau3d_ring *r, int nsteps) {
   TAU_HIP(hipSetDevice(r->device));
   if (!r->primed && ring_prime_impl(r)) return 1;
+  if (r->spec) {
+    for (int s = 0; s < nsteps; s++)
+      if (ring_step_spec(r)) return 1;
+    return 0;
+  }
   if (r->pipelined) {
     for (int s = 0; s < nsteps; s++)
       if (r->direct() ? ring_step_pipelined(r) : ring_step_pipelined_packed(r)) return 1;

@@ -136,6 +136,7 @@ def load():
         "tau3d_clock_end_async": ([vp], i32),
         "tau3d_slab_begin_async": ([vp], i32), "tau3d_slab_edges_async": ([vp, i32], i32),
         "tau3d_slab_xy_async": ([vp], i32), "tau3d_slab_z_async": ([vp], i32), "tau3d_slab_clock_async": ([vp], i32),
+        "tau3d_slab_xy_fix_async": ([vp], i32), "tau3d_debug_set_fmax_in": ([vp, C.c_float], i32),
         "tau3d_slab_interior_async": ([vp, i32], i32), "tau3d_slab_end_async": ([vp], i32),
         "tau3d_fill_halo_periodic_async": ([vp], i32),
         "tau3d_halo_send_ptr": ([vp, i32, i32, i32, C.POINTER(vp)], i32),
@@ -501,6 +502,10 @@ class Tau3D:
 
     def state_written(self):
         _ck(self._L.tau3d_state_written(self._h))
+
+    def debug_set_fmax_in(self, v):
+        """test hook: the field-range word an x/y flux launch issued ahead of the clock reads (tau3d_debug_set_fmax_in)"""
+        _ck(self._L.tau3d_debug_set_fmax_in(self._h, C.c_float(v)))
 
     def field_range(self):
         """(read_max, written_max, fast_form) — see tau3d_field_range"""

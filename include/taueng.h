@@ -126,6 +126,15 @@ int tau3d_slab_end_async(tau3d_t *h);
 int tau3d_slab_clock_async(tau3d_t *h);   /* tau3d_slab_begin_async without the unpack (packed transports: tau3d_unpack_halos_async follows before the z piece) */
 int tau3d_slab_xy_async(tau3d_t *h);
 int tau3d_slab_z_async(tau3d_t *h);
+/* Round 5: the x/y fluxes may also be issued AHEAD of the step's clock — tau3d_slab_xy_async, <all-reduce of the step before
+ * landed>, begin / clock, tau3d_slab_xy_fix_async, z.  The x/y flux kernel reads one word of the clock block, the field range that
+ * picks the WENO weight form; ahead of the clock it sees the range of the step before, and the clock's commit records whether the
+ * new range is on the other side of the limit.  tau3d_slab_xy_fix_async repeats the fluxes in that case (never in a sane run: one
+ * near-empty launch) — the step's results do not depend on when the first launch ran.  The ring's pipelined steps use it to take
+ * the all-reduce off the critical path. */
+int tau3d_slab_xy_fix_async(tau3d_t *h);
+/* test hook: overwrite the range word a launch ahead of the clock reads (the next clock commit replaces it) */
+int tau3d_debug_set_fmax_in(tau3d_t *h, float v);
 /* fill own halos from own interior (periodic single domain) */
 int tau3d_fill_halo_periodic_async(tau3d_t *h);
 /* side 0 = low-z, 1 = high-z; which = 0 current (input) state, 1 = next (output) state.

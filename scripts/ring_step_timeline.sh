@@ -1,9 +1,15 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for mode in plain ipc0 ipc; do
+# usage: ring_step_timeline.sh [modes...]   modes: plain | ipc0 (TAU3D_RING_PIPELINE=0) | ipc4 / rccl4 (TAU3D_RING_SPEC=0: the round-4 schedule) | ipc | rccl | local
+# (TAU3D_RING_INJECT_AR_US in the environment is passed through)
+MODES=${@:-plain ipc0 ipc}
+for mode in $MODES; do
 rm -rf /tmp/rt && mkdir -p /tmp/rt
-if [ $mode = ipc0 ]; then export TAU3D_RING_PIPELINE=0; m=ipc; else export TAU3D_RING_PIPELINE=1; m=$mode; fi
+export TAU3D_RING_PIPELINE=1 TAU3D_RING_SPEC=1; m=$mode
+if [ $mode = ipc0 ]; then export TAU3D_RING_PIPELINE=0; m=ipc; fi
+if [ $mode = ipc4 ]; then export TAU3D_RING_SPEC=0; m=ipc; fi
+if [ $mode = rccl4 ]; then export TAU3D_RING_SPEC=0; m=rccl; fi
 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/rt -o t -- python scripts/ring_step_timeline.py $m > /tmp/rt/log.txt 2>&1
 python - $mode <<'PY'
 import csv, sys, glob
