@@ -170,9 +170,15 @@ def _profile_traffic(keys):
         return None, None
 
 
-def _roof(kernel, ms_per_launch, units_per_launch, bytes_per_unit, bound, note=None, traffic_keys=None):
+def _roof(kernel, ms_per_launch, units_per_launch, bytes_per_unit, bound, note=None, traffic_keys=None, traffic_field=None):
     gbs = units_per_launch * bytes_per_unit / (ms_per_launch * 1e-3) / 1e9
     traffic, tsrc = _profile_traffic(traffic_keys) if traffic_keys else (None, None)
+    if traffic_field:   # a ready-made per-launch total of the committed profile (e.g. the SPH developed state's own passes)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "k_step_traffic.json")))
+            traffic, tsrc = tj[traffic_field[0]], tj.get(traffic_field[1])
+        except Exception:
+            traffic, tsrc = None, None
     r = {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
          "traffic": traffic, "kernel": kernel, "avg_launch_ms": round(ms_per_launch, 5),
          "algorithmic_bytes_per_launch": units_per_launch * bytes_per_unit, "binding_bound": bound}
@@ -219,7 +225,7 @@ def other_configs(f, torch, dev):
     ms = _event_timed(torch, stream, lambda: g.step_async(1000), g.sync)   # ONE call: 1000 launches enqueued back to back
     out.append({"config": f"tau_gray_scott {n}x{n}, one step per launch", "steps": 1000, "warmup": 8,
                 "value": round(n * n * 1000 / ms / 1e6, 2), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 1000, 5),
-                "roofline": _roof("st2::k_march<GS>", ms / 1000, n * n, 16, "hbm")})   # (the profile pass runs the fused default)
+                "roofline": _roof("st2::k_march<GS>", ms / 1000, n * n, 16, "hbm", traffic_keys=["st2::k_march<0>"])})
     g.close()
 
     # ---- C4: tau_sph 4 194 304 particles, reset_particles(seed 69420), rain off, 200 sub-steps: on the lattice start
@@ -245,7 +251,8 @@ def other_configs(f, torch, dev):
                     "roofline": _roof("sph sub-step (counting-sort cell build + k_density + k_forces)", ms / 200, N, 100,
                                       "valu (pair evaluation)",
                                       traffic_keys=(["sph::k_tile_sums", "sph::k_scan", "sph::k_scatter", "sph::k_rank_gather", "sph::k_density<1>",
-                                                     "sph::k_forces<1>"] if not pre else None))})
+                                                     "sph::k_forces<1>"] if not pre else None),
+                                      traffic_field=(("sph_developed_hbm_bytes_per_substep", "sph_developed_source") if pre else None))})
     s.close()
 
     # ---- C1: tau_hypersonic.c restated (fp64 scalar CPU program), 256^2, 100 steps after init_sim, 1 thread

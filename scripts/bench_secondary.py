@@ -39,12 +39,29 @@ def line(name, unit, rate, ms, bytes_per_unit, bound, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--only", default=None, help="sph_developed: the SPH developed state alone (1 520 sub-steps in, then the timed tail)")
     a = ap.parse_args()
     k = 0.25 if a.quick else 1.0
+
+    if a.only == "sph_developed":
+        N = 1 << 22
+        s = f.Sph2D(N)
+        s.reset_particles()
+        s.step_async(1520)
+        s.sync()
+        r, ms = timed(s.step_async, s.sync, N, 50, 0)
+        line(f"tau_sph {N} particles, developed state (1 520 sub-steps after reset)", "particle-substeps", r, ms, 100, "pair-evaluation valu",
+             {"grid": s.grid(), "timed_substeps": 50})
+        s.close()
+        return
 
     n = 8192
     g = f.GrayScott(n, n)
     g.init_pattern(1337)
+    g.set_levels(1)          # the reference's structure, one launch per step: st2::k_march<0> (the 70 % HBM figure of bench.py's configs)
+    r, ms = timed(g.step_async, g.sync, n * n, int(200 * k), 8)
+    line(f"tau_gray_scott {n}^2, one step per launch", "cell-updates", r, ms, 16, "hbm")
+    g.set_levels(4)
     r, ms = timed(g.step_async, g.sync, n * n, int(400 * k), 20)
     fused = {"levels_per_pass": 4, "hbm_bytes_per_update_moved": 4.6,
              "note": "4 time levels per pass (temporal fusion): 16 B is the single-step algorithmic figure, the pass moves ~4.6 B per update"}

@@ -26,4 +26,15 @@ CMD="python scripts/bench_secondary.py --quick"
 run secondary_stats --kernel-trace --stats
 run secondary_fetch --pmc FETCH_SIZE
 run secondary_write --pmc WRITE_SIZE
+# the SPH developed state by itself: the kernels carry the same names as on the lattice, so the summary takes the timed tail only
+CMD="python scripts/bench_secondary.py --only sph_developed"
+runlast() { # name, rocprof args...
+  local name=$1; shift
+  rm -rf /tmp/rp_$name
+  rocprofv3 "$@" -d /tmp/rp_$name -o x -- $CMD > /tmp/rp_$name.log 2>&1
+  { echo "# rocprofv3 $* -- $CMD   (summary: the last 50 dispatches of every kernel = the timed sub-steps)"; grep -E '^\{"workload"' /tmp/rp_$name.log | cut -c1-400; python scripts/rocpd_summary.py /tmp/rp_$name/x_results.db --last 50; } > "$OUT/$name.txt"
+}
+runlast sphdev_stats --kernel-trace --stats
+runlast sphdev_fetch --pmc FETCH_SIZE
+runlast sphdev_write --pmc WRITE_SIZE
 ls -la "$OUT"
