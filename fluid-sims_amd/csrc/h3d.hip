@@ -146,15 +146,35 @@ __device__ __forceinline__ float copysign_v(float mag, float sgn, float maskv) {
 }
 // sinh with full relative accuracy for small arguments (the reference calls sinhf, :119): the odd series to x^7 below 0.5
 // (truncation 2.7e-9 relative), (e^x - e^-x) / 2 above.  Signed exponential: no copysign; Horner on literal multiplies.
-__device__ __forceinline__ float fsinh(float x) {
+__device__ __forceinline__ float fsinh_series(float x) {
   const float x2 = x * x;
   const float a = opaque(x2 * (1.f / 42.f)) + 1.f;
   const float c = (x2 * (1.f / 20.f)) * a + 1.f;
   const float s = (x2 * (1.f / 6.f)) * c + 1.f;
-  const float series = x * s;
+  return x * s;
+}
+__device__ __forceinline__ float fsinh_big(float x) {
   const float e = fexp(x);
-  const float big = 0.5f * (e - rcp(e));
+  return 0.5f * (e - rcp(e));
+}
+__device__ __forceinline__ float fsinh(float x) {
+  const float series = fsinh_series(x), big = fsinh_big(x);
   return (fabsf(x) < 0.5f) ? series : big;
+}
+// The same value in every lane, but the wave evaluates only the forms its lanes take (round 5): fsinh computes both — 8 VALU for
+// the series, 5 with two transcendentals (~30 cycles) for the exponential form — and selects; the lanes of a wave are 64
+// neighbouring cells of a row, and a velocity component sits on one side of |u| = 0.52 u_ref for all of them almost everywhere
+// (the transverse components below it, the streamwise one above it outside the wake's core).  Two scalar branches on ballots;
+// a mixed wave falls back to fsinh's select.  Call it from code whose loads are already waited for: a branch pins the arithmetic
+// where it is written (the z kernel decodes a plane when it enters the ring, not where it is fetched).
+__device__ __forceinline__ float fsinh_wave(float x) {
+  const bool small = fabsf(x) < 0.5f;
+  const unsigned long long sm = __builtin_amdgcn_ballot_w64(small), act = __builtin_amdgcn_ballot_w64(true);
+  float r;
+  if (sm == act) r = fsinh_series(x);
+  else if (sm == 0ull) r = fsinh_big(x);
+  else r = small ? fsinh_series(x) : fsinh_big(x);
+  return r;
 }
 // asinh as the reference writes it, :121-125.  maskv: 0x7fffffff in a VGPR (vlit), or use the two-argument form
 __device__ __forceinline__ float fasinh(float x, float maskv) {
@@ -645,11 +665,22 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 __device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
   return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
 }
+#ifndef TAU3D_DECODE_WAVE
+#define TAU3D_DECODE_WAVE 1
+#endif
+// decode_field for the split step's kernels: fsinh_wave (bit-identical values)
+__device__ __forceinline__ float decode_field_w(float u_ref, int m, float e) {
+#if TAU3D_DECODE_WAVE
+  return (m >= 1 && m <= 3) ? u_ref * fsinh_wave(e) : fexp(e);
+#else
+  return decode_field(u_ref, m, e);
+#endif
+}
 // (timing experiment only, DESIGN §8: what k_update_z would save if it read decoded primitives instead of decoding — wrong results)
 #ifdef TAU3D_EXP_NODECODE_Z
 #define ZDEC(u, m, e) (e)
 #else
-#define ZDEC(u, m, e) decode_field(u, m, e)
+#define ZDEC(u, m, e) decode_field_w(u, m, e)
 #endif
 using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::lane_off;   // tau_common.h: scalar base + 32-bit lane offset
 
@@ -663,15 +694,21 @@ __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GC
     sol = sdf_solid(A, gx, gyw, zg);
   } else if (gx >= A.nx) {
     const unsigned vo = lane_off((unsigned)(gyw * A.nx + (A.nx - 1)) << 2);
+    float e[6];
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = decode_field(uref, m, gld(qpl + m * fs4, vo));
+    for (int m = 0; m < 6; m++) e[m] = gld(qpl + m * fs4, vo);
+#pragma unroll
+    for (int m = 0; m < 6; m++) p.q[m] = decode_field_w(uref, m, e[m]);
     p = outflow_prim(A, p);
     sol = sdf_solid(A, gx, gyw, zg);
   } else {
     const unsigned vo = lane_off((unsigned)(gyw * A.nx + gx) << 2);
+    float e[6];   // all six loads in flight before the first decode (fsinh_wave's branches pin the arithmetic behind its load)
 #pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = decode_field(uref, m, gld(qpl + m * fs4, vo));
+    for (int m = 0; m < 6; m++) e[m] = gld(qpl + m * fs4, vo);
     sol = spl[vo >> 2] != 0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) p.q[m] = decode_field_w(uref, m, e[m]);
   }
 #pragma unroll
   for (int m = 0; m < 6; m++) q[m] = p.q[m];
@@ -1458,9 +1495,13 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   unsigned ws = 0;
   auto load_own = [&](int k, float (&dst)[6]) -> unsigned {   // plane zc_lo-3+k
     const unsigned vo = col4 + (unsigned)k * plane4;
+    float e[6];   // the six loads first: fsinh_wave's branches pin a decode behind its own load
 #pragma unroll
-    for (int m = 0; m < 6; m++) dst[m] = ZDEC(uref, m, *(const GFloat *)(qP + m * fs4 + vo));
-    return solP[vo >> 2] != 0 ? 1u : 0u;
+    for (int m = 0; m < 6; m++) e[m] = *(const GFloat *)(qP + m * fs4 + vo);
+    const unsigned sol = solP[vo >> 2] != 0 ? 1u : 0u;
+#pragma unroll
+    for (int m = 0; m < 6; m++) dst[m] = ZDEC(uref, m, e[m]);
+    return sol;
   };
 
   // prologue: planes zc_lo-2 .. zc_lo+2 into slots 0 .. 4 (plane zc_lo-3 is only needed here); flux through the low
@@ -1519,7 +1560,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     asm volatile("" : "+s"(f4), "+s"(d4));
     if (more) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) Nx[m] = ZDEC(uref, m, gld(qN + m * f4, vo));
+      for (int m = 0; m < 6; m++) Nx[m] = gld(qN + m * f4, vo);   // encoded: decoded where the plane enters the ring
       nsol = solN[vo >> 2] != 0 ? 1u : 0u;
     }
     const bool own_solid = (ws >> 2) & 1u;
@@ -1536,7 +1577,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     if (face_dead) {
       if (more) {
 #pragma unroll
-        for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
+        for (int m = 0; m < 6; m++) ring[s0][m][tid] = ZDEC(uref, m, Nx[m]);
       }
 #pragma unroll
       for (int m = 0; m < 6; m++) Fz_hi[m] = 0.f;
@@ -1561,7 +1602,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       // trip: 3.9 cycles per instruction against 3.1 for the mix.)
       if (more) {
 #pragma unroll
-        for (int m = 0; m < 6; m++) ring[s0][m][tid] = Nx[m];
+        for (int m = 0; m < 6; m++) ring[s0][m][tid] = ZDEC(uref, m, Nx[m]);
       }
 #ifndef TAU3D_EXP_NOD   // (timing experiment: the step without the divergence read — wrong results)
       if (in_xy && !own_solid) {

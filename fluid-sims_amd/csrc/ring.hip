@@ -207,9 +207,19 @@ static int barrier(Shared *sh, const char *what) {
 
 } // namespace ring
 
-struct tau3d_ring {
+// what a ring knows about its rendezvous file (shared by the 3D Z-slab ring and the row-slab ring of the 2D stencil handles)
+struct tau_rendezvous {
+  int rank = 0, world = 1, transport = 0;
+  ring::Shared *sh = nullptr;
+  size_t sh_bytes = 0;
+  char path[256] = "";
+  uint64_t ino = 0, dev = 0;   // identity of the mapped rendezvous file (ranks != 0)
+  uint64_t key = 0;
+  bool published = false, failed = false;
+};
+struct tau3d_ring : tau_rendezvous {
   tau3d_t *h = nullptr;
-  int rank = 0, world = 1, transport = 0, lo = 0, hi = 0;
+  int lo = 0, hi = 0;
   int nzl = 0, edge = 3, device = 0;
   hipStream_t S = nullptr, X = nullptr;
   hipEvent_t evE = nullptr, evI = nullptr, evX = nullptr, evH = nullptr;
@@ -218,9 +228,6 @@ struct tau3d_ring {
   bool spec = false;             // ... and start AHEAD of all-reduce(n) (ring_step_spec): one all-reduce per step, off the critical path
   int inject_us = 0;             // TAU3D_RING_INJECT_AR_US: a spin kernel of that many us behind every all-reduce (latency pricing on one GPU)
   ncclComm_t comm = nullptr;
-  ring::Shared *sh = nullptr;
-  size_t sh_bytes = 0;
-  char path[256] = "";
   float *buf[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [kind: 0 send, 1 recv][side]
   size_t nfloats = 0;
   float *maxw = nullptr;
@@ -231,17 +238,14 @@ struct tau3d_ring {
   void *opened[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // what hipIpcCloseMemHandle gets back
   size_t peer_stride[2] = {0, 0};
   int peer_nzl[2] = {0, 0}, peer_cur[2] = {0, 0};
-  uint64_t ino = 0, dev = 0;   // identity of the mapped rendezvous file (ranks != 0)
-  uint64_t key = 0;
-  bool published = false, failed = false;
   bool uses_rccl() const { return transport == TAU3D_RING_RCCL || transport == TAU3D_RING_IPC; }
   bool direct() const { return transport == TAU3D_RING_IPC || transport == TAU3D_RING_IPC_HOSTMAX; }
 };
 
 // a rank that cannot go on says so in the rendezvous file: its peers leave their barriers with an error instead of waiting
 // out the timeout (or sitting inside a collective for ever)
-static int ring_publish(tau3d_ring *r);
-static void mark_failed(tau3d_ring *r) {
+static int ring_publish(tau_rendezvous *r);
+static void mark_failed(tau_rendezvous *r) {
   if (!r || !r->sh || r->rank < 0 || r->rank >= ring::MAX_WORLD) return;
   r->failed = true;
   r->sh->status[r->rank].store(2, std::memory_order_release);
@@ -256,7 +260,7 @@ static void mark_failed(tau3d_ring *r) {
   }
 }
 
-static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) {
+static int ring_map(tau_rendezvous *r, const char *path, uint64_t key, size_t slot) {
   using namespace ring;
   const size_t bytes = shared_bytes(r->world, slot);
   snprintf(r->path, sizeof r->path, "%s", path);
@@ -334,7 +338,7 @@ static int ring_map(tau3d_ring *r, const char *path, uint64_t key, size_t slot) 
   }
 }
 // rank 0: the header is complete -> the file appears under its public name
-static int ring_publish(tau3d_ring *r) {
+static int ring_publish(tau_rendezvous *r) {
   char tmp[300];
   snprintf(tmp, sizeof tmp, "%s.%ld.tmp", r->path, (long)getpid());
   r->sh->ready.store(ring::MAGIC ^ r->key, std::memory_order_release);
@@ -344,7 +348,7 @@ static int ring_publish(tau3d_ring *r) {
 }
 // after the create barrier: the file this rank mapped must still be the one under `path` (a file left behind by a crashed job
 // with the same path AND key could have been picked up before rank 0 replaced it — then the barrier was someone else's)
-static int ring_check_same_file(tau3d_ring *r) {
+static int ring_check_same_file(tau_rendezvous *r) {
   if (r->rank == 0) return 0;
   struct stat st;
   if (stat(r->path, &st) != 0 || (uint64_t)st.st_ino != r->ino || (uint64_t)st.st_dev != r->dev)
@@ -892,3 +896,249 @@ extern "C" int tau3d_ring_barrier(tau3d_ring_t *r) {
   if (!r->sh) return 0;
   return ring::barrier(r->sh, "tau3d_ring_barrier");
 }
+
+// =====================================================================================================================
+// The row-slab ring of the periodic two-field 5-point-stencil handles — Gray-Scott (taugs_*) and the Burgers / shallow-water
+// viscosity passes (taulap_*) — in the library (round 5; SURVEY §8e: "also slab-shardable, 1-row halo, periodic"; the loop it
+// shards is tau_gray_scott.cu:321-329).  Same scheme as fluid-sims_amd/slab2d.py, without Python or torch.distributed:
+//
+// Rank r owns rows [y0, y0 + nyl) of the ny x nx grid and keeps H halo rows on each side; its handle is created with
+// ny_local = nyl + 2H rows and steps that array as the periodic domain it believes it has.  What wraps around the ends of the
+// local array is wrong, but a 5-point stencil carries that one row per step: after k <= H steps only the outer k rows of each
+// halo are contaminated and every owned row is what the single-domain run computes — same kernel, same operands, bit for bit.
+// Every H steps the halos are refreshed from the ring neighbours (first H owned rows -> the low neighbour's high halo, last H
+// owned rows -> the high neighbour's low halo): 2 fields x H x nx x 4 B a side — 262 KB at nx = 8192, H = 4, one exchange per
+// four-level fused pass.  A deeper halo (H = 8, 16 ...) trades 2H / nyl of redundant rows for fewer, larger exchanges.
+// No global reduction (fixed dt), no pack kernel (H rows of a field are contiguous: RCCL sends and receives them in place).
+// Transports: TAU3D_RING_RCCL (ncclSend / ncclRecv on the handle's stream), TAU3D_RING_HOST (staged through the rendezvous
+// file: ranks may share a device — the multi-process tests of a one-GPU box), TAU3D_RING_LOCAL (world 1, device copies).
+struct taurow_ring : tau_rendezvous {
+  void *h = nullptr;
+  int (*ptrs)(void *, float **, float **) = nullptr;
+  int (*step)(void *, int) = nullptr;
+  int nx = 0, nyl = 0, H = 0, device = 0, lo = 0, hi = 0;
+  hipStream_t S = nullptr;
+  ncclComm_t comm = nullptr;
+  long steps = 0, exchanges = 0;
+};
+
+extern "C" int taurow_bounds(int ny, int world, int rank, int *y0, int *nyl) {
+  if (world < 1 || rank < 0 || rank >= world || !y0 || !nyl) return tau::fail("taurow_bounds: bad argument");
+  const int base = ny / world, rem = ny % world;
+  *y0 = rank * base + (rank < rem ? rank : rem);
+  *nyl = base + (rank < rem ? 1 : 0);
+  if (*nyl < 1) return tau::fail("taurow_bounds: ny=%d over %d ranks leaves an empty slab", ny, world);
+  return 0;
+}
+
+static int rowring_exchange(taurow_ring *r) {
+  using namespace ring;
+  float *f[2] = {nullptr, nullptr};
+  if (r->ptrs(r->h, &f[0], &f[1])) return 1;
+  const size_t n = (size_t)r->H * r->nx, b = n * sizeof(float);
+  const size_t first = (size_t)r->H * r->nx, last = (size_t)r->nyl * r->nx, hihalo = (size_t)(r->nyl + r->H) * r->nx;
+  switch (r->transport) {
+    case TAU3D_RING_RCCL:
+      // one group; between one pair of ranks RCCL matches sends and receives in issue order (world 2: both neighbours are one
+      // peer): per field, send (first rows -> lo, last rows -> hi), receive (high halo <- hi, low halo <- lo)
+      TAU_NCCL(g_rccl.GroupStart());
+      for (int k = 0; k < 2; k++) {
+        TAU_NCCL(g_rccl.Send(f[k] + first, n, ncclFloat, r->lo, r->comm, r->S));
+        TAU_NCCL(g_rccl.Send(f[k] + last, n, ncclFloat, r->hi, r->comm, r->S));
+        TAU_NCCL(g_rccl.Recv(f[k] + hihalo, n, ncclFloat, r->hi, r->comm, r->S));
+        TAU_NCCL(g_rccl.Recv(f[k], n, ncclFloat, r->lo, r->comm, r->S));
+      }
+      TAU_NCCL(g_rccl.GroupEnd());
+      break;
+    case TAU3D_RING_HOST:
+      if (r->sh) {
+        for (int k = 0; k < 2; k++) {
+          TAU_HIP(hipMemcpyAsync(slot_ptr(r->sh, r->rank, 0) + k * b, f[k] + first, b, hipMemcpyDeviceToHost, r->S));
+          TAU_HIP(hipMemcpyAsync(slot_ptr(r->sh, r->rank, 1) + k * b, f[k] + last, b, hipMemcpyDeviceToHost, r->S));
+        }
+        TAU_HIP(hipStreamSynchronize(r->S));
+        if (barrier(r->sh, "row halo slots written")) return 1;
+        for (int k = 0; k < 2; k++) {
+          TAU_HIP(hipMemcpyAsync(f[k] + hihalo, slot_ptr(r->sh, r->hi, 0) + k * b, b, hipMemcpyHostToDevice, r->S));
+          TAU_HIP(hipMemcpyAsync(f[k], slot_ptr(r->sh, r->lo, 1) + k * b, b, hipMemcpyHostToDevice, r->S));
+        }
+        TAU_HIP(hipStreamSynchronize(r->S));
+        if (barrier(r->sh, "row halo slots read")) return 1;
+        break;
+      }
+      // (no rendezvous file: a world of one)
+      [[fallthrough]];
+    default:
+      for (int k = 0; k < 2; k++) {
+        TAU_HIP(hipMemcpyAsync(f[k] + hihalo, f[k] + first, b, hipMemcpyDeviceToDevice, r->S));
+        TAU_HIP(hipMemcpyAsync(f[k], f[k] + last, b, hipMemcpyDeviceToDevice, r->S));
+      }
+      break;
+  }
+  r->exchanges++;
+  return 0;
+}
+
+static int rowring_create_impl(taurow_ring *r, int nx, int ny_local, int device, void *stream, int halo, int rank, int world, int transport,
+                               const char *rendezvous, uint64_t job_key) {
+  using namespace ring;
+  r->rank = rank; r->world = world; r->transport = transport; r->key = job_key;
+  r->nx = nx; r->H = halo; r->nyl = ny_local - 2 * halo; r->device = device; r->S = (hipStream_t)stream;
+  r->lo = (rank + world - 1) % world; r->hi = (rank + 1) % world;
+  const size_t slot = transport == TAU3D_RING_HOST ? 2 * (size_t)halo * nx * sizeof(float) : 0;
+  if (world > 1 && ring_map(r, rendezvous, job_key, slot)) return 1;
+  if (halo < 1 || r->nyl < halo)
+    return tau::fail("taurow_ring_create: a handle of %d rows with a %d-row halo either side owns %d rows; it needs at least the halo depth",
+                     ny_local, halo, r->nyl);
+  TAU_HIP(hipSetDevice(device));
+  ncclUniqueId id;
+  memset(&id, 0, sizeof id);
+  if (transport == TAU3D_RING_RCCL) {
+    if (rccl_load()) return 1;
+    if (rank == 0 && g_rccl.GetUniqueId(&id) != ncclSuccess) return tau::fail("taurow_ring_create: ncclGetUniqueId failed");
+  }
+  if (r->sh) {
+    Shared *sh = r->sh;
+    char bus[32] = "";
+    TAU_HIP(hipDeviceGetPCIBusId(bus, (int)sizeof bus, device));
+    snprintf(sh->busid[rank], sizeof sh->busid[rank], "%s", bus);
+    sh->nzl[rank] = r->nyl;
+    sh->field_stride[rank] = (uint64_t)nx | ((uint64_t)halo << 32);   // what every rank must agree on
+    if (rank == 0) {
+      sh->id = id;
+      if (ring_publish(r)) return 1;
+    }
+    sh->status[rank].store(1, std::memory_order_release);
+    if (barrier(sh, "row ring create")) return 1;
+    if (ring_check_same_file(r)) return 1;
+    for (int k = 0; k < world; k++) {
+      if (sh->status[k].load(std::memory_order_acquire) != 1) return tau::fail("taurow_ring_create: rank %d could not start", k);
+      if (sh->field_stride[k] != sh->field_stride[rank])
+        return tau::fail("taurow_ring_create: rank %d runs nx=%u halo=%u, rank %d nx=%d halo=%d", k, (unsigned)sh->field_stride[k],
+                         (unsigned)(sh->field_stride[k] >> 32), rank, nx, halo);
+      if (sh->nzl[k] < halo) return tau::fail("taurow_ring_create: rank %d owns %d rows, fewer than the %d-row halo", k, sh->nzl[k], halo);
+    }
+    id = sh->id;
+    if (transport == TAU3D_RING_RCCL && !getenv("TAU3D_RING_NO_DEVICE_CHECK"))
+      for (int a = 0; a < world; a++)
+        for (int b = a + 1; b < world; b++)
+          if (strncmp(sh->busid[a], sh->busid[b], sizeof sh->busid[a]) == 0)
+            return tau::fail("taurow_ring_create: the RCCL transport needs one device per rank, ranks %d and %d both run on %s "
+                             "(the host transport lets ranks share a device)", a, b, sh->busid[a]);
+  }
+  if (transport == TAU3D_RING_RCCL) TAU_NCCL(g_rccl.CommInitRank(&r->comm, world, id, rank));
+  return 0;
+}
+
+static int rowring_create(taurow_ring_t **out, void *h, int (*ptrs)(void *, float **, float **), int (*step)(void *, int), int nx, int ny_local,
+                          int device, void *stream, int halo, int rank, int world, int transport, const char *rendezvous, uint64_t job_key) {
+  using namespace ring;
+  if (!out || !h) return tau::fail("taurow_ring_create: null argument");
+  if (world < 1 || world > MAX_WORLD || rank < 0 || rank >= world) return tau::fail("taurow_ring_create: rank %d of %d", rank, world);
+  if (transport != TAU3D_RING_RCCL && transport != TAU3D_RING_HOST && transport != TAU3D_RING_LOCAL)
+    return tau::fail("taurow_ring_create: transport %d (the row ring runs over rccl, host or local)", transport);
+  if (transport == TAU3D_RING_LOCAL && world != 1) return tau::fail("taurow_ring_create: the local transport is for world 1");
+  if (world > 1 && (!rendezvous || !rendezvous[0])) return tau::fail("taurow_ring_create: world %d needs a rendezvous path", world);
+  if (world > 1 && job_key == 0) return tau::fail("taurow_ring_create: world %d needs a non-zero job key, unique per launch", world);
+  taurow_ring *r = new (std::nothrow) taurow_ring();
+  if (!r) return tau::fail("taurow_ring_create: out of host memory");
+  r->h = h; r->ptrs = ptrs; r->step = step;
+  if (rowring_create_impl(r, nx, ny_local, device, stream, halo, rank, world, transport, rendezvous, job_key)) {
+    char keep[512];
+    snprintf(keep, sizeof keep, "%s", tau_last_error());
+    mark_failed(r);
+    taurow_ring_destroy(r);
+    return tau::fail("%s", keep);
+  }
+  *out = r;
+  return 0;
+}
+extern "C" int taugs_ring_create(taurow_ring_t **out, taugs_t *h, int halo, int rank, int world, int transport, const char *rendezvous,
+                                 uint64_t job_key) {
+  int nx = 0, ny = 0, device = 0;
+  void *stream = nullptr;
+  if (!h || taugs_info(h, &nx, &ny, &device, &stream)) return tau::fail("taugs_ring_create: null handle");
+  return rowring_create(out, h, [](void *p, float **a, float **b) { return taugs_state_ptrs((taugs_t *)p, a, b); },
+                        [](void *p, int n) { return taugs_step_async((taugs_t *)p, n); }, nx, ny, device, stream, halo, rank, world, transport,
+                        rendezvous, job_key);
+}
+extern "C" int taulap_ring_create(taurow_ring_t **out, taulap_t *h, int halo, int rank, int world, int transport, const char *rendezvous,
+                                  uint64_t job_key) {
+  int nx = 0, ny = 0, device = 0;
+  void *stream = nullptr;
+  if (!h || taulap_info(h, &nx, &ny, &device, &stream)) return tau::fail("taulap_ring_create: null handle");
+  return rowring_create(out, h, [](void *p, float **a, float **b) { return taulap_state_ptrs((taulap_t *)p, a, b); },
+                        [](void *p, int n) { return taulap_step_async((taulap_t *)p, n); }, nx, ny, device, stream, halo, rank, world, transport,
+                        rendezvous, job_key);
+}
+extern "C" void taurow_ring_destroy(taurow_ring_t *r) {
+  if (!r) return;
+  hipSetDevice(r->device);
+  if (r->S) hipStreamSynchronize(r->S);
+  if (r->comm) ring::g_rccl.CommDestroy(r->comm);
+  if (r->sh) {
+    munmap(r->sh, r->sh_bytes);
+    if (r->rank == 0 && r->path[0] && !(r->failed && r->world > 1)) {
+      unlink(r->path);
+      char tmp[300];
+      snprintf(tmp, sizeof tmp, "%s.%ld.tmp", r->path, (long)getpid());
+      unlink(tmp);
+    }
+  }
+  delete r;
+}
+/* refresh both halos of the current state from the ring neighbours (after init / upload, and every `halo` steps) */
+extern "C" int taurow_ring_exchange_async(taurow_ring_t *r) {
+  if (!r) return tau::fail("taurow_ring_exchange: null ring");
+  TAU_HIP(hipSetDevice(r->device));
+  const int rc = rowring_exchange(r);
+  if (rc) mark_failed(r);
+  return rc;
+}
+/* nsteps time steps (any count: the last stretch may be shorter than the halo); the halos are current when it returns */
+extern "C" int taurow_ring_step_async(taurow_ring_t *r, int nsteps) {
+  if (!r) return tau::fail("taurow_ring_step: null ring");
+  TAU_HIP(hipSetDevice(r->device));
+  for (int done = 0; done < nsteps;) {
+    const int k = nsteps - done < r->H ? nsteps - done : r->H;
+    if (r->step(r->h, k) || rowring_exchange(r)) { mark_failed(r); return 1; }
+    done += k;
+    r->steps += k;
+  }
+  return 0;
+}
+extern "C" int taurow_ring_finish(taurow_ring_t *r) {
+  if (!r) return tau::fail("taurow_ring_finish: null ring");
+  TAU_HIP(hipSetDevice(r->device));
+  TAU_HIP(hipStreamSynchronize(r->S));
+  return 0;
+}
+extern "C" int taurow_ring_barrier(taurow_ring_t *r) {
+  if (!r) return tau::fail("taurow_ring_barrier: null ring");
+  if (!r->sh) return 0;
+  return ring::barrier(r->sh, "taurow_ring_barrier");
+}
+extern "C" int taurow_ring_info(taurow_ring_t *r, int *nyl, int *halo, long *exchanges, int *rccl_version, int *comm_ranks) {
+  if (!r) return tau::fail("taurow_ring_info: null ring");
+  if (nyl) *nyl = r->nyl;
+  if (halo) *halo = r->H;
+  if (exchanges) *exchanges = r->exchanges;
+  if (rccl_version) *rccl_version = 0;
+  if (comm_ranks) *comm_ranks = r->comm ? 0 : r->world;
+  if (r->comm) {
+    if (rccl_version) TAU_NCCL(ring::g_rccl.GetVersion(rccl_version));
+    if (comm_ranks) TAU_NCCL(ring::g_rccl.CommCount(r->comm, comm_ranks));
+  }
+  return 0;
+}
+// the names the two simulators' drivers use (one implementation: the ring does not care which stencil steps its rows)
+extern "C" int taugs_ring_step_async(taurow_ring_t *r, int nsteps) { return taurow_ring_step_async(r, nsteps); }
+extern "C" int taugs_ring_exchange_async(taurow_ring_t *r) { return taurow_ring_exchange_async(r); }
+extern "C" int taugs_ring_finish(taurow_ring_t *r) { return taurow_ring_finish(r); }
+extern "C" int taugs_ring_barrier(taurow_ring_t *r) { return taurow_ring_barrier(r); }
+extern "C" void taugs_ring_destroy(taurow_ring_t *r) { taurow_ring_destroy(r); }
+extern "C" int taulap_ring_step_async(taurow_ring_t *r, int npasses) { return taurow_ring_step_async(r, npasses); }
+extern "C" int taulap_ring_exchange_async(taurow_ring_t *r) { return taurow_ring_exchange_async(r); }
+extern "C" int taulap_ring_finish(taurow_ring_t *r) { return taurow_ring_finish(r); }
+extern "C" int taulap_ring_barrier(taurow_ring_t *r) { return taurow_ring_barrier(r); }
+extern "C" void taulap_ring_destroy(taurow_ring_t *r) { taurow_ring_destroy(r); }

@@ -478,9 +478,10 @@ extern "C" int taugs_create(taugs_t **out, const taugs_params *p, int device, vo
 }
 extern "C" void taugs_destroy(taugs_t *h) { if (h) { st2::pair_destroy(&h->pr); delete h; } }
 
-extern "C" int taugs_init_pattern(taugs_t *h, uint32_t seed) { // init_pattern, :173-204 (host) + H2D :308-309
-  const int nx = h->p.nx, ny = h->p.ny;
-  std::vector<float> u((size_t)nx * ny, 1.0f), v((size_t)nx * ny, 0.0f);
+/* init_pattern (:173-204) into host arrays of nx * ny floats: what a row-slab rank cuts its rows out of */
+extern "C" int taugs_pattern_host(int nx, int ny, uint32_t seed, float *u, float *v) {
+  if (nx < 1 || ny < 1 || !u || !v) return tau::fail("taugs_pattern_host: bad argument");
+  for (size_t i = 0; i < (size_t)nx * ny; i++) { u[i] = 1.0f; v[i] = 0.0f; }
   const int cx = nx / 2, cy = ny / 2, r = (nx < ny ? nx : ny) / 12;
   for (int j = -r; j <= r; ++j)
     for (int i = -r; i <= r; ++i) {
@@ -496,7 +497,21 @@ extern "C" int taugs_init_pattern(taugs_t *h, uint32_t seed) { // init_pattern, 
     u[(size_t)y * nx + x] = 0.35f;
     v[(size_t)y * nx + x] = 0.65f;
   }
+  return 0;
+}
+extern "C" int taugs_init_pattern(taugs_t *h, uint32_t seed) { // init_pattern, :173-204 (host) + H2D :308-309
+  const int nx = h->p.nx, ny = h->p.ny;
+  std::vector<float> u((size_t)nx * ny), v((size_t)nx * ny);
+  if (taugs_pattern_host(nx, ny, seed, u.data(), v.data())) return 1;
   return st2::pair_upload(&h->pr, u.data(), v.data());
+}
+extern "C" int taugs_info(taugs_t *h, int *nx, int *ny, int *device, void **stream) {
+  if (!h) return tau::fail("taugs_info: null handle");
+  if (nx) *nx = h->pr.nx;
+  if (ny) *ny = h->pr.ny;
+  if (device) *device = h->pr.device;
+  if (stream) *stream = (void *)h->pr.stream;
+  return 0;
 }
 extern "C" int taugs_upload(taugs_t *h, const float *u, const float *v) { return st2::pair_upload(&h->pr, u, v); }
 extern "C" int taugs_download(taugs_t *h, float *u, float *v) { return st2::pair_download(&h->pr, u, v); }
@@ -552,6 +567,14 @@ extern "C" int taulap_create(taulap_t **out, const taulap_params *p, int kind, i
   return 0;
 }
 extern "C" void taulap_destroy(taulap_t *h) { if (h) { st2::pair_destroy(&h->pr); delete h; } }
+extern "C" int taulap_info(taulap_t *h, int *nx, int *ny, int *device, void **stream) {
+  if (!h) return tau::fail("taulap_info: null handle");
+  if (nx) *nx = h->pr.nx;
+  if (ny) *ny = h->pr.ny;
+  if (device) *device = h->pr.device;
+  if (stream) *stream = (void *)h->pr.stream;
+  return 0;
+}
 extern "C" int taulap_upload(taulap_t *h, const float *a, const float *b) { return st2::pair_upload(&h->pr, a, b); }
 extern "C" int taulap_download(taulap_t *h, float *a, float *b) { return st2::pair_download(&h->pr, a, b); }
 extern "C" int taulap_state_ptrs(taulap_t *h, float **a, float **b) {

@@ -240,6 +240,19 @@ def load():
         "taugs_step": ([vp, i32], i32),
         "taugs_step_async": ([vp, i32], i32),
         "taugs_sync": ([vp], i32),
+        "taugs_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)], i32),
+        "taulap_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)], i32),
+        "taugs_pattern_host": ([i32, i32, C.c_uint32, vp, vp], i32),
+        "taurow_bounds": ([i32, i32, i32, C.POINTER(i32), C.POINTER(i32)], i32),
+        "taugs_ring_create": ([C.POINTER(vp), vp, i32, i32, i32, i32, C.c_char_p, C.c_uint64], i32),
+        "taulap_ring_create": ([C.POINTER(vp), vp, i32, i32, i32, i32, C.c_char_p, C.c_uint64], i32),
+        "taurow_ring_step_async": ([vp, i32], i32), "taurow_ring_exchange_async": ([vp], i32), "taurow_ring_finish": ([vp], i32),
+        "taurow_ring_barrier": ([vp], i32), "taurow_ring_destroy": ([vp], None),
+        "taurow_ring_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_long), C.POINTER(i32), C.POINTER(i32)], i32),
+        "taugs_ring_step_async": ([vp, i32], i32), "taugs_ring_exchange_async": ([vp], i32), "taugs_ring_finish": ([vp], i32),
+        "taugs_ring_barrier": ([vp], i32), "taugs_ring_destroy": ([vp], None),
+        "taulap_ring_step_async": ([vp, i32], i32), "taulap_ring_exchange_async": ([vp], i32), "taulap_ring_finish": ([vp], i32),
+        "taulap_ring_barrier": ([vp], i32), "taulap_ring_destroy": ([vp], None),
         "taugs_set_levels": ([vp, i32], i32),
         "taulap_create": ([C.POINTER(vp), C.POINTER(LapParams), i32, i32, i32, vp], i32),
         "taulap_destroy": ([vp], None),
@@ -854,6 +867,56 @@ class Flow2D:
 
     def sync(self):
         _ck(self._L.tauflow_sync(self._h))
+
+
+def row_bounds(ny, world, rank):
+    """(y0, nyl): the contiguous rows of rank `rank` (taurow_bounds)"""
+    y0, nyl = C.c_int32(), C.c_int32()
+    _ck(load().taurow_bounds(ny, world, rank, C.byref(y0), C.byref(nyl)))
+    return y0.value, nyl.value
+
+
+def gs_pattern_host(nx, ny, seed=1337):
+    """init_pattern of tau_gray_scott.cu:173-204 as two (ny, nx) host arrays (taugs_pattern_host)"""
+    u, v = np.empty((ny, nx), np.float32), np.empty((ny, nx), np.float32)
+    _ck(load().taugs_pattern_host(nx, ny, seed, u.ctypes.data, v.ctypes.data))
+    return u, v
+
+
+class RowRing:
+    """taugs_ring_* / taulap_ring_*: the row-slab ring inside the library (csrc/ring.hip) around one GrayScott or Laplacian2D
+    handle created with ny = nyl + 2 * halo rows.  transport: RING_RCCL, RING_HOST (ranks may share a device), RING_LOCAL (world 1)."""
+
+    def __init__(self, eng, halo, rank, world, transport=RING_RCCL, rendezvous=None, job_key=0):
+        self._L = eng._L
+        self.eng, self.halo = eng, halo
+        self._r = C.c_void_p()
+        create = self._L.taugs_ring_create if isinstance(eng, GrayScott) else self._L.taulap_ring_create
+        _ck(create(C.byref(self._r), eng._h, halo, rank, world, transport, rendezvous.encode() if rendezvous else None, job_key))
+
+    def close(self):
+        if getattr(self, "_r", None):
+            self._L.taurow_ring_destroy(self._r)
+            self._r = None
+
+    __del__ = close
+
+    def exchange(self):
+        _ck(self._L.taurow_ring_exchange_async(self._r))
+
+    def step(self, n):
+        _ck(self._L.taurow_ring_step_async(self._r, n))
+
+    def finish(self):
+        _ck(self._L.taurow_ring_finish(self._r))
+
+    def barrier(self):
+        _ck(self._L.taurow_ring_barrier(self._r))
+
+    def info(self):
+        nyl, halo, ver, ranks, ex = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_long()
+        _ck(self._L.taurow_ring_info(self._r, C.byref(nyl), C.byref(halo), C.byref(ex), C.byref(ver), C.byref(ranks)))
+        return {"nyl": nyl.value, "halo": halo.value, "exchanges": ex.value, "rccl_version": ver.value, "comm_ranks": ranks.value}
 
 
 class GrayScott:

@@ -329,6 +329,10 @@ int taugs_init_pattern(taugs_t *h, uint32_t seed);                         /* :1
 int taugs_upload(taugs_t *h, const float *u, const float *v);
 int taugs_download(taugs_t *h, float *u, float *v);
 int taugs_state_ptrs(taugs_t *h, float **u, float **v);
+int taugs_info(taugs_t *h, int *nx, int *ny, int *device, void **stream);   /* any pointer may be NULL */
+/* init_pattern (tau_gray_scott.cu:173-204) into host arrays of nx * ny floats (what taugs_init_pattern uploads): a row-slab
+ * rank cuts its rows, halo rows included, out of the global pattern */
+int taugs_pattern_host(int nx, int ny, uint32_t seed, float *u, float *v);
 int taugs_step(taugs_t *h, int nsteps);                                    /* :321-329 */
 int taugs_step_async(taugs_t *h, int nsteps);
 /* time levels per launch: 0 = default (four levels fused per pass, the remainder as single steps), 1 = one launch per
@@ -347,10 +351,41 @@ void taulap_destroy(taulap_t *h);
 int taulap_upload(taulap_t *h, const float *a, const float *b);
 int taulap_download(taulap_t *h, float *a, float *b);
 int taulap_state_ptrs(taulap_t *h, float **a, float **b);
+int taulap_info(taulap_t *h, int *nx, int *ny, int *device, void **stream);
 int taulap_set_dt(taulap_t *h, float dt);
 int taulap_step(taulap_t *h, int npasses);
 int taulap_step_async(taulap_t *h, int npasses);
 int taulap_sync(taulap_t *h);
+
+/* ---- row-slab ring of the two periodic 5-point-stencil handles above (csrc/ring.hip; SURVEY §8e, no reference counterpart: the
+ * reference is single-GPU, the loop sharded is tau_gray_scott.cu:321-329 / the viscosity calls of tau_burgers.cu:490-525 and
+ * tau_shallow_water.cu:516-547).  Rank r of `world` owns rows [y0, y0 + nyl) (taurow_bounds) and creates ITS handle with
+ * ny = nyl + 2 * halo rows; the ring steps it `halo` time levels at a time and refreshes the halo rows from the ring neighbours in
+ * between — owned rows are bit-identical to the single-domain run (a 5-point stencil carries the wrap-around error one row per
+ * step).  transport: TAU3D_RING_RCCL (one device per rank), TAU3D_RING_HOST (ranks may share a device), TAU3D_RING_LOCAL
+ * (world 1).  rendezvous / job_key as for tau3d_ring_create.  Upload the local rows INCLUDING halo rows (or upload anything and
+ * call *_ring_exchange_async once: the halos are then current). */
+typedef struct taurow_ring taurow_ring_t;
+int taurow_bounds(int ny, int world, int rank, int *y0, int *nyl);
+int taugs_ring_create(taurow_ring_t **out, taugs_t *h, int halo, int rank, int world, int transport, const char *rendezvous, uint64_t job_key);
+int taugs_ring_step_async(taurow_ring_t *r, int nsteps);
+int taugs_ring_exchange_async(taurow_ring_t *r);
+int taugs_ring_finish(taurow_ring_t *r);
+int taugs_ring_barrier(taurow_ring_t *r);
+void taugs_ring_destroy(taurow_ring_t *r);
+int taulap_ring_create(taurow_ring_t **out, taulap_t *h, int halo, int rank, int world, int transport, const char *rendezvous, uint64_t job_key);
+int taulap_ring_step_async(taurow_ring_t *r, int npasses);
+int taulap_ring_exchange_async(taurow_ring_t *r);
+int taulap_ring_finish(taurow_ring_t *r);
+int taulap_ring_barrier(taurow_ring_t *r);
+void taulap_ring_destroy(taurow_ring_t *r);
+/* the same ring under its own name (one implementation) */
+int taurow_ring_step_async(taurow_ring_t *r, int nsteps);
+int taurow_ring_exchange_async(taurow_ring_t *r);
+int taurow_ring_finish(taurow_ring_t *r);
+int taurow_ring_barrier(taurow_ring_t *r);
+void taurow_ring_destroy(taurow_ring_t *r);
+int taurow_ring_info(taurow_ring_t *r, int *nyl, int *halo, long *exchanges, int *rccl_version, int *comm_ranks);
 
 /* =====================================================================
  * Full Burgers (kind 0) and shallow-water (kind 1) programs — replace do_step of

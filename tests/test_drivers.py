@@ -98,6 +98,18 @@ def test_tau3d_multi_rank_refuses_without_gpu(built):
     assert "rccl | ipc | host | ipc-host" in run(os.path.join(built, "tau3d"), "--transport", "mpi").stderr
 
 
+def test_tgs_multi_rank_refuses_without_gpu(built):
+    """tgs --gpus N (the row-slab ring in the library, round 5) forks its ranks before touching the HIP runtime as well"""
+    import fluid_sims_amd as f
+    if f.load().tau_device_available():
+        pytest.skip("a GPU is visible")
+    r = run(os.path.join(built, "tgs"), "--nx", "64", "--ny", "64", "--steps", "4", "--gpus", "2", "--transport", "host")
+    assert r.returncode == 1 and r.stderr.count("no CPU path") == 2 and "rank 1 exited with 1" in r.stderr
+    assert run(os.path.join(built, "tgs"), "--gpus", "0").returncode == 1
+    assert "rccl | host" in run(os.path.join(built, "tgs"), "--transport", "mpi").stderr
+    assert run(os.path.join(built, "tgs"), "--halo", "0").returncode == 1
+
+
 @pytest.mark.gpu
 def test_tgs_getopt_forms(built):
     """`--nx=64 --st=20` (getopt_long forms of the reference, tau_gray_scott.cu:95-104) run the same problem as the spaced forms"""
