@@ -225,10 +225,18 @@ __device__ __forceinline__ C4 hlle(const Args &A, P4 L, P4 R, C4 UL, C4 UR, C4 F
 __device__ __forceinline__ C4 hllc(const Args &A, P4 L, P4 R, int ax) {
   L.r = fmaxf(L.r, EPS_RHO); R.r = fmaxf(R.r, EPS_RHO);
   L.p = fmaxf(L.p, EPS_P);   R.p = fmaxf(R.p, EPS_P);
-  C4 UL = p2c(A, L), UR = p2c(A, R);
   float unL = ax ? L.v : L.u, unR = ax ? R.v : R.u, utL = ax ? L.u : L.v, utR = ax ? R.u : R.v;
   float aL = sound(A, L), aR = sound(A, R);
   float SL = fminf(unL - aL, unR - aR), SR = fmaxf(unL + aL, unR + aR);
+#ifndef TAU_H2_SUPER_WAVE
+#define TAU_H2_SUPER_WAVE 1
+#endif
+#if TAU_H2_SUPER_WAVE
+  // every face of the wave supersonic to the right (the x faces ahead of and through most of the bow shock): the left flux alone,
+  // before the right state's conserved vector and flux exist (round 5; the per-lane return below leaves them computed)
+  if (__builtin_amdgcn_ballot_w64(!(SL >= 0.0f)) == 0ull) return flux_p(A, L, p2c(A, L), ax);
+#endif
+  C4 UL = p2c(A, L), UR = p2c(A, R);
   C4 FL = flux_p(A, L, UL, ax), FR = flux_p(A, R, UR, ax);
   if (SL >= 0.0f) return FL;
   if (SR <= 0.0f) return FR;

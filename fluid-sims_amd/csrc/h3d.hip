@@ -467,6 +467,9 @@ __device__ __forceinline__ float vreg(float s) {
 __device__ __forceinline__ Gas gas_sgpr(const Args &A) { return Gas{A.gamma, A.gm1, A.inv_gm1}; }
 __device__ __forceinline__ Gas gas_vgpr(const Args &A) { return Gas{vreg(A.gamma), vreg(A.gm1), vreg(A.inv_gm1)}; }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+#ifndef TAU3D_EFIX_WAVE
+#define TAU3D_EFIX_WAVE 1
+#endif
 __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R, int axis) {
   const float rL = L.q[IR], rR = R.q[IR], pL = L.q[IP], pR = R.q[IP];
   const float irL = rcp(rL), irR = rcp(rR);
@@ -482,11 +485,19 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   const float aRef = fmaxf(aL, aR);
   const float iaRef = fminf(rsL, rsR);
   { // entropy_fix_speed, :366-374  (1/max(0.1 a, eps) == 10/a)
-    const float d = 0.1f * aRef, id = 10.f * iaRef;
+    const float d = 0.1f * aRef;
     float asl = fabsf(sL), asr = fabsf(sR);
-    float fl = 0.5f * (asl * asl * id + d), fr = 0.5f * (asr * asr * id + d);
-    sL = (asl >= d) ? sL : ((sL >= 0.f) ? fl : -fl);
-    sR = (asr >= d) ? sR : ((sR >= 0.f) ? fr : -fr);
+#if TAU3D_EFIX_WAVE
+    // the fix touches a signal speed within a tenth of the sound speed of zero — the sonic lines; a wave none of whose 64 faces
+    // is there skips its arithmetic and selects (round 5; same values: the selects below keep sL / sR wherever the test fails)
+    if (__builtin_amdgcn_ballot_w64(!(asl >= d) || !(asr >= d)) != 0ull)
+#endif
+    {
+      const float id = 10.f * iaRef;
+      float fl = 0.5f * (asl * asl * id + d), fr = 0.5f * (asr * asr * id + d);
+      sL = (asl >= d) ? sL : ((sL >= 0.f) ? fl : -fl);
+      sR = (asr >= d) ? sR : ((sR >= 0.f) ? fr : -fr);
+    }
   }
   // conserved states and physical fluxes, :234-245, 268-308
   const float keL = 0.5f * (L.q[IU] * L.q[IU] + L.q[IV] * L.q[IV] + L.q[IW] * L.q[IW]);
@@ -495,7 +506,24 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   const float gL = A.gm1 * rL, gR = A.gm1 * rR;
   const float ethL = (gL >= RHO_P_FLOOR) ? pL * irL * A.inv_gm1 : pL * (1.f / RHO_P_FLOOR);
   const float ethR = (gR >= RHO_P_FLOOR) ? pR * irR * A.inv_gm1 : pR * (1.f / RHO_P_FLOOR);
+#ifndef TAU3D_HLLC_SUPER_WAVE
+#define TAU3D_HLLC_SUPER_WAVE 0   // measured, not kept
+#endif
   Cons UL, UR, FL, FR;
+#if TAU3D_HLLC_SUPER_WAVE
+  // Timing build only (round 5): every face of the wave supersonic to the right — the x faces of the free stream at Mach 100 — takes
+  // the left flux alone, formed before the right state's conserved vector and flux exist.  With all three axes k_update_z went
+  // 2.14 -> 2.57 ms (no room in its allocation for the second exit) while k_flux_xy read 3.37 -> 3.17 — which was the chip clocking
+  // up behind the slower z kernel: restricted to the x / y faces the same k_flux_xy measures 3.29 -> 3.28 ms (79 VGPRs against 75).
+  if (axis != 2 && __builtin_amdgcn_ballot_w64(!(sL >= 0.f)) == 0ull) {
+    UL.c[1] = rL * L.q[IU]; UL.c[2] = rL * L.q[IV]; UL.c[3] = rL * L.q[IW]; UL.c[5] = rL * L.q[IE];
+    const float HL0 = pL * irL + (keL + L.q[IE]) + ethL;
+    FL.c[0] = rL * unL; FL.c[1] = UL.c[1] * unL; FL.c[2] = UL.c[2] * unL; FL.c[3] = UL.c[3] * unL;
+    FL.c[4] = rL * HL0 * unL; FL.c[5] = UL.c[5] * unL;
+    if (axis == 0) FL.c[1] += pL; else if (axis == 1) FL.c[2] += pL; else FL.c[3] += pL;
+    return FL;
+  }
+#endif
   UL.c[0] = rL; UL.c[1] = rL * L.q[IU]; UL.c[2] = rL * L.q[IV]; UL.c[3] = rL * L.q[IW];
   UL.c[4] = rL * (keL + ethL + L.q[IE]); UL.c[5] = rL * L.q[IE];
   UR.c[0] = rR; UR.c[1] = rR * R.q[IU]; UR.c[2] = rR * R.q[IV]; UR.c[3] = rR * R.q[IW];
