@@ -229,7 +229,7 @@ __device__ __forceinline__ C4 hllc(const Args &A, P4 L, P4 R, int ax) {
   float aL = sound(A, L), aR = sound(A, R);
   float SL = fminf(unL - aL, unR - aR), SR = fmaxf(unL + aL, unR + aR);
 #ifndef TAU_H2_SUPER_WAVE
-#define TAU_H2_SUPER_WAVE 1
+#define TAU_H2_SUPER_WAVE 0   // measured, not kept: 60.07 against 60.61 Gcell/s at 4096^2 (round 5)
 #endif
 #if TAU_H2_SUPER_WAVE
   // every face of the wave supersonic to the right (the x faces ahead of and through most of the bow shock): the left flux alone,
@@ -238,6 +238,9 @@ __device__ __forceinline__ C4 hllc(const Args &A, P4 L, P4 R, int ax) {
 #endif
   C4 UL = p2c(A, L), UR = p2c(A, R);
   C4 FL = flux_p(A, L, UL, ax), FR = flux_p(A, R, UR, ax);
+  // (round 5, measured and not kept: the ladder of returns below flattened into one straight-line star-state path with a single
+  //  degeneracy flag and one HLLE evaluation per wave that needs it — 57.1 against 60.0 Gcell/s at 4096^2: the returns, divergent as
+  //  they are, let the supersonic x faces skip the star state; profiles/r05/ab2d_euler_hllc.txt)
   if (SL >= 0.0f) return FL;
   if (SR <= 0.0f) return FR;
   float num = R.p - L.p + L.r * unL * (SL - unL) - R.r * unR * (SR - unR);
