@@ -39,7 +39,7 @@ def line(name, unit, rate, ms, bytes_per_unit, bound, extra=None):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--quick", action="store_true")
-    ap.add_argument("--only", default=None, help="sph_developed: the SPH developed state alone (1 520 sub-steps in, then the timed tail)")
+    ap.add_argument("--only", default=None, help="sph_developed: the SPH developed state alone (1 720 sub-steps in, then the 200 bench.py times)")
     a = ap.parse_args()
     k = 0.25 if a.quick else 1.0
 
@@ -47,11 +47,11 @@ def main():
         N = 1 << 22
         s = f.Sph2D(N)
         s.reset_particles()
-        s.step_async(1520)
+        s.step_async(1720)        # bench.py: 20 + 200 (its lattice window) + 1 500 sub-steps before the developed window
         s.sync()
-        r, ms = timed(s.step_async, s.sync, N, 50, 0)
-        line(f"tau_sph {N} particles, developed state (1 520 sub-steps after reset)", "particle-substeps", r, ms, 100, "pair-evaluation valu",
-             {"grid": s.grid(), "timed_substeps": 50})
+        r, ms = timed(s.step_async, s.sync, N, 200, 0)      # the window bench.py times: sub-steps 1 720 .. 1 920
+        line(f"tau_sph {N} particles, developed state (1 720 sub-steps after reset)", "particle-substeps", r, ms, 100, "pair-evaluation valu",
+             {"grid": s.grid(), "timed_substeps": 200})
         s.close()
         return
 

@@ -200,7 +200,11 @@ def main():
         n = sum(tot.values())
         print(f"  {'sum of the phases':58s}         {fmt(tot)}")
         if sq:
-            print(f"  executed (SQ_INSTS_VALU / cell): {sq:.0f}  ->  staging, addressing, selects, divergence, control: {sq - n:.0f} ({100 * (sq - n) / sq:.0f} %)")
+            print(f"  executed (SQ_INSTS_VALU / cell): {sq:.0f}  =  sum of the phases {sq - n:+.0f} ({100 * (sq - n) / sq:+.0f} %)")
+            print("    (the static sum is an UPPER bound of the arithmetic — it takes every wave-uniform branch: both sinh forms of each decoded\n"
+                  "     velocity [fsinh_wave runs one], the entropy fix [skipped away from sonic lines], HLLC's star-state path behind the supersonic\n"
+                  "     return [the free stream's x faces leave at it], tiles inside the body — and a LOWER bound of the rest: staging, addressing,\n"
+                  "     selects, the divergence and control are not in it.  Executed below the sum = the branches pay more than the rest costs.)")
 
 
 if __name__ == "__main__":

@@ -8,7 +8,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/profiles_$TAG
 mkdir -p "$OUT"
-CMD="python bench.py --steps 10 --warmup 5 --no-cpu-baseline --no-variants --no-configs"
+CMD="python bench.py --steps 20 --warmup 10 --no-cpu-baseline --no-variants --no-configs"   # bench.py's default window
 run() { # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
@@ -32,7 +32,7 @@ runlast() { # name, rocprof args...
   local name=$1; shift
   rm -rf /tmp/rp_$name
   rocprofv3 "$@" -d /tmp/rp_$name -o x -- $CMD > /tmp/rp_$name.log 2>&1
-  { echo "# rocprofv3 $* -- $CMD   (summary: the last 50 dispatches of every kernel = the timed sub-steps)"; grep -E '^\{"workload"' /tmp/rp_$name.log | cut -c1-400; python scripts/rocpd_summary.py /tmp/rp_$name/x_results.db --last 50; } > "$OUT/$name.txt"
+  { echo "# rocprofv3 $* -- $CMD   (summary: the last 200 dispatches of every kernel = the timed sub-steps)"; grep -E '^\{"workload"' /tmp/rp_$name.log | cut -c1-400; python scripts/rocpd_summary.py /tmp/rp_$name/x_results.db --last 200; } > "$OUT/$name.txt"
 }
 runlast sphdev_stats --kernel-trace --stats
 runlast sphdev_fetch --pmc FETCH_SIZE
