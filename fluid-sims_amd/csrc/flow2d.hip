@@ -680,6 +680,7 @@ struct tauflow {
   taulap_t *visc;   // Burgers: extra viscosity passes (K > 1) through the marching kernel
   int *crow = nullptr;   // chunk schedule of the march (flow_schedule)
   int crow_n = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // tauflow_timer_*: device time of a stretch of launches (lazy)
 };
 
 extern "C" void tauflow_params_default(tauflow_params *P, int kind, int nx, int ny) {
@@ -726,6 +727,8 @@ extern "C" void tauflow_destroy(tauflow_t *h) {
   for (int s = 0; s < 2; s++)
     for (int f = 0; f < h->nf; f++) hipFree(h->buf[s][f]);
   hipFree(h->st); hipFree(h->crow);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
   if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -909,6 +912,27 @@ extern "C" int tauflow_step_async(tauflow_t *h, int nsteps) { // headless loop b
     h->t *= expf(h->p.dtau);
     h->step++;
   }
+  return 0;
+}
+/* Device time of what is enqueued between the two calls, from events on the handle's stream — what the reference's headless
+ * summaries print as "GPU" / "GPU only" (cudaEvent pairs, tau_burgers.cu:790-820, tau_shallow_water.cu:751-782).  stop
+ * waits for the stream. */
+extern "C" int tauflow_timer_start(tauflow_t *h) {
+  if (!h) return tau::fail("tauflow_timer_start: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  if (!h->ev0) { TAU_HIP(hipEventCreate(&h->ev0)); TAU_HIP(hipEventCreate(&h->ev1)); }
+  TAU_HIP(hipEventRecord(h->ev0, h->stream));
+  return 0;
+}
+extern "C" int tauflow_timer_stop(tauflow_t *h, double *ms) {
+  if (!h || !ms) return tau::fail("tauflow_timer_stop: null argument");
+  if (!h->ev0) return tau::fail("tauflow_timer_stop: no tauflow_timer_start before it");
+  TAU_HIP(hipSetDevice(h->device));
+  TAU_HIP(hipEventRecord(h->ev1, h->stream));
+  TAU_HIP(hipEventSynchronize(h->ev1));
+  float f = 0.f;
+  TAU_HIP(hipEventElapsedTime(&f, h->ev0, h->ev1));
+  *ms = (double)f;
   return 0;
 }
 extern "C" int tauflow_sync(tauflow_t *h) {

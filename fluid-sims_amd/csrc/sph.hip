@@ -932,9 +932,15 @@ extern "C" int tausph_create(tausph_t **out, const tausph_params *P, int device,
   TAU_HIP(hipMalloc(&A.recA, N * sizeof(float4))); TAU_HIP(hipMalloc(&A.recB, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.recP, N * sizeof(float2)));
   TAU_HIP(hipMalloc(&A.nbrMask, N * sizeof(unsigned) * 12));
-  // overflow-block masks (720 B per particle; written and read only where a row holds more than 128 candidates)
-  if (!(getenv("TAU_SPH_OVFMASK") && atoi(getenv("TAU_SPH_OVFMASK")) == 0))
-    TAU_HIP(hipMalloc(&A.ovfMask, N * sizeof(unsigned) * 3 * sph::OVW));
+  // overflow-block masks (720 B per particle — 3 GB at 4 M particles; written and read only where a row holds more than 128
+  // candidates).  An optimisation, not a requirement: without them the force pass scans the overflow blocks again (MODE 0), same
+  // results — so a device that cannot spare the buffer runs without it instead of failing the create.
+  if (!(getenv("TAU_SPH_OVFMASK") && atoi(getenv("TAU_SPH_OVFMASK")) == 0)) {
+    if (hipMalloc(&A.ovfMask, N * sizeof(unsigned) * 3 * sph::OVW) != hipSuccess) {
+      (void)hipGetLastError();
+      A.ovfMask = nullptr;
+    }
+  }
   A.xsphEps = P->xsphEps;
   if (P->useXSPH && P->xsphEps > 0.f) TAU_HIP(hipMalloc(&A.recA2, N * sizeof(float4)));
   if (P->rain) {

@@ -230,6 +230,7 @@ def load():
         "tauflow_get_clock": ([vp, C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(f32), C.POINTER(C.c_int64)], i32),
         "tauflow_colehopf_relL2": ([vp, f32, C.POINTER(C.c_double)], i32),
         "tauflow_sync": ([vp], i32),
+        "tauflow_timer_start": ([vp], i32), "tauflow_timer_stop": ([vp, C.POINTER(C.c_double)], i32),
         "taugs_params_default": ([C.POINTER(GSParams), i32, i32], None),
         "taugs_create": ([C.POINTER(vp), C.POINTER(GSParams), i32, vp], i32),
         "taugs_destroy": ([vp], None),

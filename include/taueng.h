@@ -407,6 +407,10 @@ int tauflow_step_explicit(tauflow_t *h, float dt);          /* one do_step with 
 int tauflow_get_clock(tauflow_t *h, float *t, float *tau, float *dt_last, float *wavespeed, int64_t *step);
 int tauflow_colehopf_relL2(tauflow_t *h, float t_now, double *rel);   /* tau_burgers.cu:720-736 */
 int tauflow_sync(tauflow_t *h);
+/* device time (ms) of what is enqueued between the two calls, from events on the handle's stream: the "GPU" / "GPU only" line of
+ * the reference's headless summaries (cudaEvent pairs, tau_burgers.cu:790-820, tau_shallow_water.cu:751-782) */
+int tauflow_timer_start(tauflow_t *h);
+int tauflow_timer_stop(tauflow_t *h, double *ms);
 
 /* =====================================================================
  * D2Q9 BGK lattice Boltzmann — replaces the launches of tau_lbm.cu:245-247 (init) and the loop body
