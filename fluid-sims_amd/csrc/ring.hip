@@ -21,8 +21,9 @@
 // selects the round-4 pipelined schedules (ring_step_pipelined / _packed: all-reduce first, then the exchange beside the x/y launch).
 //
 // No host synchronisation between the pieces: tau3d_ring_step_async(n) only enqueues.  One communicator, used on ONE stream
-// (X) in the default schedule — tau3d_ring_prime's all-reduce on the direct transports is issued on S, once, between two host
-// synchronisations of both streams — so RCCL sees its operations in one order on every rank.
+// (X) in the default and the round-4 pipelined schedules, tau3d_ring_prime included, so RCCL sees its operations in one order on
+// every rank.  (TAU3D_RING_PIPELINE=0 and TAU3D_RING_AR_ON_S=1 put the direct transport's all-reduce on S, behind the interior
+// launch; RCCL then orders the operations of two user streams.)
 //
 // Transports:
 //   TAU3D_RING_RCCL   ncclSend / ncclRecv / ncclAllReduce over xGMI.  librccl is bound at run time (dlopen) — the copy the
@@ -691,7 +692,12 @@ static int ring_prime_impl(tau3d_ring *r) {
     }
     TAU_HIP(hipEventRecord(r->evE, r->S));
     TAU_HIP(hipEventRecord(r->evI, r->S));
-    if (communicate(r, true, 0)) return 1;
+    if (r->pipelined && r->transport == TAU3D_RING_IPC) {
+      // as the default step does it: copies, then the all-reduce, both on X — the communicator never sees another stream
+      TAU_HIP(hipStreamWaitEvent(r->X, r->evE, 0));
+      if (exchange_ipc(r, 0) || ring_allreduce(r, r->X)) return 1;
+      TAU_HIP(hipEventRecord(r->evX, r->X));
+    } else if (communicate(r, true, 0)) return 1;
     TAU_HIP(hipStreamSynchronize(r->X));
     TAU_HIP(hipStreamSynchronize(r->S));
     if (r->sh && ring::barrier(r->sh, "prime: halos landed")) return 1;
