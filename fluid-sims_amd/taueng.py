@@ -866,6 +866,15 @@ class Flow2D:
         _ck(self._L.tauflow_colehopf_relL2(self._h, t_now, C.byref(r)))
         return r.value
 
+    def timer_start(self):
+        """device time of what is enqueued until timer_stop (events on the handle's stream): tauflow_timer_*"""
+        _ck(self._L.tauflow_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = C.c_double()
+        _ck(self._L.tauflow_timer_stop(self._h, C.byref(ms)))
+        return ms.value
+
     def sync(self):
         _ck(self._L.tauflow_sync(self._h))
 

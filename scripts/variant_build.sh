@@ -10,7 +10,7 @@ OUT=../build_var/$NAME; mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -fno-slp-vectorize -Wno-unused-function -Wno-sometimes-uninitialized -Wno-unused-value -Wno-unused-const-variable -ffp-contract=on"
 $HIPCC $FLAGS $DEFS -c csrc/h3d.hip -o "$OUT/h3d.o" &
-$HIPCC $FLAGS $DEFS -DTAU3D_SPLIT_TU -mllvm -amdgpu-sched-strategy=max-ilp -c csrc/h3d.hip -o "$OUT/h3d_split.o" &
+$HIPCC $FLAGS $DEFS -DTAU3D_SPLIT_TU -mllvm -amdgpu-sched-strategy=${SCHED:-max-ilp} -c csrc/h3d.hip -o "$OUT/h3d_split.o" &
 wait
 OBJS=$(ls build/*.o | grep -v -E '/h3d(_split)?\.o$')
 g++ -shared -fPIC -o "$OUT/libtaueng.so" $OBJS "$OUT/h3d.o" "$OUT/h3d_split.o" -ldl

@@ -171,3 +171,31 @@ def test_marching_step_agrees_with_the_tile_step(eng, tmp_path, kind, nx, ny, kw
             assert np.isfinite(a[k]).all()
             scale = max(float(np.abs(b[k]).max()), 1e-30)
             assert float(np.abs(a[k].astype(np.float64) - b[k]).max()) <= 1e-4 * scale, k
+
+
+def test_device_timer_brackets_the_launches(eng):
+    """tauflow_timer_*: the "GPU" line of the reference's headless summaries (cudaEvent pairs, tau_burgers.cu:790-820) — events on
+    the handle's stream around the launches; the program's own summary prints it beside the wall clock"""
+    import os
+    import re
+    import subprocess
+    import time
+    f = eng.Flow2D("burgers", 1024, 1024, dtau=0.01)
+    f.init()
+    f.step_async(5)
+    f.sync()
+    t0 = time.perf_counter()
+    f.timer_start()
+    f.step_async(50)
+    ms = f.timer_stop()
+    wall = (time.perf_counter() - t0) * 1e3
+    f.close()
+    assert 0.0 < ms <= wall * 1.05, (ms, wall)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "bin", "tau_burgers"), "--headless", "--nx", "512", "--ny", "512", "--steps", "200"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    w = re.search(r"Wall:\s+(\d+) frames in ([0-9.]+) s", r.stdout)
+    g = re.search(r"GPU:\s+(\d+) frames in ([0-9.]+) s", r.stdout)
+    assert w and g and w.group(1) == g.group(1), r.stdout
+    assert 0.0 < float(g.group(2)) <= float(w.group(2)) + 1e-3, r.stdout
