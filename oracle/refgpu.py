@@ -639,6 +639,24 @@ class RefFlow:
                                                               f32(self.dx), f32(self.dy), f32(dt), f32(self.g)])
         self.m.sync()
 
+    def viscosity_single_wave(self, nu, dt, block):
+        """The reference's in-place viscosity kernel (tau_burgers.cu:490-525 viscosity_step, tau_shallow_water.cu:516-547
+        viscosity_uv) launched as ONE workgroup of ONE wave (block = the whole grid, nx * ny = 64 cells).  As the programs launch it
+        (16 x 16 blocks over a large grid) its result depends on the order in which threads overwrite the cells their neighbours
+        still have to read — no defined answer, SURVEY §2.1.  Inside a single wave64 it has one: every load of the kernel precedes
+        its stores in the instruction stream, the stored values depend on the loaded ones (so the wave waits for ALL its lanes'
+        loads before the store instruction issues), and nobody else touches the arrays — the in-place update is the Jacobi step,
+        computed by the reference's own arithmetic.  That is the regime in which the kernel can referee."""
+        i32, f32 = C.c_int, C.c_float
+        nx, ny = self.nx, self.ny
+        assert nx * ny == 64 and block[0] * block[1] == 64 and block[0] == nx and block[1] == ny, "one wave covering the whole grid"
+        if self.kind == "burgers":
+            self.m.launch("viscosity_step", (1, 1), block, [_p(self.f[0]), _p(self.f[1]), i32(nx), i32(ny), f32(self.dx), f32(self.dy), f32(nu),
+                                                           f32(dt), f32(self.u0), i32(self.oneD)])
+        else:
+            self.m.launch("viscosity_uv", (1, 1), block, [_p(self.f[1]), _p(self.f[2]), i32(nx), i32(ny), f32(self.dx), f32(self.dy), f32(nu), f32(dt)])
+        self.m.sync()
+
     def close(self):
         for b in self.f + self.flux + [self.blk]:
             b.free()

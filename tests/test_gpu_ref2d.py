@@ -277,3 +277,42 @@ def test_flow_convective_step_vs_reference_kernels(eng, refgpu, kind, nx, ny, kw
     e.close()
     e2.close()
     r.close()
+
+
+# ---------------------------------------------------------------------------------------------------- viscosity passes (e1 / e2)
+@pytest.mark.parametrize("kind", ["sw", "burgers"])
+@pytest.mark.parametrize("nx,ny", [(8, 8), (16, 4), (4, 16), (32, 2), (2, 32)])
+def test_viscosity_pass_vs_reference_kernel_single_wave(eng, refgpu, kind, nx, ny):
+    """The referee the round-4 review found missing for SURVEY §8 rows e1 / e2.  The reference's viscosity kernels update their
+    arrays in place and race as the programs launch them; launched as ONE wave covering the whole (64-cell, periodic) grid they do
+    not — every load of the kernel precedes its stores, and the stores wait for the wave's loads (oracle/refgpu.py:
+    viscosity_single_wave) — and compute the Jacobi step with the reference's own arithmetic.  The engine's ping-pong pass against
+    that, five passes: shallow water bit for bit (IEEE build of the reference), Burgers within the fp32 tolerance of its sinh /
+    asinh codec; and the Makefile (-use_fast_math) build of the reference beside it."""
+    rng = np.random.default_rng(1000 * nx + ny)
+    a = (0.7 * rng.standard_normal((ny, nx))).astype(np.float32)
+    b = (0.7 * rng.standard_normal((ny, nx))).astype(np.float32)
+    nu, dt, dx, dy, u0, K = 0.1, 0.2, 1.0, 1.25, 1.5, 5
+    h = eng.Laplacian2D(nx, ny, kind, nu, dt, dx=dx, dy=dy, u0=u0)
+    h.upload(a, b)
+    h.step(K)
+    ga, gb = h.download()
+    h.close()
+    for fast in (False, True):
+        r = refgpu.RefFlow(kind, nx, ny, dx, dy, u0=u0, fast=fast)
+        fields = [a, b] if kind == "burgers" else [np.zeros_like(a), a, b]      # shallow water: (sigma, u, v), the pass touches u, v
+        r.upload(fields)
+        for _ in range(K):
+            r.viscosity_single_wave(nu, dt, (nx, ny))
+        out = r.download()
+        wa, wb = (out[0], out[1]) if kind == "burgers" else (out[1], out[2])
+        r.close()
+        if kind == "sw" and not fast:
+            assert np.array_equal(ga, wa) and np.array_equal(gb, wb), "shallow-water viscosity pass: not the reference kernel's bits"
+        else:
+            if kind == "burgers":   # decoded velocities against their scale, and the encoded arrays
+                du = np.abs(u0 * np.sinh(ga.astype(np.float64)) - u0 * np.sinh(wa.astype(np.float64))).max()
+                dv = np.abs(u0 * np.sinh(gb.astype(np.float64)) - u0 * np.sinh(wb.astype(np.float64))).max()
+                sc = max(np.abs(u0 * np.sinh(wa.astype(np.float64))).max(), np.abs(u0 * np.sinh(wb.astype(np.float64))).max())
+                assert max(du, dv) <= 1e-5 * sc, (du, dv, sc)
+            assert max(np.abs(ga - wa).max(), np.abs(gb - wb).max()) <= 1e-5, (kind, fast)
