@@ -223,7 +223,9 @@ struct tau3d_ring : tau_rendezvous {
   int lo = 0, hi = 0;
   int nzl = 0, edge = 3, device = 0;
   hipStream_t S = nullptr, X = nullptr;
+  hipStream_t X2 = nullptr;      // direct transports: the copies towards the HIGH neighbour (another xGMI link than the low one's)
   hipEvent_t evE = nullptr, evI = nullptr, evX = nullptr, evH = nullptr;
+  hipEvent_t evJ = nullptr, evC2 = nullptr;   // fork of X2 from X / its join back (exchange_ipc)
   float *syncw = nullptr;        // one device word: the all-reduce that says "my halo copies have landed" (pipelined direct step)
   bool pipelined = false;        // x/y fluxes of step n+1 overlap the exchange of step n (ring_step_pipelined*; every transport)
   bool spec = false;             // ... and start AHEAD of all-reduce(n) (ring_step_spec): one all-reduce per step, off the critical path
@@ -382,6 +384,9 @@ extern "C" void tau3d_ring_destroy(tau3d_ring_t *r) {
   if (r->evX) hipEventDestroy(r->evX);
   if (r->evH) hipEventDestroy(r->evH);
   if (r->syncw) hipFree(r->syncw);
+  if (r->evJ) hipEventDestroy(r->evJ);
+  if (r->evC2) hipEventDestroy(r->evC2);
+  if (r->X2) { hipStreamSynchronize(r->X2); hipStreamDestroy(r->X2); }
   if (r->X) hipStreamDestroy(r->X);
   if (r->sh) {
     munmap(r->sh, r->sh_bytes);
@@ -434,6 +439,12 @@ static int ring_create_impl(tau3d_ring *r, tau3d_t *h, int rank, int world, int 
   if (r->direct()) {
     TAU_HIP(hipMalloc(&r->syncw, sizeof(float)));
     TAU_HIP(hipMemset(r->syncw, 0, sizeof(float)));
+    const char *e = getenv("TAU3D_RING_ONE_COPY_STREAM");
+    if (!(e && atoi(e) != 0)) {
+      TAU_HIP(hipStreamCreateWithFlags(&r->X2, hipStreamNonBlocking));
+      TAU_HIP(hipEventCreateWithFlags(&r->evJ, hipEventDisableTiming));
+      TAU_HIP(hipEventCreateWithFlags(&r->evC2, hipEventDisableTiming));
+    }
   }
   if (tau3d_max_ptr(h, &r->maxw)) return 1;
 
@@ -633,11 +644,24 @@ static int exchange_ipc(tau3d_ring *r, int which) {
   if (tau3d_state_group(r->h, which, &base, nullptr, &stride, nullptr)) return 1;
   const float *me = (const float *)base;
   float *lo = r->peer_base[0][r->peer_cur[0] ^ which], *hi = r->peer_base[1][r->peer_cur[1] ^ which];
+  // The two directions go to two different peers over two different xGMI links: on ONE stream the twelve copies run one after the
+  // other — 37.7 MB at one link's rate, more than the x/y launch they are meant to hide behind —, so the copies towards the high
+  // neighbour take a second stream that forks from X here (whatever X waits for, X2 waits for) and joins it again below: what
+  // follows on X (the all-reduce, evX) still follows every copy.  (TAU3D_RING_ONE_COPY_STREAM=1: all on X, the round-4 form.)
+  hipStream_t xh = r->X2 ? r->X2 : r->X;
+  if (r->X2) {
+    TAU_HIP(hipEventRecord(r->evJ, r->X));
+    TAU_HIP(hipStreamWaitEvent(r->X2, r->evJ, 0));
+  }
   for (int f = 0; f < 6; f++) {
     // (hipMemcpyDefault: the destination is another device's memory behind an IPC mapping — the runtime resolves both ends)
     TAU_HIP(hipMemcpyAsync(lo + f * r->peer_stride[0] + (size_t)(r->peer_nzl[0] + 3) * plane_n, me + f * stride + 3 * plane_n, bytes,
                            hipMemcpyDefault, r->X));
-    TAU_HIP(hipMemcpyAsync(hi + f * r->peer_stride[1], me + f * stride + (size_t)r->nzl * plane_n, bytes, hipMemcpyDefault, r->X));
+    TAU_HIP(hipMemcpyAsync(hi + f * r->peer_stride[1], me + f * stride + (size_t)r->nzl * plane_n, bytes, hipMemcpyDefault, xh));
+  }
+  if (r->X2) {
+    TAU_HIP(hipEventRecord(r->evC2, r->X2));
+    TAU_HIP(hipStreamWaitEvent(r->X, r->evC2, 0));
   }
   return 0;
 }
