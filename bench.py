@@ -321,6 +321,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(_self_spawn(args.gpus))
 
+    if args.gpus > 1:   # before the HIP runtime comes up in this rank (the launcher's environment normally carries it already)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import fluid_sims_amd as f
