@@ -70,14 +70,29 @@ def kappa(want):
     return np.maximum(1.0, (GAMMA - 1) * E / p)
 
 
+THETA_V = 0.2       # tau3d_params_default (tau_hypersonic_3d_cuda.cu: theta_v)
+
+
+def kappa_zet(want):
+    """kappa for zet = ln e_v.  e_v relaxes towards e_eq(T) = R theta_v / (exp(theta_v / T) - 1), T = p / (rho R): beside the factor
+    kappa that T inherits from p, d ln e_eq = (theta_v / T) d ln T.  Where vibration is frozen out — theta_v / T > 10, e_eq below
+    5e-5 R theta_v — that second factor is what the error of zet consists of, and the cell's e_v is no energy to speak of.  Found by
+    scripts/fuzz_ref3d.py in round 5 (seed 12: 104 x 65 x 29, 22 steps in; scripts/fuzz_case3d.py): a wake cell with T = 3.9e-3,
+    theta_v / T = 52, e_v = 5.7e-24, kappa = 1.3e4 where the reference's OWN two builds differ by 6.5e-2 in zet (5.0e-6 kappa) and
+    every form of the engine's step (fused / split, fast / reciprocal weights: the same 0.2036) by 1.57e-5 kappa = 3.0e-7 kappa
+    theta_v / T.  Everywhere else (the free stream sits at theta_v / T = 2) the factor stays 1."""
+    r, u, v, w, p, ev = decode(want)
+    th_T = THETA_V * r * R_GAS / np.maximum(p, 1e-300)
+    return kappa(want) * np.where(th_T > 10.0, th_T, 1.0)
+
+
 def assert_parity(got, want, mask=None, what=""):
     r = report(got, want, mask)
     bad = {k: v for k, v in r.items()
            if k in ("xi", "phix", "phiy", "phiz", "rho", "mx", "my", "mz", "E")
            and v > (TOL_LOG if k == "xi" else TOL_PHI if k.startswith("phi") else TOL_CONS)}
     # conditioning-scaled fields
-    kap = kappa(want)
-    for name, idx in (("lam", 4), ("zet", 5)):
+    for name, idx, kap in (("lam", 4, kappa(want)), ("zet", 5, kappa_zet(want))):
         d = np.abs(np.asarray(got[idx], np.float64) - np.asarray(want[idx], np.float64)) / kap
         if mask is not None:
             d = d[mask]
