@@ -153,7 +153,7 @@ def _p(buf):
 
 
 # ------------------------------------------------------------------------------------------------------------------
-# 3D hypersonic: the device code of th3cs.cu (the headless twin of tau_hypersonic_3d_cuda.cu)
+# 3D hypersonic: the device code of tau_hypersonic_3d_cuda.cu (the file north_star names) and of th3cs.cu (its headless twin)
 # ------------------------------------------------------------------------------------------------------------------
 class Params3D(C.Structure):
     """th3cs.cu:69-90 == tau_hypersonic_3d_cuda.cu:21-42"""
@@ -187,10 +187,20 @@ class Ref3D:
     WENO_HALO = 3
     BLOCK = (8, 8, 4)
 
-    def __init__(self, nx, ny=None, nz=None, params=None, ieee=False):
+    SOURCES = {"th3cs": "th3cs", "3d_cuda": "tau_hypersonic_3d_cuda"}
+
+    def __init__(self, nx, ny=None, nz=None, params=None, ieee=False, source=None):
+        """source: "3d_cuda" = tau_hypersonic_3d_cuda.cu, the file north_star names (oracle/build_ref.sh's line cut 1-1409 minus
+        the raylib includes and the Vector3 helpers: k_step :987-1359, k_init :939-985, k_build_solid_mask :759-770, k_vis
+        :800-905, k_maxwavespeed_pre :909-937, k_schlieren :1361-1387, k_outflow_reflection_metric :1389-1408); "th3cs" = its
+        headless twin (adds k_schlieren_export).  Default: the named file when its code object is there, else the twin."""
         ny = nx if ny is None else ny
         nz = nx if nz is None else nz
-        self.m = RefModule("th3cs.ieee" if ieee else "th3cs")
+        if source is None:
+            source = "3d_cuda" if available("tau_hypersonic_3d_cuda") else "th3cs"
+        self.source = source
+        stem = self.SOURCES[source]
+        self.m = RefModule(stem + ".ieee" if ieee else stem)
         self.p = params3d_default(nx, ny, nz) if params is None else params
         self.m.set_global("P", self.p)
         self.shape = (self.p.nz, self.p.ny, self.p.nx)
@@ -238,6 +248,38 @@ class Ref3D:
                       shmem=self.smem)
         self.m.sync()
         self.a, self.b = self.b, self.a
+        return float(self.maxs.get(np.float32, (1,))[0])
+
+    def vis(self, mode):
+        """k_vis (tau_hypersonic_3d_cuda.cu:800-905, launched :1715-1716) of the current state, mode 0..7 (VisMode :784-794)"""
+        out = DevBuf(4 * self.N)
+        self.m.launch("k_vis", self.grid, self.BLOCK, [_p(x) for x in self.a] + [_p(self.solid), _p(out), C.c_int(int(mode))])
+        self.m.sync()
+        v = out.get(np.float32, self.shape)
+        out.free()
+        return v
+
+    def schlieren_xi(self):
+        """k_schlieren (tau_hypersonic_3d_cuda.cu:1361-1387): |grad rho| from xi alone, no solid handling"""
+        out = DevBuf(4 * self.N)
+        self.m.launch("k_schlieren", self.grid, self.BLOCK, [_p(self.a[0]), _p(out)])
+        self.m.sync()
+        v = out.get(np.float32, self.shape)
+        out.free()
+        return v
+
+    def outflow_reflection(self, nprobe=6):
+        """k_outflow_reflection_metric (tau_hypersonic_3d_cuda.cu:1389-1408) as the frame loop launches it (:1723-1733, nprobe 6)"""
+        self.maxs.put(np.zeros(1, np.float32))
+        self.m.launch("k_outflow_reflection_metric", self.grid, self.BLOCK, [_p(x) for x in self.a] + [_p(self.maxs), C.c_int(int(nprobe))])
+        self.m.sync()
+        return float(self.maxs.get(np.float32, (1,))[0])
+
+    def maxwavespeed_pre(self):
+        """k_maxwavespeed_pre (tau_hypersonic_3d_cuda.cu:909-937): max over fluid cells of sum_axes (|u_a| + a) / d_a"""
+        self.maxs.put(np.zeros(1, np.float32))
+        self.m.launch("k_maxwavespeed_pre", self.grid, self.BLOCK, [_p(x) for x in self.a] + [_p(self.solid), _p(self.maxs)])
+        self.m.sync()
         return float(self.maxs.get(np.float32, (1,))[0])
 
     def schlieren(self):

@@ -1,124 +1,61 @@
 #!/bin/bash
-# scripts/regen_checkvalues.sh — regenerates the CPU-solver check-values of tests/golden/ref_checkvalues.json from the
-# reference's own source and compares them with the committed digits.
+# scripts/regen_checkvalues.sh — regenerates the CPU-solver check-values of tests/golden/ref_checkvalues.json and the field
+# fixture tests/golden/cpu2d_ref_96x64_steps12_13.npz from the reference's own source and compares them with the committed data.
 #
-# BUILD CONTAINER ONLY: it needs /root/reference (absent on the GPU box; the path is in .gpurunignore) and works entirely in
-# a temporary directory — no reference source and no stand-in build enters the repository or travels anywhere.  This is
-# SURVEY.md §8(c) / Appendix A's recipe for the two CPU files: a declarations-only raylib.h (display types and no-op window
-# calls: the solver never reads anything from them), `#define main ref_main`, `#include "<reference file>"`, then the
-# file's own static init_sim() / step_physics() called directly.  It is NOT oracle/_ref (the task's rule: a reference that
-# needs stand-in headers is unbuildable; the oracles are pinned to the recorded outputs) — it only makes the
-# transcribed digits of the CPU entries reproducible.  The CUDA entries (2D / 3D / Gray-Scott / SPH) came from the survey's
-# host-side block emulator (Appendix A), which is not reproduced here.
+# BUILD CONTAINER ONLY (needs /root/reference; listed in .gpurunignore).  The programs it runs are oracle/_ref/libref_hyp_cpu*.so:
+# oracle/build_ref.sh's pure line cuts of tau_hypersonic.c (lines 1-674) and tau_hypersonic_simd.c (1-804) minus the raylib
+# include, compiled by gcc with the reference Makefile's flags — no stand-in header (the declarations-only raylib.h this script
+# used to write is gone).  The CUDA entries of the JSON (2D / 3D / Gray-Scott / SPH) came from the survey's host-side block
+# emulator (Appendix A); those are pinned on the GPU against oracle/_ref/*.co instead (tests/test_gpu_ref*.py).
 set -euo pipefail
-REF=${REF:-/root/reference}
-[ -f "$REF/tau_hypersonic.c" ] || { echo "regen_checkvalues: $REF/tau_hypersonic.c not found (build container only)"; exit 2; }
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-T=$(mktemp -d); trap 'rm -rf "$T"' EXIT
-mkdir -p "$T/stub"
-cat > "$T/stub/raylib.h" <<'H'
-/* declarations only: what the two CPU files mention of raylib; nothing here computes */
-#ifndef RAYLIB_H
-#define RAYLIB_H
-typedef struct { unsigned char r, g, b, a; } Color;
-typedef struct { void *data; int width, height, mipmaps, format; } Image;
-typedef struct { unsigned id; int width, height, mipmaps, format; } Texture2D;
-typedef struct { float x, y, width, height; } Rectangle;
-typedef struct { float x, y; } Vector2;
-enum { KEY_R = 82, KEY_M = 77, KEY_SPACE = 32, PIXELFORMAT_UNCOMPRESSED_R8G8B8A8 = 7 };
-#define WHITE ((Color){255, 255, 255, 255})
-#define BLACK ((Color){0, 0, 0, 255})
-#define GREEN ((Color){0, 228, 48, 255})
-#define RAYWHITE WHITE
-#define RED WHITE
-#define YELLOW WHITE
-#define GRAY WHITE
-static inline void InitWindow(int w, int h, const char *t) { (void)w; (void)h; (void)t; }
-static inline void SetTargetFPS(int f) { (void)f; }
-static inline Texture2D LoadTextureFromImage(Image i) { Texture2D t = {0, i.width, i.height, 1, i.format}; return t; }
-static inline int WindowShouldClose(void) { return 1; }
-static inline int IsKeyPressed(int k) { (void)k; return 0; }
-static inline int IsKeyDown(int k) { (void)k; return 0; }
-static inline void UpdateTexture(Texture2D t, const void *p) { (void)t; (void)p; }
-static inline void BeginDrawing(void) {}
-static inline void EndDrawing(void) {}
-static inline void ClearBackground(Color c) { (void)c; }
-static inline void DrawTexturePro(Texture2D t, Rectangle a, Rectangle b, Vector2 o, float r, Color c) { (void)t; (void)a; (void)b; (void)o; (void)r; (void)c; }
-static inline void DrawText(const char *s, int x, int y, int z, Color c) { (void)s; (void)x; (void)y; (void)z; (void)c; }
-static inline const char *TextFormat(const char *f, ...) { return f; }
-static inline void UnloadTexture(Texture2D t) { (void)t; }
-static inline void CloseWindow(void) {}
-static inline int GetFPS(void) { return 0; }
-static inline void DrawFPS(int x, int y) { (void)x; (void)y; }
-#endif
-H
-cat > "$T/harness.c" <<'C'
-#define main ref_main
-#include REF_FILE
-#undef main
-#include <stdio.h>
-int main(int argc, char **argv) {
-  int steps = argc > 1 ? atoi(argv[1]) : 1;
-  init_sim();
-  for (int s = 0; s < steps; s++) step_physics();
-  double sr = 0, sm = 0, sE = 0; long fluid = 0;
-  for (int i = 0; i < W * H; i++) if (!mask[i]) { fluid++; sr += U[i].rho; sm += U[i].mx; sE += U[i].E; }
-  printf("{\"t\": %.17g, \"fluid\": %ld, \"sum_rho\": %.17g, \"sum_mx\": %.17g, \"sum_E\": %.17g}\n", sim_t, fluid, sr, sm, sE);
-  if (argc > 2) { /* whole fields: W, H, steps, t, then rho / mx / my / E planes (fp64) and the mask */
-    FILE *f = fopen(argv[2], "wb");
-    int hdr[3] = {W, H, steps};
-    fwrite(hdr, sizeof hdr, 1, f); fwrite(&sim_t, sizeof sim_t, 1, f);
-    for (int k = 0; k < 4; k++) for (int i = 0; i < W * H; i++) { double v = k == 0 ? U[i].rho : k == 1 ? U[i].mx : k == 2 ? U[i].my : U[i].E; fwrite(&v, 8, 1, f); }
-    fwrite(mask, 1, W * H, f);
-    fclose(f);
-  }
-  return 0;
-}
-C
-build() { # name, file, extra flags
-  gcc -O3 $3 -I"$T/stub" -DREF_FILE="\"$2\"" "$T/harness.c" -lm -o "$T/$1" 2> "$T/$1.log" || { cat "$T/$1.log"; exit 1; }
-}
-build cpu300 "$REF/tau_hypersonic.c" ""
-sed 's/^#define W 300/#define W 256/; s/^#define H 300/#define H 256/' "$REF/tau_hypersonic.c" > "$T/ref256.c"
-build cpu256 "$T/ref256.c" ""
-build simd300 "$REF/tau_hypersonic_simd.c" "-mavx2 -mfma"
-{ echo "{"; echo "\"cpu300_1\": $("$T/cpu300" 1),"; echo "\"cpu300_24\": $("$T/cpu300" 24),"; echo "\"cpu256_8\": $("$T/cpu256" 8),"; echo "\"simd300_10\": $("$T/simd300" 10)"; echo "}"; } > "$T/out.json"
-# field fixtures (data: the reference's own outputs; SURVEY §8c fixture (ii) for config C1): 96 x 64 after 12 and 13 steps
-sed 's/^#define W 300/#define W 96/; s/^#define H 300/#define H 64/' "$REF/tau_hypersonic.c" > "$T/ref96.c"
-build cpu96 "$T/ref96.c" ""
-"$T/cpu96" 12 "$T/f12.bin" > /dev/null; "$T/cpu96" 13 "$T/f13.bin" > /dev/null
-python3 - "$T/f12.bin" "$T/f13.bin" "$ROOT/tests/golden/cpu2d_ref_96x64_steps12_13.npz" <<'PY'
-import sys, numpy as np
-def rd(p):
-    b = open(p, "rb").read()
-    W, H, steps = np.frombuffer(b[:12], np.int32)
-    t = np.frombuffer(b[12:20], np.float64)[0]
-    f = np.frombuffer(b[20:20 + 32 * W * H], np.float64).reshape(4, H, W)
-    m = np.frombuffer(b[20 + 32 * W * H:], np.uint8).reshape(H, W)
-    return int(W), int(H), int(steps), t, f, m
-W, H, s0, t0, f0, m0 = rd(sys.argv[1]); _, _, s1, t1, f1, m1 = rd(sys.argv[2])
-new = dict(W=W, H=H, steps0=s0, steps1=s1, t0=t0, t1=t1, U0=f0, U1=f1, mask=m0)
-try:
-    old = np.load(sys.argv[3])
-    same = all(np.array_equal(old[k], np.asarray(v)) for k, v in new.items())
-    print(("ok   " if same else "DIFF ") + "96x64 field fixture (steps 12 -> 13) against the committed tests/golden file")
-except FileNotFoundError:
-    np.savez_compressed(sys.argv[3], **new); print("wrote", sys.argv[3])
-PY
-python3 - "$T/out.json" "$ROOT/tests/golden/ref_checkvalues.json" <<'PY'
-import json, sys
-new, gold = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+[ -d "${TAU_REFERENCE:-/root/reference}" ] || { echo "regen_checkvalues: no reference tree (build container only)"; exit 2; }
+sh "$ROOT/oracle/build_ref.sh"
+cd "$ROOT"
+python3 - <<'PY'
+import json, os, sys
+import numpy as np
+sys.path.insert(0, ".")
+from oracle import refcpu
+
+def sums(r):                      # the survey's harness: left-to-right sums over fluid cells
+    u, m = r.state()
+    fl = m.ravel() == 0
+    acc = lambda a: float(np.add.accumulate(a.ravel()[fl])[-1])
+    return dict(t=r.t, fluid=int(fl.sum()), sum_rho=acc(u[..., 0]), sum_mx=acc(u[..., 1]), sum_E=acc(u[..., 3]))
+
+def run(W, H, n, simd=False):
+    r = refcpu.RefHypCpu(W, H, simd=simd)
+    r.step(n)
+    return sums(r)
+
+gold = json.load(open("tests/golden/ref_checkvalues.json"))
 g3, g2 = gold["tau_hypersonic_cpu_300sq"], gold["tau_hypersonic_cpu_256sq_8steps"]
-checks = [("300^2 t after 1 step", new["cpu300_1"]["t"], g3["t_1step"]), ("300^2 t after 24", new["cpu300_24"]["t"], g3["t_24steps"]),
-          ("300^2 fluid", new["cpu300_24"]["fluid"], g3["fluid"]), ("300^2 sum rho", new["cpu300_24"]["sum_rho"], g3["sum_rho_24"]),
-          ("300^2 sum mx", new["cpu300_24"]["sum_mx"], g3["sum_mx_24"]), ("300^2 sum E", new["cpu300_24"]["sum_E"], g3["sum_E_24"]),
-          ("256^2 t after 8", new["cpu256_8"]["t"], g2["t"]), ("256^2 fluid", new["cpu256_8"]["fluid"], g2["fluid"]),
-          ("256^2 sum rho", new["cpu256_8"]["sum_rho"], g2["sum_rho"]),
-          ("SIMD file 300^2 sum rho after 10 (tests/test_drivers.py)", new["simd300_10"]["sum_rho"], 82947.469425548319)]
+a1, a24, b8, s10 = run(300, 300, 1), run(300, 300, 24), run(256, 256, 8), run(300, 300, 10, simd=True)
+checks = [("300^2 t after 1 step", a1["t"], g3["t_1step"]), ("300^2 t after 24", a24["t"], g3["t_24steps"]),
+          ("300^2 fluid", a24["fluid"], g3["fluid"]), ("300^2 sum rho", a24["sum_rho"], g3["sum_rho_24"]),
+          ("300^2 sum mx", a24["sum_mx"], g3["sum_mx_24"]), ("300^2 sum E", a24["sum_E"], g3["sum_E_24"]),
+          ("256^2 t after 8", b8["t"], g2["t"]), ("256^2 fluid", b8["fluid"], g2["fluid"]), ("256^2 sum rho", b8["sum_rho"], g2["sum_rho"]),
+          ("SIMD file 300^2 sum rho after 10 (tests/test_drivers.py)", s10["sum_rho"], 82947.469425548319)]
 bad = 0
 for name, a, b in checks:
     ok = a == b
     bad += not ok
     print(("ok   " if ok else "DIFF ") + f"{name}: regenerated {a!r} committed {b!r}")
+# field fixture (SURVEY 8c fixture ii for config C1): 96 x 64 after 12 and 13 steps
+r = refcpu.RefHypCpu(96, 64)
+r.step(12)
+u0, m = r.state(); t0 = r.t
+r.step(1)
+u1, _ = r.state(); t1 = r.t
+new = dict(W=96, H=64, steps0=12, steps1=13, t0=t0, t1=t1, U0=np.moveaxis(u0, 2, 0), U1=np.moveaxis(u1, 2, 0), mask=m)
+path = "tests/golden/cpu2d_ref_96x64_steps12_13.npz"
+if os.path.exists(path):
+    old = np.load(path)
+    same = all(np.array_equal(old[k], np.asarray(v)) for k, v in new.items())
+    bad += not same
+    print(("ok   " if same else "DIFF ") + "96x64 field fixture (steps 12 -> 13) against the committed tests/golden file")
+else:
+    np.savez_compressed(path, **new); print("wrote", path)
 sys.exit(1 if bad else 0)
 PY

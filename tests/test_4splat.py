@@ -106,6 +106,43 @@ def test_palette_indices_match_the_oracle(eng, oracle_built):
     e.close()
 
 
+def test_oracle_palette_map_vs_reference_lines(oracle_built):
+    """th3cs.cu:1199-1222 itself (oracle/_ref/libref_hostmaps.so: those lines, cut and compiled with g++) against the oracle's
+    restatement: same libm powf on the same host, so the indices are identical"""
+    from oracle import refcpu
+    if not refcpu.available_hostmaps():
+        pytest.skip("oracle/_ref/libref_hostmaps.so absent (needs /root/reference to build)")
+    rng = np.random.default_rng(5)
+    o = oracle_built.Oracle3D(8, 8, 8)
+    for shape in ((3, 5, 7), (16, 12, 9)):
+        vol = (rng.random(shape, dtype=np.float32) ** 3 * 40.0).astype(np.float32)
+        want = refcpu.th3cs_palette(vol, frame=1, frames=3)
+        assert (want[0] == 0).all() and (want[2] == 0).all()          # written at offset f * N only (:1207)
+        got, mn, mx = o.palette_indices(vol, 0.65)
+        assert np.array_equal(got.astype(np.uint64), want[1])
+    flat = refcpu.th3cs_palette(np.full((2, 3, 4), 7.0, np.float32))
+    assert (flat == 0).all()
+
+
+@pytest.mark.gpu
+def test_palette_indices_vs_reference_lines(eng):
+    """tau3d_palette_indices against th3cs.cu:1199-1222 itself on the engine's schlieren volume: an integer output of a float
+    map — identical except where powf(norm) * 255 sits on an integer (device powf vs libm)"""
+    from oracle import refcpu
+    if not refcpu.available_hostmaps():
+        pytest.skip("oracle/_ref/libref_hostmaps.so absent — the palette map is NOT checked against the reference")
+    e = eng.Tau3D(40, 32, 24)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(20)
+    sch = e.vis(0)
+    got, mn, mx = e.palette_indices(0.65)
+    want = refcpu.th3cs_palette(sch)[0]
+    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3, (int(d.max()), float((d != 0).mean()))
+    e.close()
+
+
 @pytest.mark.gpu
 def test_th3cs_end_to_end(eng, oracle_built, tmp_path):
     if not os.path.exists(os.path.join(BIN, "th3cs")):

@@ -1,8 +1,10 @@
 """GPU: the 3D hypersonic step against THE REFERENCE'S OWN KERNELS running on the same MI355X.
 
-oracle/_ref/th3cs.co is the device code of the reference's th3cs.cu (k_build_solid_mask, k_init, k_step — the reference author's
-headless twin of tau_hypersonic_3d_cuda.cu:759-770, 939-985, 987-1359), compiled for gfx950 by oracle/build_ref.sh from the
-source where it lies in /root/reference.  These tests pin, on identical inputs:
+oracle/_ref/tau_hypersonic_3d_cuda.co is the device code of the file north_star names — tau_hypersonic_3d_cuda.cu lines 1-1409
+minus the raylib includes (4-5) and the Vector3 helpers (69-101), SURVEY 8c's line cut: k_build_solid_mask :759-770, k_init
+:939-985, k_step :987-1359 — and oracle/_ref/th3cs.co that of the reference author's headless twin th3cs.cu; both compiled for
+gfx950 by oracle/build_ref.sh from the sources where they lie in /root/reference.  refgpu.Ref3D() uses the named file unless
+told otherwise (source="th3cs").  These tests pin, on identical inputs:
   * the CPU oracle (oracle/tau3d_oracle.c) against the reference kernels   -> the oracle is no longer "parity unpinned";
   * the engine (through the C-ABI) against the reference kernels           -> north_star's sentence, literally.
 Tolerances are those of tests/parity.py (1e-5 relative on the conserved fields).
@@ -22,8 +24,8 @@ GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_che
 @pytest.fixture(scope="module")
 def refgpu():
     from oracle import refgpu as r
-    if not r.available("th3cs"):   # built by __graft_entry__.build() where /root/reference exists; travels with the snapshot
-        pytest.skip("oracle/_ref/th3cs.co absent: oracle/build_ref.sh has not run (needs /root/reference) — the reference-kernel pins are NOT checked")
+    if not (r.available("th3cs") and r.available("tau_hypersonic_3d_cuda")):   # built by __graft_entry__.build() where /root/reference exists; travels with the snapshot
+        pytest.skip("oracle/_ref/{tau_hypersonic_3d_cuda,th3cs}.co absent: oracle/build_ref.sh has not run (needs /root/reference) — the reference-kernel pins are NOT checked")
     return r
 
 
@@ -218,7 +220,7 @@ def test_schlieren_field_vs_reference_kernel(eng, refgpu, shape, warm):
     e.set_clock(0.02, 1e-4)
     e.step(warm)
     state = e.download()
-    r = refgpu.Ref3D(nx, ny, nz)
+    r = refgpu.Ref3D(nx, ny, nz, source="th3cs")
     r.upload(state)
     want = r.schlieren().astype(np.float64)
     got = e.vis(0).astype(np.float64)
@@ -231,3 +233,33 @@ def test_schlieren_field_vs_reference_kernel(eng, refgpu, shape, warm):
     assert err <= 2e-6 and want.max() > 0
     e.close()
     r.close()
+
+
+
+@pytest.mark.parametrize("shape,warm", [((32, 32, 32), 30), ((61, 61, 50), 25), ((96, 64, 32), 40)])
+def test_named_file_and_its_twin_step_alike(eng, refgpu, shape, warm):
+    """k_step of tau_hypersonic_3d_cuda.cu (:987-1359) and of th3cs.cu (:716-1058) on the same developed state: the twin differs
+    only in dead Tv solves and merged declarations, so the two code objects must produce the same six arrays and the same max
+    wavespeed — which is why referees that exist only in th3cs (k_schlieren_export) still speak for the named file."""
+    nx, ny, nz = shape
+    e = eng.Tau3D(nx, ny, nz)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(warm)
+    state = e.download()
+    e.close()
+    out = {}
+    for ieee in (False, True):
+        for src in ("3d_cuda", "th3cs"):
+            r = refgpu.Ref3D(nx, ny, nz, source=src, ieee=ieee)
+            assert r.source == src
+            r.upload(state)
+            m = r.step(2.0e-6, 1.0)
+            out[src, ieee] = (m, r.download(), r.solid_mask())
+            r.close()
+        a, b = out["3d_cuda", ieee], out["th3cs", ieee]
+        assert np.array_equal(a[2], b[2])
+        same = a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1], b[1]))
+        worst = max(float(np.abs(x.astype(np.float64) - y).max()) for x, y in zip(a[1], b[1]))
+        print(shape, "ieee" if ieee else "default", "builds of the two files:", "bit-identical" if same else f"max |diff| {worst:.2e}")
+        assert same, worst

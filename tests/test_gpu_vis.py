@@ -88,6 +88,100 @@ def test_vis_on_slab_equals_single_domain(eng):
     e.close(); s.close()
 
 
+# ------------------------------------------------------------------ the reference's own k_vis / k_outflow_reflection_metric /
+# k_maxwavespeed_pre / k_schlieren (tau_hypersonic_3d_cuda.cu, oracle/_ref line-cut build) and its host slice_to_rgba as referees
+@pytest.fixture(scope="module")
+def ref3d():
+    from oracle import refgpu as r
+    if not r.available("tau_hypersonic_3d_cuda"):
+        pytest.skip("oracle/_ref/tau_hypersonic_3d_cuda.co absent (oracle/build_ref.sh needs /root/reference) — the k_vis referees are NOT checked")
+    return r
+
+
+@pytest.mark.parametrize("shape,warm", [((32, 32, 32), 30), ((48, 40, 24), 25), ((64, 64, 64), 40), ((96, 80, 40), 40)])
+def test_vis_fields_vs_reference_k_vis(eng, oracle_built, ref3d, shape, warm):
+    """tau3d_vis modes 0-7 against k_vis (tau_hypersonic_3d_cuda.cu:800-905) launched on the engine's developed state; the
+    tolerance is the one of the oracle test above — relative to the operands of the differences a gradient mode takes —
+    and the oracle's restatement of k_vis is held to the same kernel in the same breath."""
+    e, o, st = developed(eng, oracle_built, shape, warm)
+    nx, ny, nz = shape
+    r = ref3d.Ref3D(nx, ny, nz, source="3d_cuda")
+    r.upload(e.download())
+    fluid = r.solid_mask() == 0
+    for mode in range(8):
+        want = r.vis(mode).astype(np.float64)
+        got = e.vis(mode).astype(np.float64)
+        orc, scale = o.vis(st, mode)
+        sc = np.maximum(scale[fluid].astype(np.float64), 1e-30)
+        assert (want[~fluid] == 0).all() and (got[~fluid] == 0).all()
+        err = (np.abs(got - want)[fluid] / sc).max()
+        err_o = (np.abs(orc - want)[fluid] / sc).max()
+        print("k_vis mode", mode, e.VIS_MODES[mode], "engine %.2e oracle %.2e of scale; max|field| %.3g" % (err, err_o, np.abs(want).max()))
+        assert err <= 1e-5 and err_o <= 1e-5, (mode, err, err_o)
+    # k_schlieren (:1361-1387): |grad rho| from xi alone — mode 0 in fluid cells away from the body and the x boundaries
+    want = r.schlieren_xi().astype(np.float64)
+    got = e.vis(0).astype(np.float64)
+    solid = ~fluid
+    near = solid.copy()
+    for ax in range(3):
+        near |= np.roll(solid, 1, ax) | np.roll(solid, -1, ax)
+    far = ~near
+    far[:, :, 0] = far[:, :, -1] = False
+    rho = np.exp(e.download()[0].astype(np.float64))
+    scale = rho.max() / (2.0 / max(shape))
+    assert (np.abs(got - want)[far] / scale).max() <= 1e-5
+    r.close()
+    e.close()
+
+
+@pytest.mark.parametrize("shape,warm", [((32, 32, 32), 30), ((48, 40, 24), 25), ((64, 64, 64), 40)])
+def test_outflow_metric_and_wavespeed_vs_reference_kernels(eng, ref3d, shape, warm):
+    """tau3d_outflow_reflection against k_outflow_reflection_metric (:1389-1408), and the max wavespeed the engine's step
+    returns against k_maxwavespeed_pre (:909-937) evaluated on the state that step produced... the step's own max is over its
+    INPUT state (k_step :1338-1356 reduces the cell it just read), so: pre(state) == maxs of the step taken from that state."""
+    nx, ny, nz = shape
+    e = eng.Tau3D(nx, ny, nz)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(warm)
+    r = ref3d.Ref3D(nx, ny, nz, source="3d_cuda")
+    r.upload(e.download())
+    for nprobe in (0, 1, 6, 40):
+        assert e.outflow_reflection(nprobe) == pytest.approx(r.outflow_reflection(nprobe), rel=1e-5, abs=1e-9), nprobe
+    pre = r.maxwavespeed_pre()
+    m_ref = r.step(2.0e-6, 1.0)
+    m_eng = e.step_explicit(2.0e-6, 1.0)
+    print(shape, "k_maxwavespeed_pre", pre, "k_step maxs", m_ref, "engine", m_eng)
+    assert m_eng == pytest.approx(m_ref, rel=1e-5)
+    r.close()
+    e.close()
+
+
+@pytest.mark.parametrize("log_scale,a_gain", [(False, 1.0), (True, 0.55), (True, 2.0), (False, 3.0)])
+def test_slice_rgba_vs_reference_host_code(eng, log_scale, a_gain):
+    """tau3d_slice_rgba against slice_to_rgba itself (tau_hypersonic_3d_cuda.cu:1416-1442, g++ build of the line cut in
+    oracle/_ref/libref_hostmaps.so) fed the engine's own field: linear ramp byte-exact; with the log ramp device logf and libm
+    logf may differ in the last place: +-1 per channel, and only in a sliver of the pixels."""
+    from oracle import refcpu
+    if not refcpu.available_hostmaps():
+        pytest.skip("oracle/_ref/libref_hostmaps.so absent — slice_to_rgba is NOT checked against the reference")
+    e = eng.Tau3D(48, 40, 24)
+    e.init(1)
+    e.set_clock(0.02, 1e-4)
+    e.step(25)
+    for mode in (0, 4):
+        vol = e.vis(mode)
+        for z in (-3, 0, 11, 23, 99):
+            got, mn, mx = e.slice_rgba(z, log_scale, a_gain)
+            want = refcpu.slice_to_rgba(vol, z, log_scale, a_gain)
+            if not log_scale:
+                assert np.array_equal(got, want), (mode, z)
+            else:
+                d = np.abs(got.astype(np.int16) - want.astype(np.int16))
+                assert d.max() <= 1 and (d != 0).mean() < 2e-2, (mode, z, int(d.max()), float((d != 0).mean()))
+    e.close()
+
+
 # ------------------------------------------------------------------ 2D solver: the seven view modes + colour ramp
 @pytest.mark.parametrize("W,H,warm", [(512, 256, 60), (257, 96, 40), (100, 60, 25)])
 def test_render_2d_matches_oracle(eng, oracle_built, W, H, warm):

@@ -8,6 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 WANT = {
+    # the file north_star names, from SURVEY 8c's line cut (1-1409 minus raylib includes and Vector3 helpers)
+    "tau_hypersonic_3d_cuda": ["k_build_solid_mask(", "k_init(", "k_step(", "k_vis(", "k_maxwavespeed_pre(", "k_schlieren(",
+                               "k_outflow_reflection_metric(", "P"],
+    "tau_hypersonic_3d_cuda.ieee": ["k_build_solid_mask(", "k_step("],
     "th3cs": ["k_build_solid_mask(", "k_init(", "k_step(", "P"],
     "th3cs.ieee": ["k_build_solid_mask(", "k_step("],
     "tau_hypersonic_cuda_tests": ["k_init(", "k_apply_inflow_left(", "k_max_wavespeed_blocks(", "k_reduce_block_max(", "k_predict_face_states(",
@@ -30,6 +34,9 @@ def test_reference_objects_hold_the_kernels_the_gpu_tests_launch():
         syms = [l.rstrip("\n").split("\t")[1] for l in open(os.path.join(REF, name + ".syms"))]
         for k in kernels:
             assert any(s == k or s.startswith(k) for s in syms), (name, k)
+    for lib in ("libref_hostmaps.so", "libref_hyp_cpu_300x300.so", "libref_hyp_cpu_256x256.so", "libref_hyp_cpu_96x64.so",
+                "libref_hyp_cpu_simd_300x300.so", "libref_hyp_cpu_simd_256x256.so", "libref_hyp_cpu_simd_96x64.so"):
+        assert lib in manifest and open(os.path.join(REF, lib), "rb").read(4) == b"\x7fELF"
     for prog in ("tgs", "tau_sph", "tau_lbm", "tau_burgers", "tau_sw", "tau_hypersonic_cuda_tests"):
         p = os.path.join(REF, "bin", prog)
         assert os.path.exists(p) and os.access(p, os.X_OK)
@@ -43,3 +50,15 @@ def test_the_recipe_writes_nothing_for_the_reference():
     assert lines
     for l in lines:
         assert " -I" not in l and "-include" not in l and "$HERE" not in l.replace('"$OUT', "").replace("$OUT", "")
+
+
+def test_the_line_cuts_are_cuts_not_rewrites():
+    """the files that include raylib.h are built from `sed -n 'A,Bp'` ranges of the reference's own text with lines DELETED
+    (`sed '/raylib.h/d'`, `-e '4,5d' -e '69,101d'`) — the only substitution anywhere is the survey's W/H #define patch — and the
+    harnesses #include the cut rather than paste anything in its place"""
+    sh = open(os.path.join(ROOT, "oracle", "build_ref.sh")).read()
+    assert "sed -n '1,674p' \"$REF/tau_hypersonic.c\"" in sh and "sed -n '1,804p' \"$REF/tau_hypersonic_simd.c\"" in sh
+    assert "sed -n '1,1409p' \"$REF/tau_hypersonic_3d_cuda.cu\" | sed -e '4,5d' -e '69,101d'" in sh
+    subs = [l for l in sh.splitlines() if "sed" in l and "s/" in l and not l.lstrip().startswith("#")]
+    assert len(subs) == 1 and "#define W 300" in subs[0] and "#define H 300" in subs[0], subs
+    assert "typedef struct" not in sh and "InitWindow" not in sh      # no stand-in declarations
