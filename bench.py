@@ -312,6 +312,10 @@ def main():
                          "rank is skipped).  host / ipc-host: halos (resp. only the all-reduce) staged through shared memory so that "
                          "the ranks may SHARE a device — this script's N > 1 path on a one-GPU box (process group over gloo); not a "
                          "performance configuration")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N > 1 (or --force-slab): skip the check that follows the timed region — every rank recomputes warmup + steps "
+                         "single-domain steps of the whole grid from the same start on its own device and compares its slab with "
+                         "those planes byte for byte (ring.matches_single_domain; a mismatch exits 4)")
     ap.add_argument("--ring-driver", choices=("c", "python"), default="c",
                     help="c: the library's ring (tau3d_ring_*, librccl called from C); python: fluid-sims_amd/slab.py over torch.distributed")
     args = ap.parse_args()
@@ -378,6 +382,7 @@ def main():
 
     ring_info = None
     closer = None
+    ring_obj = None
     if not use_ring:
         eng = f.Tau3D(n, n, n, params=params, device=local)
         eng.init(1)
@@ -398,7 +403,7 @@ def main():
             info = {"driver": "python (torch.distributed batch_isend_irecv + all_reduce)"}
             if why:
                 info["fallback_from_c_ring"] = why
-            return (lambda k: ring.step(k)), ring.finish, be.h.clock, be.h, info, None
+            return (lambda k: ring.step(k)), ring.finish, be.h.clock, be.h, info, None, None
 
         TRANSPORT_NAMES = {f.RING_RCCL: "rccl", f.RING_LOCAL: "local device copies", f.RING_IPC: "ipc",
                            f.RING_HOST: "host-staged (ranks share a device: not a performance configuration)",
@@ -442,26 +447,61 @@ def main():
             def close_all():
                 ring.close()
                 eng.close()
-            return ((lambda k: ring.step(k)), ring.finish, ring.clock, eng, info, close_all), None
+            return ((lambda k: ring.step(k)), ring.finish, ring.clock, eng, info, close_all, ring), None
 
         def probe(transport, steps=10):
             """ms per step of one candidate over `steps` steps after the same warm-up, max over ranks (untimed region of the bench)"""
             got, why = c_ring(transport)
             if got is None:
                 return None, why
-            st, sy, _, _, _, cl = got
-            st(args.warmup)
-            sy()
-            barrier()
+            st, sy, _, _, _, cl, _ = got
+            # a candidate that builds but then fails while stepping (a HIP / RCCL error out of the library) must not take the run
+            # down: every rank says how it went, the candidate counts only if ALL of them got through, and it is closed either way
+            # Every rank walks the SAME sequence of process-group collectives whatever happens in between.
+            ms, err = float("inf"), None
+
+            def attempt(fn):
+                nonlocal err
+                if err is None:
+                    try:
+                        fn()
+                    except Exception as e:
+                        err = f"rank {rank}: {e}"
+
+            def warm():
+                if os.environ.get("TAU_BENCH_FAIL_PROBE") == str(transport) and rank == world - 1:
+                    raise RuntimeError("TAU_BENCH_FAIL_PROBE is set (test: a candidate that fails while stepping)")
+                st(args.warmup)
+                sy()
+            def always(fn):      # a collective: issued even by a rank that already failed, so that the others are not left waiting
+                nonlocal err
+                try:
+                    fn()
+                except Exception as e:
+                    err = err or f"rank {rank}: {e}"
+
+            attempt(warm)
+            always(barrier)
             t0 = time.perf_counter()
-            st(steps)
-            sy()
-            barrier()
-            t = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device="cpu" if shared else dev)
-            if world > 1:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            cl()
-            return float(t.item()), None
+            attempt(lambda: (st(steps), sy()))
+            if err is None:
+                ms = (time.perf_counter() - t0) / steps * 1e3
+            always(barrier)
+            try:
+                t = torch.tensor([ms if err is None else float("inf")], dtype=torch.float64, device="cpu" if shared else dev)
+                if world > 1:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                ms = float(t.item())
+            except Exception as e:
+                err = err or f"rank {rank}: {e}"
+                ms = float("inf")
+            try:
+                cl()
+            except Exception as e:
+                err = err or f"rank {rank}: close: {e}"
+            if not math.isfinite(ms):
+                return None, err or "another rank failed while stepping this transport"
+            return ms, None
 
         want = args.ring_transport
         if world == 1:
@@ -484,17 +524,22 @@ def main():
             if why and rank == 0:
                 print(f"bench.py: C ring unavailable ({why}); falling back to the torch.distributed ring", file=sys.stderr)
             got = python_ring(why)
-        step, sync, get_clock, h, ring_info, closer = got
+        step, sync, get_clock, h, ring_info, closer, ring_obj = got
 
     step(args.warmup)
     sync()
     h.timing_enable(True)
+    if ring_obj is not None:
+        ring_obj.timing_enable(True)
     barrier()
     t0 = time.perf_counter()
     step(args.steps)
     sync()
     barrier()
     el = time.perf_counter() - t0
+    ring_times = ring_obj.timing_read() if ring_obj is not None else None
+    if ring_obj is not None:
+        ring_obj.timing_enable(False)
     k_ms, k_launches, k_cells = h.timing_read()
     span_ms = h.timing_span()          # HIP events on the launch stream: first launch of the timed region -> end of the last
     xy_ms, z_ms, n_split = h.timing_read_split()
@@ -517,9 +562,66 @@ def main():
 
     clk = get_clock()
     frange = h.field_range()
+
+    # ---- the ring run proves itself: slab == single domain, byte for byte (SURVEY 8e's parity oracle, on the hardware and with
+    # the transport that was just timed).  The grid fits one GPU, so EVERY rank recomputes warmup + steps single-domain steps from
+    # the same start on its own device and compares its own planes locally — no data crosses the ring it is checking.
+    verify = None
+    per_rank = None
+    if use_ring:
+        cdev = "cpu" if shared else dev
+        if not args.no_verify:
+            t0v = time.perf_counter()
+            ok, first_bad, nbad, clock_ok, verr = 1, 2 ** 31 - 1, 0, 1, None
+            try:
+                mine = h.download()
+                one = f.Tau3D(n, n, n, params=params, device=local)
+                one.init(1)
+                one.set_clock(0.02, 1e-4)
+                one.step_async(args.warmup + args.steps)
+                one.sync()
+                c1 = one.clock()
+                want = one.download_planes(z0, z0 + nzl)
+                one.close()
+                if os.environ.get("TAU_BENCH_VERIFY_SELFTEST") and rank == world - 1:   # test of the check itself: one bit of one word
+                    mine[3].view(np.uint32)[nzl // 2, 5, 7] ^= 1
+                bad_planes = np.zeros(nzl, bool)
+                for a, b in zip(mine, want):       # bit patterns, so that -0.0 / NaN payloads count too
+                    bad_planes |= (a.view(np.uint32) != b.view(np.uint32)).reshape(nzl, -1).any(axis=1)
+                nbad = int(bad_planes.sum())
+                if nbad:
+                    ok, first_bad = 0, z0 + int(np.argmax(bad_planes))
+                clock_ok = int((c1.t, c1.d_tau, c1.maxs) == (clk.t, clk.d_tau, clk.maxs))
+                if not clock_ok:
+                    ok = 0
+            except Exception as e:
+                ok, verr = 0, f"rank {rank}: {e}"
+            v = torch.tensor([ok, clock_ok, -first_bad, -nbad], dtype=torch.int64, device=cdev)
+            tot = torch.tensor([nbad], dtype=torch.int64, device=cdev)
+            if world > 1:
+                dist.all_reduce(v, op=dist.ReduceOp.MIN)
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            v = [int(x) for x in v.tolist()]
+            verify = {"matches_single_domain": bool(v[0]), "clock_matches": bool(v[1]),
+                      "first_differing_plane": (-v[2] if -v[2] < 2 ** 31 - 1 else None), "differing_planes": int(tot.item()),
+                      "compared": f"{n}^3 x 6 fields, every rank's planes against its own single-domain recompute of "
+                                  f"{args.warmup + args.steps} steps, bit patterns", "seconds": round(time.perf_counter() - t0v, 2)}
+            if verr:
+                verify["error"] = verr
+        # per-rank event times of the timed steps: x/y kernel, z kernel (handle's stream), exchange, all-reduce (ring's stream)
+        rt = ring_times or (0.0, 0.0, 0)
+        row = torch.zeros(world, 4, dtype=torch.float64, device=cdev)
+        row[rank] = torch.tensor([xy_ms / max(n_split, 1), z_ms / max(n_split, 1), rt[0] / max(rt[2], 1), rt[1] / max(rt[2], 1)],
+                                 dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(row, op=dist.ReduceOp.SUM)
+        per_rank = [{"rank": i, "xy_ms": round(r[0], 4), "z_ms": round(r[1], 4), "exchange_ms": round(r[2], 4),
+                     "allreduce_ms": round(r[3], 4)} for i, r in enumerate(row.tolist())]
     cells_total = float(n) ** 3 * args.steps
     value = cells_total / el / 1e9
-    state_sane = bool(frange[2]) and math.isfinite(float(clk.maxs)) and float(clk.maxs) > 0.0 and float(max(frange[0], frange[1])) <= 6e4
+    # sane = finite, positive wavespeed and every |primitive| bounded — whichever WENO weight form the steps ran (the reciprocal
+    # form is a legitimate run: TAU3D_WENO_RCP=1, or a state between the fast window's 2.5e3 and 6e4)
+    state_sane = math.isfinite(float(clk.maxs)) and float(clk.maxs) > 0.0 and float(max(frange[0], frange[1])) <= 6e4
 
     if rank == 0:
         # The step is two kernels over the same planes (k_flux_xy, then k_update_z): the events bracket the pair, so
@@ -588,6 +690,14 @@ def main():
             out["roofline_valu"] = out_valu
         if ring_info:
             out["ring"] = ring_info
+            if verify is not None:
+                out["ring"].update(verify)
+            else:
+                out["ring"]["matches_single_domain"] = None     # --no-verify
+            if per_rank:
+                out["ring"]["per_rank_event_ms_per_step"] = per_rank
+                out["ring"]["per_rank_event_note"] = ("xy / z: kernels on the slab handle's stream; exchange / allreduce: the ring's "
+                                                      "communication stream (the all-reduce waits for the slowest rank's exchange)")
         if world == 1 and not args.no_variants and not use_ring:
             try:
                 out["other_inputs"] = input_variants(f, torch, dev, n)
@@ -632,16 +742,26 @@ def main():
             pass
         print(json.dumps(out), flush=True)
 
+    rc = 0
     if not state_sane:   # every rank sees the same all-reduced clock block
         if rank == 0:
             print(f"bench.py: the timed window [{args.warmup}, {args.warmup + args.steps}) crossed into the runaway of the impulsive "
                   f"start (fast form {bool(frange[2])}, maxs {clk.maxs}, max |primitive| {max(frange[0], frange[1])}): not a valid "
                   f"measurement — use fewer steps / less warm-up", file=sys.stderr)
-        sys.exit(3)
-    if use_ring and closer is not None:
-        closer()
-    if need_pg:
-        dist.destroy_process_group()
+        rc = 3
+    if verify is not None and not verify["matches_single_domain"]:
+        if rank == 0:
+            print(f"bench.py: the Z-slab run does NOT reproduce the single-domain run ({verify}): the number above is not a valid "
+                  f"measurement", file=sys.stderr)
+        rc = 4
+    try:                 # tear down on every path: a non-zero exit still closes the ring and the process group
+        if use_ring and closer is not None:
+            closer()
+        if need_pg:
+            dist.destroy_process_group()
+    finally:
+        if rc:
+            sys.exit(rc)
 
 
 if __name__ == "__main__":

@@ -241,6 +241,12 @@ struct tau3d_ring : tau_rendezvous {
   void *opened[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};    // what hipIpcCloseMemHandle gets back
   size_t peer_stride[2] = {0, 0};
   int peer_nzl[2] = {0, 0}, peer_cur[2] = {0, 0};
+  // tau3d_ring_timing_*: HIP events on X around the exchange and around the all-reduce of every step (ring_step_spec), read
+  // back by tau3d_ring_timing_read once the streams are idle — what one rank's communication stream spent where
+  static constexpr int TIMED_STEPS = 256;
+  bool timing = false;
+  int timed = 0;
+  hipEvent_t tev[TIMED_STEPS][3] = {};
   bool uses_rccl() const { return transport == TAU3D_RING_RCCL || transport == TAU3D_RING_IPC; }
   bool direct() const { return transport == TAU3D_RING_IPC || transport == TAU3D_RING_IPC_HOSTMAX; }
 };
@@ -383,6 +389,9 @@ extern "C" void tau3d_ring_destroy(tau3d_ring_t *r) {
   if (r->evI) hipEventDestroy(r->evI);
   if (r->evX) hipEventDestroy(r->evX);
   if (r->evH) hipEventDestroy(r->evH);
+  for (auto &st : r->tev)
+    for (hipEvent_t e : st)
+      if (e) hipEventDestroy(e);
   if (r->syncw) hipFree(r->syncw);
   if (r->evJ) hipEventDestroy(r->evJ);
   if (r->evC2) hipEventDestroy(r->evC2);
@@ -859,13 +868,22 @@ static int ring_step_spec(tau3d_ring *r) {
   if (tau3d_slab_z_async(r->h)) return 1;
   TAU_HIP(hipEventRecord(r->evI, r->S));
   TAU_HIP(hipStreamWaitEvent(r->X, r->evI, 0));
-  switch (r->transport) {
-    case TAU3D_RING_RCCL: if (exchange_rccl(r) || ring_allreduce(r, r->X)) return 1; break;
-    case TAU3D_RING_IPC: if (exchange_ipc(r, 1) || ring_allreduce(r, r->X)) return 1; break;
-    case TAU3D_RING_HOST: if (exchange_host(r) || allreduce_host(r)) return 1; break;
-    case TAU3D_RING_IPC_HOSTMAX: if (exchange_ipc(r, 1) || allreduce_host(r)) return 1; break;   // (its first barrier follows a sync of X: copies landed)
-    default: if (exchange_local(r) || ring_inject(r, r->X)) return 1; break;
+  const bool timed = r->timing && r->timed < tau3d_ring::TIMED_STEPS;
+  hipEvent_t *te = timed ? r->tev[r->timed] : nullptr;
+  if (timed) {
+    for (int k = 0; k < 3; k++)
+      if (!te[k]) TAU_HIP(hipEventCreate(&te[k]));
+    TAU_HIP(hipEventRecord(te[0], r->X));
   }
+  auto mid = [&]() -> int { return timed ? (int)(hipEventRecord(te[1], r->X) != hipSuccess) : 0; };
+  switch (r->transport) {
+    case TAU3D_RING_RCCL: if (exchange_rccl(r) || mid() || ring_allreduce(r, r->X)) return 1; break;
+    case TAU3D_RING_IPC: if (exchange_ipc(r, 1) || mid() || ring_allreduce(r, r->X)) return 1; break;
+    case TAU3D_RING_HOST: if (exchange_host(r) || mid() || allreduce_host(r)) return 1; break;
+    case TAU3D_RING_IPC_HOSTMAX: if (exchange_ipc(r, 1) || mid() || allreduce_host(r)) return 1; break;   // (its first barrier follows a sync of X: copies landed)
+    default: if (exchange_local(r) || mid() || ring_inject(r, r->X)) return 1; break;
+  }
+  if (timed) { TAU_HIP(hipEventRecord(te[2], r->X)); r->timed++; }
   TAU_HIP(hipEventRecord(r->evX, r->X));
   if (tau3d_slab_end_async(r->h)) return 1;
   r->peer_cur[0] ^= 1; r->peer_cur[1] ^= 1;
@@ -908,6 +926,30 @@ extern "C" int tau3d_ring_finish(tau3d_ring_t *r) {
   TAU_HIP(hipSetDevice(r->device));
   TAU_HIP(hipStreamSynchronize(r->X));
   TAU_HIP(hipStreamSynchronize(r->S));
+  return 0;
+}
+
+/* Per-step event timing of the communication stream (default schedule, ring_step_spec): enable, step, tau3d_ring_finish, read.
+ * exchange_ms: halo copies / send-recv of this rank; allreduce_ms: the max all-reduce behind them — which also waits for the
+ * slowest rank's exchange, so it carries the skew between ranks.  Sums over `steps` timed steps (at most 256 per enable). */
+extern "C" int tau3d_ring_timing_enable(tau3d_ring_t *r, int on) {
+  if (!r) return tau::fail("tau3d_ring_timing_enable: null ring");
+  r->timing = on != 0;
+  r->timed = 0;
+  return 0;
+}
+extern "C" int tau3d_ring_timing_read(tau3d_ring_t *r, double *exchange_ms, double *allreduce_ms, int *steps) {
+  if (!r || !exchange_ms || !allreduce_ms || !steps) return tau::fail("tau3d_ring_timing_read: null argument");
+  TAU_HIP(hipSetDevice(r->device));
+  TAU_HIP(hipStreamSynchronize(r->X));
+  double ex = 0.0, ar = 0.0;
+  for (int s = 0; s < r->timed; s++) {
+    float a = 0.f, b = 0.f;
+    TAU_HIP(hipEventElapsedTime(&a, r->tev[s][0], r->tev[s][1]));
+    TAU_HIP(hipEventElapsedTime(&b, r->tev[s][1], r->tev[s][2]));
+    ex += a; ar += b;
+  }
+  *exchange_ms = ex; *allreduce_ms = ar; *steps = r->timed;
   return 0;
 }
 
@@ -1015,11 +1057,12 @@ static int rowring_create_impl(taurow_ring *r, int nx, int ny_local, int device,
   r->rank = rank; r->world = world; r->transport = transport; r->key = job_key;
   r->nx = nx; r->H = halo; r->nyl = ny_local - 2 * halo; r->device = device; r->S = (hipStream_t)stream;
   r->lo = (rank + world - 1) % world; r->hi = (rank + 1) % world;
-  const size_t slot = transport == TAU3D_RING_HOST ? 2 * (size_t)halo * nx * sizeof(float) : 0;
-  if (world > 1 && ring_map(r, rendezvous, job_key, slot)) return 1;
+  // arguments first: nothing is mapped, and no peer can be attached to anything, when a bad halo depth is refused
   if (halo < 1 || r->nyl < halo)
     return tau::fail("taurow_ring_create: a handle of %d rows with a %d-row halo either side owns %d rows; it needs at least the halo depth",
                      ny_local, halo, r->nyl);
+  const size_t slot = transport == TAU3D_RING_HOST ? 2 * (size_t)halo * nx * sizeof(float) : 0;
+  if (world > 1 && ring_map(r, rendezvous, job_key, slot)) return 1;
   TAU_HIP(hipSetDevice(device));
   ncclUniqueId id;
   memset(&id, 0, sizeof id);

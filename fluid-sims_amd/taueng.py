@@ -161,6 +161,8 @@ def load():
         "tau3d_ring_prime": ([vp], i32), "tau3d_ring_invalidate": ([vp], i32),
         "tau3d_ring_step_async": ([vp, i32], i32), "tau3d_ring_finish": ([vp], i32),
         "tau3d_ring_get_clock": ([vp, C.POINTER(Tau3DClock)], i32), "tau3d_ring_barrier": ([vp], i32),
+        "tau3d_ring_timing_enable": ([vp, i32], i32),
+        "tau3d_ring_timing_read": ([vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(i32)], i32),
         "tau3d_ring_info": ([vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.c_char_p, C.c_size_t], i32),
         "tau3d_vis": ([vp, i32, vp], i32),
         "tau3d_vis_async": ([vp, i32, vp], i32),
@@ -365,6 +367,15 @@ class Tau3DRing:
         c = Tau3DClock()
         _ck(self._L.tau3d_ring_get_clock(self._r, C.byref(c)))
         return c
+
+    def timing_enable(self, on=True):
+        _ck(self._L.tau3d_ring_timing_enable(self._r, 1 if on else 0))
+
+    def timing_read(self):
+        """(exchange_ms, allreduce_ms, steps): sums of the event intervals on the communication stream since timing_enable"""
+        ex, ar, n = C.c_double(), C.c_double(), C.c_int()
+        _ck(self._L.tau3d_ring_timing_read(self._r, C.byref(ex), C.byref(ar), C.byref(n)))
+        return ex.value, ar.value, n.value
 
     def info(self):
         ver, ranks, edge = C.c_int(), C.c_int(), C.c_int()

@@ -211,6 +211,12 @@ int tau3d_ring_get_clock(tau3d_ring_t *r, tau3d_clock *out);
 int tau3d_ring_barrier(tau3d_ring_t *r);           /* host barrier over the ranks (through the rendezvous file) */
 /* RCCL's version (ncclGetVersion), the rank count of the communicator (ncclCommCount), planes per edge launch, the
  * librccl the ring bound to; any pointer may be NULL */
+/* HIP events on the ring's communication stream around the exchange and around the all-reduce of every step (default
+ * schedule): enable, step, finish, read the sums over `steps` timed steps (<= 256 per enable).  The all-reduce follows the
+ * exchange on that stream and completes when the slowest rank's has — it carries the skew between ranks.  (The reference has no
+ * counterpart: its loop is single-GPU, tau_hypersonic_3d_cuda.cu:1680-1711; these are bench.py's per-rank ring figures.) */
+int tau3d_ring_timing_enable(tau3d_ring_t *r, int on);
+int tau3d_ring_timing_read(tau3d_ring_t *r, double *exchange_ms, double *allreduce_ms, int *steps);
 int tau3d_ring_info(tau3d_ring_t *r, int *rccl_version, int *comm_ranks, int *edge_planes, char *lib_path, size_t lib_path_len);
 
 /* The export path of th3cs.cu (:1193-1222): the volume of the last tau3d_vis — th3cs uses mode 0, its

@@ -200,6 +200,7 @@ def test_bench_force_slab_c_ring(eng):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["ring"]["transport"] == "rccl" and j["ring"]["comm_ranks"] == 1 and j["value"] > 0
+    assert j["ring"]["matches_single_domain"] is True and j["ring"]["clock_matches"] is True and j["ring"]["differing_planes"] == 0
 
 
 def test_ring_rendezvous_times_out_instead_of_hanging(eng, tmp_path):
@@ -245,23 +246,71 @@ def test_bench_two_ranks_end_to_end_on_one_gpu(eng, transport, word):
     assert j["n_gpus"] == 2 and j["config"]["decomposition"] == "z-slab x2" and j["value"] > 0
     assert len(j["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and all(t > 0 for t in j["roofline"]["per_rank_kernel_ms_per_step"])
     assert word in j["ring"]["transport"]
+    # the run proved itself: every rank's slab == its own single-domain recompute, bit for bit, and the per-rank event times are there
+    assert j["ring"]["matches_single_domain"] is True and j["ring"]["clock_matches"] is True and j["ring"]["first_differing_plane"] is None
+    pr = j["ring"]["per_rank_event_ms_per_step"]
+    assert [r["rank"] for r in pr] == [0, 1] and all(r["xy_ms"] > 0 and r["z_ms"] > 0 and r["exchange_ms"] > 0 and r["allreduce_ms"] > 0 for r in pr), pr
 
 
-def test_bench_auto_transport_probe_on_one_gpu(eng):
-    """`bench.py --gpus 2` with the default --ring-transport auto: both candidate transports are built, timed over a few warm-up
-    steps and closed again, the faster one is rebuilt for the timed region.  On this one-GPU box the candidates are the two that let
-    ranks share a device (TAU_BENCH_AUTO_SHARED: ipc-host against host; with a device per rank: ipc against rccl)."""
+@pytest.mark.parametrize("ranks,grid", [(2, 128), (8, 128)])
+def test_bench_auto_transport_probe_on_one_gpu(eng, ranks, grid):
+    """`bench.py --gpus N` with the default --ring-transport auto, the command the driver's scaling run issues: both candidate
+    transports are built, timed over a few warm-up steps and closed again, the faster one is rebuilt for the timed region, and
+    after it every rank checks its slab against its own single-domain recompute (ring.matches_single_domain).  On this one-GPU box
+    the candidates are the two that let ranks share a device (TAU_BENCH_AUTO_SHARED: ipc-host against host; with a device per
+    rank: ipc against rccl)."""
     import json
     import sys
-    env = dict(os.environ, TAU_BENCH_AUTO_SHARED="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TAU3D_RING_TIMEOUT="60")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "4", "--warmup", "2"],
+    env = dict(os.environ, TAU_BENCH_AUTO_SHARED="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TAU3D_RING_TIMEOUT="120")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--grid", str(grid), "--steps", "4", "--warmup", "2"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    probes = j["ring"]["auto_probe_ms_per_step"]
+    assert j["n_gpus"] == ranks and len(probes) == 2 and all(isinstance(v, float) and v > 0 for v in probes.values()), probes
+    fastest = min(probes, key=probes.get)
+    assert j["ring"]["transport"] == fastest
+    assert j["ring"]["matches_single_domain"] is True and j["ring"]["clock_matches"] is True and j["ring"]["differing_planes"] == 0
+    assert len(j["ring"]["per_rank_event_ms_per_step"]) == ranks
+
+
+def test_bench_verification_catches_a_single_flipped_bit(eng):
+    """the check can fail: TAU_BENCH_VERIFY_SELFTEST flips one bit of one word of the last rank's downloaded slab before the
+    comparison -> matches_single_domain false, the plane named, exit code 4 (and the ring / process group still torn down)"""
+    import json
+    import sys
+    env = dict(os.environ, TAU_BENCH_VERIFY_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TAU3D_RING_TIMEOUT="60")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "3", "--warmup", "1",
+                        "--ring-transport", "host"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 4, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["ring"]["matches_single_domain"] is False and j["ring"]["clock_matches"] is True
+    assert j["ring"]["first_differing_plane"] == 64 + 32 and j["ring"]["differing_planes"] == 1
+    assert "does NOT reproduce" in r.stderr
+    # --no-verify skips it
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "3", "--warmup", "1",
+                        "--ring-transport", "host", "--no-verify"], capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["ring"]["matches_single_domain"] is None
+
+
+def test_bench_probe_survives_a_candidate_that_fails_while_stepping(eng):
+    """auto: the first candidate builds on every rank and then throws on one rank while stepping (TAU_BENCH_FAIL_PROBE) — it is
+    reported unavailable, closed, and the other candidate runs the timed region; the run still verifies"""
+    import json
+    import sys
+    import fluid_sims_amd as f
+    env = dict(os.environ, TAU_BENCH_AUTO_SHARED="1", TAU_BENCH_FAIL_PROBE=str(f.RING_IPC_HOSTMAX), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               TAU3D_RING_TIMEOUT="20")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--grid", "128", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     probes = j["ring"]["auto_probe_ms_per_step"]
-    assert j["n_gpus"] == 2 and len(probes) == 2 and all(isinstance(v, float) and v > 0 for v in probes.values()), probes
-    fastest = min(probes, key=probes.get)
-    assert j["ring"]["transport"] == fastest
+    bad = [k for k, v in probes.items() if isinstance(v, str)]
+    assert len(bad) == 1 and "ipc-host" in bad[0] and "TAU_BENCH_FAIL_PROBE" in probes[bad[0]], probes
+    assert "host-staged" in j["ring"]["transport"] and j["ring"]["matches_single_domain"] is True
 
 
 def test_ring_refuses_a_zero_job_key_and_reports_a_failed_peer(eng, tmp_path):
