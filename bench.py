@@ -596,14 +596,14 @@ def main():
                     ok = 0
             except Exception as e:
                 ok, verr = 0, f"rank {rank}: {e}"
-            v = torch.tensor([ok, clock_ok, -first_bad, -nbad], dtype=torch.int64, device=cdev)
+            v = torch.tensor([ok, clock_ok, first_bad], dtype=torch.int64, device=cdev)
             tot = torch.tensor([nbad], dtype=torch.int64, device=cdev)
             if world > 1:
                 dist.all_reduce(v, op=dist.ReduceOp.MIN)
                 dist.all_reduce(tot, op=dist.ReduceOp.SUM)
             v = [int(x) for x in v.tolist()]
             verify = {"matches_single_domain": bool(v[0]), "clock_matches": bool(v[1]),
-                      "first_differing_plane": (-v[2] if -v[2] < 2 ** 31 - 1 else None), "differing_planes": int(tot.item()),
+                      "first_differing_plane": (v[2] if v[2] < 2 ** 31 - 1 else None), "differing_planes": int(tot.item()),
                       "compared": f"{n}^3 x 6 fields, every rank's planes against its own single-domain recompute of "
                                   f"{args.warmup + args.steps} steps, bit patterns", "seconds": round(time.perf_counter() - t0v, 2)}
             if verr:
