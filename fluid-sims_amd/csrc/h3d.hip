@@ -499,52 +499,54 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
       sR = (asr >= d) ? sR : ((sR >= 0.f) ? fr : -fr);
     }
   }
-  // conserved states and physical fluxes, :234-245, 268-308
+  // ---- Round 6: the flux as ONE linear combination of the two STATES.  The reference (:383-460) forms U_L, U_R, F_L, F_R, the
+  // star state and the HLL average, then blends; every one of those is linear in the two conserved states, so with
+  //     F_K = un_K U_K + p_K (e_n + un_K e_E),      U* - U_K = g U_K  (+ the two components below),      g = (s_M - un_K) / (s_K - s_M)
+  // the blend  (1 - alpha) [F_K + s_K (U* - U_K)] + alpha [s_R F_L - s_L F_R + s_L s_R (U_R - U_L)] / (s_R - s_L)  is
+  //     F = B_L (1, u, v, w, h, ev)_L + B_R (1, u, v, w, h, ev)_R + pressure terms + the two star corrections,
+  //     B_L = r_L (c_FL un_L - c_U + [K = L] G),   B_R = r_R (c_FR un_R + c_U + [K = R] G),   G = (1 - alpha) s_K g
+  // — a multiply and an fma per component where round 5 spent seven (F_L, F_R, U_R - U_L, four fma), no conserved vectors, no
+  // physical fluxes, and the supersonic exits become a choice of COEFFICIENTS (alpha = 0, K = the upwind side, G = 0: then
+  // c_FK = 1, everything else 0, and the sum is un_K U_K + p_K terms: F_K to rounding) instead of twelve selects of components.
+  // Star corrections, the two components of U* - U_K that are not g U_K:
+  //     normal momentum  (rho un)* - (rho un)_K = s_K (rho* - rho_K) = g (rho un)_K + g r_K (s_K - un_K)
+  //     energy           E* - E_K = ((s_M - un_K) E_K - p_K un_K + p* s_M) / (s_K - s_M)   — carried as the difference the
+  //                      reference's own formulation resolves, fl(E_K + d) - E_K (round 5's finding, kept: between two floored
+  //                      densities s_M is noise and must vanish in E_K's rounding, likewise g in fl(1 + g) - 1)
+  // Explicit fma chains throughout: the inlined copies of this function (chunk prologue / marching loop, slab / single domain)
+  // must round alike.
   const float keL = 0.5f * (L.q[IU] * L.q[IU] + L.q[IV] * L.q[IV] + L.q[IW] * L.q[IW]);
   const float keR = 0.5f * (R.q[IU] * R.q[IU] + R.q[IV] * R.q[IV] + R.q[IW] * R.q[IW]);
   // e_th = p / max((gamma-1) r, floor): the floor only bites below r = 1e-29
   const float gL = A.gm1 * rL, gR = A.gm1 * rR;
   const float ethL = (gL >= RHO_P_FLOOR) ? pL * irL * A.inv_gm1 : pL * (1.f / RHO_P_FLOOR);
   const float ethR = (gR >= RHO_P_FLOOR) ? pR * irR * A.inv_gm1 : pR * (1.f / RHO_P_FLOOR);
-#ifndef TAU3D_HLLC_SUPER_WAVE
-#define TAU3D_HLLC_SUPER_WAVE 0   // measured, not kept
-#endif
-  Cons UL, UR, FL, FR;
-#if TAU3D_HLLC_SUPER_WAVE
-  // Timing build only (round 5): every face of the wave supersonic to the right — the x faces of the free stream at Mach 100 — takes
-  // the left flux alone, formed before the right state's conserved vector and flux exist.  With all three axes k_update_z went
-  // 2.14 -> 2.57 ms (no room in its allocation for the second exit) while k_flux_xy read 3.37 -> 3.17 — which was the chip clocking
-  // up behind the slower z kernel: restricted to the x / y faces the same k_flux_xy measures 3.29 -> 3.28 ms (79 VGPRs against 75).
+  const float hL = (keL + ethL) + L.q[IE];   // E / r, :234-245
+  const float EL = rL * hL;
+  // Every face of the wave supersonic to the right (:431 s_L >= 0 -> F_L) — the x faces of the free stream and of most of the
+  // shock layer at Mach 100: F_L alone, before anything of the right state's energy or of the star region exists.  (Round 5 got
+  // this skip from the compiler, which turned the early return into a divergent branch; the coefficient form below has no
+  // branch to skip, so the wave-uniform exit is spelled out.  Not on the z axis: the marching kernel's flow is never supersonic
+  // in z, and the second exit costs its allocation registers.)
   if (axis != 2 && __builtin_amdgcn_ballot_w64(!(sL >= 0.f)) == 0ull) {
-    UL.c[1] = rL * L.q[IU]; UL.c[2] = rL * L.q[IV]; UL.c[3] = rL * L.q[IW]; UL.c[5] = rL * L.q[IE];
-    const float HL0 = pL * irL + (keL + L.q[IE]) + ethL;
-    FL.c[0] = rL * unL; FL.c[1] = UL.c[1] * unL; FL.c[2] = UL.c[2] * unL; FL.c[3] = UL.c[3] * unL;
-    FL.c[4] = rL * HL0 * unL; FL.c[5] = UL.c[5] * unL;
-    if (axis == 0) FL.c[1] += pL; else if (axis == 1) FL.c[2] += pL; else FL.c[3] += pL;
-    return FL;
+    const float rm = rL * unL;
+    Cons F;
+    F.c[0] = rm;
+#pragma unroll
+    for (int k = 1; k <= 3; k++) F.c[k] = (axis == k - 1) ? __builtin_fmaf(rm, unL, pL) : rm * L.q[k];
+    F.c[4] = (EL + pL) * unL;
+    F.c[5] = rm * L.q[IE];
+    return F;
   }
-#endif
-  UL.c[0] = rL; UL.c[1] = rL * L.q[IU]; UL.c[2] = rL * L.q[IV]; UL.c[3] = rL * L.q[IW];
-  UL.c[4] = rL * (keL + ethL + L.q[IE]); UL.c[5] = rL * L.q[IE];
-  UR.c[0] = rR; UR.c[1] = rR * R.q[IU]; UR.c[2] = rR * R.q[IV]; UR.c[3] = rR * R.q[IW];
-  UR.c[4] = rR * (keR + ethR + R.q[IE]); UR.c[5] = rR * R.q[IE];
-  const float HL = pL * irL + (keL + L.q[IE]) + ethL;
-  const float HR = pR * irR + (keR + R.q[IE]) + ethR;
-  FL.c[0] = rL * unL; FL.c[1] = UL.c[1] * unL; FL.c[2] = UL.c[2] * unL; FL.c[3] = UL.c[3] * unL;
-  FL.c[4] = rL * HL * unL; FL.c[5] = UL.c[5] * unL;
-  FR.c[0] = rR * unR; FR.c[1] = UR.c[1] * unR; FR.c[2] = UR.c[2] * unR; FR.c[3] = UR.c[3] * unR;
-  FR.c[4] = rR * HR * unR; FR.c[5] = UR.c[5] * unR;
-  if (axis == 0) { FL.c[1] += pL; FR.c[1] += pR; }
-  else if (axis == 1) { FL.c[2] += pL; FR.c[2] += pR; }
-  else { FL.c[3] += pL; FR.c[3] += pR; }
+  const float hR = (keR + ethR) + R.q[IE];
+  const float ER = rR * hR;
 
-  if (sL >= 0.f) return FL;
-  if (sR <= 0.f) return FR;
-
-  const float denom = denom_guard(rL * (sL - unL) - rR * (sR - unR));
-  const float sM = (pR - pL + rL * unL * (sL - unL) - rR * unR * (sR - unR)) * rcp(denom);
-  const float pStarL = pL + rL * (sL - unL) * (sM - unL);
-  const float pStarR = pR + rR * (sR - unR) * (sM - unR);
+  const float dsL = sL - unL, dsR = sR - unR;
+  const float mdL = rL * dsL, mdR = rR * dsR;          // r_K (s_K - un_K)
+  const float denom = denom_guard(mdL - mdR);
+  const float sM = __builtin_fmaf(-mdR, unR, __builtin_fmaf(mdL, unL, pR - pL)) * rcp(denom);
+  const float pStarL = __builtin_fmaf(mdL, sM - unL, pL);
+  const float pStarR = __builtin_fmaf(mdR, sM - unR, pR);
   const float pStar = 0.5f * (pStarL + pStarR);
 
   float vc; // axis_crossflow_speed, :318-325
@@ -561,57 +563,42 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
     alpha = clampf(5.f * (0.5f * (dp + dr)), 0.f, 1.f) * align;
   }
   const float ihll = rcp(denom_guard(sR - sL));
-  const float sLR = sL * sR;
 
-  const bool left = (sM >= 0.f);
-  const float sK = left ? sL : sR, unK = left ? unL : unR, rK = left ? rL : rR, pK = left ? pL : pR;
+  // which side: the supersonic exits (:431-434: s_L >= 0 -> F_L, else s_R <= 0 -> F_R) are the star branch's own choice of K
+  // with alpha = 0 and no star correction
+  const bool supL = (sL >= 0.f), supR = (sR <= 0.f);
+  const bool sup = supL || supR;
+  const bool left = supL || (!supR && (sM >= 0.f));
+  alpha = sup ? 0.f : alpha;
+  const float sK = left ? sL : sR, unK = left ? unL : unR, pK = left ? pL : pR, EK = left ? EL : ER, mdK = left ? mdL : mdR;
   const float iden = rcp(denom_guard(sK - sM));
-  // The star state enters the flux only through dU = U* - U_K (:441-459: F_K + s_K (U* - U_K)).  The reference forms U* and
-  // subtracts; here the DIFFERENCE is formed directly —
-  //     rho* - rho_K = rho_K (s_M - un_K) / (s_K - s_M),     (rho un)* - (rho un)_K = s_K (rho* - rho_K),
-  //     E* - E_K = ((s_M - un_K) E_K - p_K un_K + p* s_M) / (s_K - s_M),      Ev* - Ev_K = Ev_K (s_M - un_K) / (s_K - s_M)
-  // — the same numbers to rounding wherever U* - U_K is well conditioned, and finite where it is not: a WENO state whose
-  // density undershoots below zero is floored at 1e-30 (prim_floor), its sound speed is ~1e15, and s_K (E* - E_K) becomes
-  // 1e15 times the rounding error of E* = ((s_K - un_K) E_K ...) / (s_K - s_M).  The reference survives such a face only when
-  // its IEEE division happens to return (s_K E_K) / s_K = E_K exactly; a reciprocal-multiply never does, and the energy flux
-  // came out at +-1e7 (found by scripts/fuzz_ref3d.py on thin anisotropic grids; round 4).
-  // Round 5: the increments are then rounded to what the reference's own formulation resolves.  It forms U* = U_K (s_K - un_K) /
-  // (s_K - s_M) and E* = (...) / (s_K - s_M) and subtracts U_K: the ratio is fl(1 + g), the energy fl(E_K + dE).  Between two
-  // floored densities (1e-30 either side of the face, sound speeds of 1e15) s_M is a ratio below its denominator guard — a
-  // one-ulp difference of the two WENO pressures makes it 3e4 — and the reference never sees it: g = 1e-10 vanishes in fl(1 + g).
-  // Formed directly and unrounded, s_K dU carried that s_M into an energy flux of 4e4 as soon as the two pressures differed in
-  // the last bit (tests/golden/weno_undershoot_yline.json with round 5's WENO rounding; round 4's happened to give equal
-  // pressures).  (x + 1) - 1 and (E + d) - E: four full-rate adds; elsewhere g = O(0.01 .. 1) and the rounding is the
-  // reference's own 6e-8 of the conserved state.
-  const float g = ((sM - unK) * iden + 1.f) - 1.f;
-  const float dR = rK * g;
-  Cons dU;
-  dU.c[0] = dR;
-  const float uK = left ? L.q[IU] : R.q[IU], vK = left ? L.q[IV] : R.q[IV], wK = left ? L.q[IW] : R.q[IW];
-  dU.c[1] = dR * ((axis == 0) ? sK : uK);   // fill_star_momentum, :335-350, as a difference
-  dU.c[2] = dR * ((axis == 1) ? sK : vK);
-  dU.c[3] = dR * ((axis == 2) ? sK : wK);
-  const float EK = left ? UL.c[4] : UR.c[4], EvK = left ? UL.c[5] : UR.c[5];
-  dU.c[4] = (EK + ((sM - unK) * EK - pK * unK + pStar * sM) * iden) - EK;
-  dU.c[5] = EvK * g;
-  // The blend  F = (1 - alpha) [F_K + s_K dU] + alpha [s_R F_L - s_L F_R + s_L s_R (U_R - U_L)] / (s_R - s_L)  (:441-459)
-  // as ONE linear combination of F_L, F_R, dU and U_R - U_L: the coefficients are picked once (two selects) instead of picking
-  // F_K per component.
+  const float dM = sM - unK;
+  const float g = (__builtin_fmaf(dM, iden, 1.f)) - 1.f;
+  const float X = __builtin_fmaf(pStar, sM, __builtin_fmaf(dM, EK, -(pK * unK)));
+  const float dEq = __builtin_fmaf(X, iden, EK) - EK;
+
   const float wC = 1.f - alpha, wH = alpha * ihll;
-  const float aS = wC * sK, cU = wH * sLR;
+  const float aS = wC * sK;
+  const float G = sup ? 0.f : aS * g;            // (a select, not a product with zero: g of a face nobody asked for may be anything)
+  const float aSdE = sup ? 0.f : aS * dEq;
+  const float cU = wH * (sL * sR);
   const float lw = left ? wC : 0.f;
-  const float cFL = wH * sR + lw, cFR = (wC - lw) - wH * sL;
-  // explicit fma chain: left to contraction, the sum was fused differently in two inlined copies of this function (the chunk
-  // prologue and the marching loop of the fused kernel), and a Z-slab run — whose chunks start elsewhere — was no longer
-  // bit-identical to the single domain
+  const float cFL = __builtin_fmaf(wH, sR, lw), cFR = __builtin_fmaf(-wH, sL, wC - lw);
+  const float fpL = cFL * unL, fpR = cFR * unR;  // what multiplies p_L, p_R in the energy flux
+  const float GL = left ? G : 0.f, GR = G - GL;
+  const float BL0 = rL * (fpL - cU), BR0 = rR * (fpR + cU);
+  const float BL = __builtin_fmaf(rL, GL, BL0), BR = __builtin_fmaf(rR, GR, BR0);
   Cons F;
+  F.c[0] = BL + BR;
+  // normal momentum: un_L B_L + un_R B_R + G r_K (s_K - un_K) + c_FL p_L + c_FR p_R
+  const float Fn = __builtin_fmaf(cFR, pR, __builtin_fmaf(cFL, pL, __builtin_fmaf(G, mdK, __builtin_fmaf(unR, BR, unL * BL))));
 #pragma unroll
-  for (int k = 0; k < 6; k++) {
-    float f = cFL * FL.c[k];
-    f = __builtin_fmaf(cFR, FR.c[k], f);
-    f = __builtin_fmaf(aS, dU.c[k], f);
-    F.c[k] = __builtin_fmaf(cU, UR.c[k] - UL.c[k], f);
+  for (int k = 1; k <= 3; k++) {
+    const float Ft = __builtin_fmaf(R.q[k], BR, L.q[k] * BL);
+    F.c[k] = (axis == k - 1) ? Fn : Ft;
   }
+  F.c[4] = aSdE + __builtin_fmaf(fpR, pR, __builtin_fmaf(fpL, pL, __builtin_fmaf(hR, BR0, hL * BL0)));
+  F.c[5] = __builtin_fmaf(R.q[IE], BR, L.q[IE] * BL);
   return F;
 }
 __device__ __forceinline__ Cons hllc(const Args &A, const Prim &L, const Prim &R, int axis) { return hllc(gas_sgpr(A), L, R, axis); }

@@ -54,6 +54,23 @@ OP(mov, asm volatile("v_mov_b32 %0, %1" : "+v"(x) : "v"(b)))
 OP(mov_dpp, asm volatile("v_mov_b32_dpp %0, %0 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x)))
 OP(mov_dpp_row, asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x)))
 OP(add_dpp, asm volatile("v_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(b)))
+// round 6: integer max / min (floors of non-negative floats), three-operand max, bit-field insert, class compare, SDWA-free abs
+OP(max_i32, asm volatile("v_max_i32 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(max_u32, asm volatile("v_max_u32 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(min_u32, asm volatile("v_min_u32 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(max_i32_lit, asm volatile("v_max_i32 %0, 0x0da24260, %0" : "+v"(x)))
+OP(max3_f32, asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b)))
+OP(max3_u32, asm volatile("v_max3_u32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b)))
+OP(bfi, asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(x) : "v"(a), "v"(b)))
+OP(cmp_class, asm volatile("v_cmp_class_f32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc"))
+OP(cmp_u32, asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(x), "v"(b) : "vcc"))
+OP(sub_u32, asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(ashr, asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(x)))
+OP(and_or, asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b)))
+OP(fmamk, asm volatile("v_fmamk_f32 %0, %0, 0x3f7fbe77, %1" : "+v"(x) : "v"(b)))
+OP(fmaak, asm volatile("v_fmaak_f32 %0, %0, %1, 0x3f7fbe77" : "+v"(x) : "v"(b)))
+OP(ldexp_f, asm volatile("v_ldexp_f32 %0, %0, %1" : "+v"(x) : "v"(b)))
+OP(frexp_mant, asm volatile("v_frexp_mant_f32 %0, %0" : "+v"(x)))
 // transcendental unit
 OP(rcp, asm volatile("v_rcp_f32 %0, %0" : "+v"(x)))
 OP(rsq, asm volatile("v_rsq_f32 %0, %0" : "+v"(x)))
@@ -233,6 +250,15 @@ int main(int argc, char **argv) {
     sweep<pk_sub_i16>(iters); sweep<dot2_i32_i16>(iters); sweep<dot2_u32_u16>(iters); sweep<pk_add_f16>(iters); sweep<pk_mul_f16>(iters);
     sweep<dot2_f32_f16>(iters); sweep<mad_i32_i16>(iters); sweep<addc>(iters); sweep<ffbl>(iters); sweep<bfrev>(iters);
     sweep<mix_scan4>(iters / 4); sweep<mix_scan6>(iters / 4);
+    return 0;
+  }
+  if (argc > 2 && !strcmp(argv[2], "r06")) {     // round 6: candidates for replacing the half-rate v_max_f32 / v_cndmask floors
+    for (int wps : {4, 6}) {
+      run<fma_vvv, 0>(wps, iters); run<max_vv, 0>(wps, iters); run<max_i32, 0>(wps, iters); run<max_u32, 0>(wps, iters); run<min_u32, 0>(wps, iters);
+      run<max_i32_lit, 0>(wps, iters); run<max3_f32, 0>(wps, iters); run<max3_u32, 0>(wps, iters); run<bfi, 0>(wps, iters);
+      run<cmp_class, 0>(wps, iters); run<cmp_u32, 0>(wps, iters); run<sub_u32, 0>(wps, iters); run<ashr, 0>(wps, iters); run<and_or, 0>(wps, iters);
+      run<fmamk, 0>(wps, iters); run<fmaak, 0>(wps, iters); run<ldexp_f, 0>(wps, iters); run<frexp_mant, 0>(wps, iters);
+    }
     return 0;
   }
   if (argc > 2 && !strcmp(argv[2], "cnd")) {     // v_cndmask reading vcc (VOP2) against an SGPR pair (VOP3), alone and behind its compare
