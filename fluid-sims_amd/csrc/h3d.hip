@@ -1156,9 +1156,6 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
     }
   }
   __syncthreads();
-#ifdef TAU3D_EXP_STAGE_ONLY   // instruction-count / timing build (TAU_EXPERIMENT): staging only — wrong results
-  C.in_xy = false; return;
-#endif
   // ---- edge states of the own cell; ring cells
   // One variable at a time.  Left alone, hipcc runs the six variables breadth-first (all first differences, then all
   // smoothness indicators, ...) and needs ~140 VGPRs for it; occupancy is worth more than that ILP here.  The empty asm
@@ -1324,355 +1321,6 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   }
 }
 
-// ---------------------------------------------------------------- round 6: k_flux_xy MARCHES along y
-// The tile kernel above pays for its y edges with every tile: a ring of XT cells above and below (re-weighted for one state
-// each), XT far y faces on one wave while the others wait, and six halo rows decoded again — ~100 of its ~1 000 instructions per
-// cell, plus the idle time of the rounds that only one wave runs.  Here a workgroup owns MXT columns and walks a chunk of rows
-// in steps of MYT: the rows of a step's y stencil are already in LDS (a window of MYT + 6 rows, the new MYT rows staged per
-// step), the left state of a step's lowest y faces is what the step before wrote for its top row, and the top row's
-// divergence waits for the next step's lowest face (sPend) — no y ring, no far y faces, no y halo decode, except once per
-// chunk: the first step weights row yc-1 for its left states and the last one weights row y_end and closes the far y faces.
-// The x edges stay as they were (ring columns -1 and MXT, far x faces), on MYT rows per step instead of YT per tile.
-// Same arithmetic, same operands, same association as the tile kernel — every face flux and every divergence is bit for bit
-// what that kernel computes (tests/test_gpu_tau3d.py: test_march_equals_tile_kernel while both exist).
-#ifndef TAU3D_MXT
-#define TAU3D_MXT 64
-#endif
-#ifndef TAU3D_MYT
-#define TAU3D_MYT 8
-#endif
-#ifndef TAU3D_MCH
-#define TAU3D_MCH 128     // rows per chunk: 512 / 128 x 8 column strips x 512 planes = 16 384 workgroups at 512^3
-#endif
-constexpr int MXT = TAU3D_MXT, MYT = TAU3D_MYT, MCH = TAU3D_MCH;
-constexpr int MNT = MXT * MYT, MNW = MNT / 64;
-constexpr int MPXS = MXT + 2 * HALO + 1;      // odd row stride: a column of cells spreads over all banks
-constexpr int MWR = MYT + 2 * HALO;           // window rows
-constexpr int MPLANE = MWR * MPXS;
-static_assert(MXT == 32 || MXT == 64, "a wave is one or two rows");
-static_assert(MCH % MYT == 0 && 2 * 6 * MYT <= MNT && 6 * MXT <= MNT, "extra rounds fit one pass of the workgroup");
-struct XmLds {
-  float sP[6][MPLANE];          // the window: rows yc-3+k (k = window row), slot k mod MWR; x halo 3
-  uint8_t sS[MPLANE];
-  float sLy[6][MYT + 1][MXT];   // [r][x], r = 1 .. MYT-1: left state of the face below row r of the step, then that face's flux
-  float sLy0[2][6][MXT];        // left state of the face below row 0 of the step: the top row's Lhi of the step before (by parity)
-  float sPend[2][12][MXT];      // the top row's x difference and low-y flux, waiting for the next step's lowest face
-  float sLx0[6][MYT], sLxT[6][MYT], sRxT[6][MYT], sFxT[6][MYT];   // x ring states / far x faces, as in XyLds
-  float sRyT[6][MXT];           // chunk end: right state of the far y faces (row y_end), then their flux
-};
-__device__ __forceinline__ int mslot(int k) { return k >= MWR ? k - MWR : (k < 0 ? k + MWR : k); }   // k in [-MWR, 2 MWR)
-
-// one step of the march: rows y0 .. y0+MYT-1 (y0 = yc + s MYT); window and sLy0[par] are in place
-template <bool FAST, bool SOLID>
-__device__ __forceinline__ void march_step(const Args &A, XmLds &S, const Gas &G, int bx0, int yc, int y_end, int s, int z, bool first, bool last) {
-  auto &sP = S.sP; auto &sS = S.sS;
-  const int tid = threadIdx.x;
-  const int tx = tid % MXT, ty = MXT == 64 ? __builtin_amdgcn_readfirstlane(tid / MXT) : tid / MXT;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int par = s & 1;
-  const int y0 = yc + s * MYT;
-  const int x = bx0 + tx, y = y0 + ty;
-  const bool in_xy = (x < A.nx) && (y < y_end);
-  const int kb = (s * MYT) % MWR;                      // window row of y0 - 3
-  const int so = mslot(kb + HALO + ty);                // slot of the own row
-  const int rm3 = mslot(so - 3) * MPXS, rm2 = mslot(so - 2) * MPXS, rm1 = mslot(so - 1) * MPXS, r0 = so * MPXS,
-            rp1 = mslot(so + 1) * MPXS, rp2 = mslot(so + 2) * MPXS;
-  const int col = tx + HALO;
-  // The chunk's far y faces (between rows y_end-1 and y_end) need a round of their own only when the chunk ends with a FULL step:
-  // after a ragged one, row y_end is a row of the step (out of the chunk, staged like any other) and its low face is that face.
-  const bool far = last && (y_end - y0 == MYT);
-
-  // ---- edge states of the own cell (one variable at a time: comment in flux_xy_core); x ring; chunk start / end rows
-  // The window is a ring of rows: the five rows of the y stencil are five cell indices formed ONCE per step (the tile kernel's were
-  // constants off one base); the variable is then a constant offset on each (m * MPLANE floats: the LDS instruction's immediate).
-  // The empty asm ties the indices to a variable's results — it orders the variables, it costs nothing.
-  float Rx[6], Ry[6], Lxo[6];
-  int c0 = r0 + col, cm2 = rm2 + col, cm1 = rm1 + col, cp1 = rp1 + col, cp2 = rp2 + col;
-  float *const ly_dst = (ty == MYT - 1) ? &S.sLy0[par ^ 1][0][tx] : &S.sLy[0][ty + 1][tx];
-  constexpr int LY_M = (MYT + 1) * MXT, LY0_M = MXT;   // floats between the variables in sLy / sLy0
-#pragma unroll
-  for (int m = 0; m < 6; m++) {
-    const float *p = &sP[m][0];
-    float Ly;
-    weno_cell<FAST>(p[c0 - 2], p[c0 - 1], p[c0], p[c0 + 1], p[c0 + 2], Lxo[m], Rx[m]);
-    weno_cell<FAST>(p[cm2], p[cm1], p[c0], p[cp1], p[cp2], Ly, Ry[m]);
-    ly_dst[m * ((ty == MYT - 1) ? LY0_M : LY_M)] = Ly;
-    asm volatile("" : "+v"(c0), "+v"(cm2), "+v"(cm1), "+v"(cp1), "+v"(cp2), "+v"(Lxo[m]), "+v"(Rx[m]), "+v"(Ry[m]));
-  }
-  if (tx == MXT - 1) {
-#pragma unroll
-    for (int m = 0; m < 6; m++) S.sLxT[m][ty] = Lxo[m];
-  }
-  const int wA = (int)((unsigned)(z + s) % (unsigned)MNW), wB = (wA + 3) % MNW, wC = (wA + 5) % MNW;
-  { // x ring: column -1 gives the LEFT states of the step's low-x faces, column MXT the RIGHT states of its far x faces
-    constexpr int RT = 2 * 6 * MYT;
-    const int wrel = (wave - wA + MNW) % MNW;          // tasks start on wave wA (rotating with the plane and the step)
-    const int tt = wrel * 64 + lane;
-    if (wrel * 64 < RT && tt < RT) {                   // (a scalar test first: the other waves form no indices)
-      const int side = tt >= 6 * MYT ? 1 : 0;
-      const int r = tt - side * (6 * MYT);
-      const int m = r / MYT, ln = r - m * MYT;
-      const int row = mslot(kb + HALO + ln) * MPXS;
-      const int c0 = row + (side ? MXT + HALO : HALO - 1);
-      const int st = side ? -1 : 1;
-      const float *p = &sP[0][0] + m * MPLANE + c0;
-      float *dst = side ? &S.sRxT[0][0] + m * MYT + ln : &S.sLx0[0][0] + m * MYT + ln;
-      *dst = weno_cell_hi<FAST>(p[-2 * st], p[-st], p[0], p[st], p[2 * st]);
-    }
-  }
-  if (first) { // chunk start: row yc-1 gives the left states of the first faces — Lhi of its own weno_cell, bit for bit
-    const int t = tid - wB * 64;
-    const int tt = t < 0 ? t + MNT : t;
-    if (tt < 6 * MXT) {
-      const int m = tt / MXT, c = tt - m * MXT;
-      const float *p = &sP[0][0] + m * MPLANE + (c + HALO);
-      // rows yc-3 .. yc+1 are window rows 0 .. 4 of step 0 (kb = 0)
-      S.sLy0[par][m][c] = weno_cell_hi<FAST>(p[0 * MPXS], p[1 * MPXS], p[2 * MPXS], p[3 * MPXS], p[4 * MPXS]);
-    }
-  }
-  if (far) { // chunk end: row y_end gives the right states of the far y faces (mirrored stencil: Rlo of its own weno_cell)
-    const int t = tid - wB * 64;
-    const int tt = t < 0 ? t + MNT : t;
-    if (tt < 6 * MXT) {
-      const int m = tt / MXT, c = tt - m * MXT;
-      const int ke = mslot(kb + HALO + MYT);           // window slot of row y_end
-      const float *p = &sP[0][0] + m * MPLANE + (c + HALO);
-      S.sRyT[m][c] = weno_cell_hi<FAST>(p[mslot(ke + 2) * MPXS], p[mslot(ke + 1) * MPXS], p[ke * MPXS], p[mslot(ke - 1) * MPXS], p[mslot(ke - 2) * MPXS]);
-    }
-  }
-  __syncthreads();
-
-  // ---- faces: low-x and low-y of the own cell; the step's far x faces; the chunk's far y faces
-  float Fx[6], Fy[6];
-  {
-    Prim L, R;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      const float l = lane_below(Lxo[m]);
-      L.q[m] = (tx == 0) ? S.sLx0[m][ty] : l;
-      R.q[m] = Rx[m];
-    }
-    if (SOLID) {
-      float lo[6], hi[6];
-      unsigned sb = 0;
-#pragma unroll
-      for (int m = 0; m < 6; m++) { lo[m] = sP[m][r0 + col - 1]; hi[m] = sP[m][r0 + col]; }
-#pragma unroll
-      for (int k = 0; k < 6; k++) sb |= (unsigned)sS[r0 + col + (k - 3)] << k;
-      solid_override(L, R, lo, hi, sb, 0);
-    }
-    prim_floor(L);
-    prim_floor(R);
-    const Cons F = hllc(G, L, R, 0);
-#pragma unroll
-    for (int m = 0; m < 6; m++) Fx[m] = F.c[m];
-  }
-  {
-    Prim L, R;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      L.q[m] = (ty == 0) ? S.sLy0[par][m][tx] : S.sLy[m][ty][tx];
-      R.q[m] = Ry[m];
-    }
-    if (SOLID) {
-      float lo[6], hi[6];
-      unsigned sb = 0;
-#pragma unroll
-      for (int m = 0; m < 6; m++) { lo[m] = sP[m][rm1 + col]; hi[m] = sP[m][r0 + col]; }
-      sb = (unsigned)sS[rm3 + col] | ((unsigned)sS[rm2 + col] << 1) | ((unsigned)sS[rm1 + col] << 2) | ((unsigned)sS[r0 + col] << 3) |
-           ((unsigned)sS[rp1 + col] << 4) | ((unsigned)sS[rp2 + col] << 5);
-      solid_override(L, R, lo, hi, sb, 1);
-    }
-    prim_floor(L);
-    prim_floor(R);
-    const Cons F = hllc(G, L, R, 1);
-#pragma unroll
-    for (int m = 0; m < 6; m++) { Fy[m] = F.c[m]; if (ty != 0) S.sLy[m][ty][tx] = F.c[m]; }
-  }
-  if (wave == wC && lane < MYT) { // far x faces: column MXT, rows of the step
-    const int row = mslot(kb + HALO + lane) * MPXS;
-    const int c0 = row + (MXT + HALO);                  // the cell right of the face
-    Prim L, R;
-#pragma unroll
-    for (int m = 0; m < 6; m++) { L.q[m] = S.sLxT[m][lane]; R.q[m] = S.sRxT[m][lane]; }
-    if (SOLID) {
-      float lo[6], hi[6];
-      unsigned sb = 0;
-#pragma unroll
-      for (int m = 0; m < 6; m++) { lo[m] = sP[m][c0 - 1]; hi[m] = sP[m][c0]; }
-#pragma unroll
-      for (int k = 0; k < 6; k++) sb |= (unsigned)sS[c0 + (k - 3)] << k;
-      solid_override(L, R, lo, hi, sb, 0);
-    }
-    prim_floor(L);
-    prim_floor(R);
-    const Cons F = hllc(G, L, R, 0);
-#pragma unroll
-    for (int m = 0; m < 6; m++) S.sFxT[m][lane] = F.c[m];
-  }
-  if (far && tid < MXT) { // far y faces of the chunk: between rows y_end-1 and y_end (wave 0, or its first half)
-    const int ke = mslot(kb + HALO + MYT);
-    const int c0 = tid + HALO;
-    Prim L, R;
-#pragma unroll
-    for (int m = 0; m < 6; m++) {
-      L.q[m] = S.sLy0[par ^ 1][m][tid];                 // the top row's Lhi (written where the next step would look for it)
-      R.q[m] = S.sRyT[m][tid];
-    }
-    if (SOLID) {
-      float lo[6], hi[6];
-      unsigned sb = 0;
-#pragma unroll
-      for (int m = 0; m < 6; m++) { lo[m] = sP[m][mslot(ke - 1) * MPXS + c0]; hi[m] = sP[m][ke * MPXS + c0]; }
-#pragma unroll
-      for (int k = 0; k < 6; k++) sb |= (unsigned)sS[mslot(ke + (k - 3)) * MPXS + c0] << k;
-      solid_override(L, R, lo, hi, sb, 1);
-    }
-    prim_floor(L);
-    prim_floor(R);
-    const Cons F = hllc(G, L, R, 1);
-#pragma unroll
-    for (int m = 0; m < 6; m++) S.sRyT[m][tid] = F.c[m];   // (the slot's right state was read by this lane alone)
-  }
-  // (solid bytes of the own cell and of the one below: read before the barrier — past it, faster waves stage the next step's rows)
-  const bool own_solid = SOLID ? sS[r0 + col] != 0 : false;
-  const bool psolid = SOLID ? sS[rm1 + col] != 0 : false;
-  __syncthreads();
-
-  // ---- x/y flux divergence: the own cell (all rows but the step's top one), the pending top row of the step before
-  const float inv_dx = vreg(A.inv_dx), inv_dy = vreg(A.inv_dy);
-  const size_t plane_n = (size_t)A.nx * A.ny;
-  GChar *const dpl = (GChar *)(A.d0 + (size_t)z * plane_n);
-  const size_t ds4 = (size_t)A.dstride << 2;
-  float ex[6];
-#pragma unroll
-  for (int m = 0; m < 6; m++) {
-    const float up = lane_above(Fx[m]);
-    const float fxh = (tx == MXT - 1) ? S.sFxT[m][ty] : up;
-    ex[m] = fxh - Fx[m];
-  }
-  const bool is_top = far && (ty == MYT - 1);
-  if (ty < MYT - 1 || is_top) {
-    if (in_xy && !own_solid) {
-      const unsigned vo = lane_off((unsigned)(y * A.nx + x) << 2);
-#pragma unroll
-      for (int m = 0; m < 6; m++) {
-        const float fyh = is_top ? S.sRyT[m][tx] : S.sLy[m][ty + 1][tx];
-        gst(dpl + m * ds4, vo, ex[m] * inv_dx + (fyh - Fy[m]) * inv_dy);
-      }
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 6; m++) { S.sPend[par ^ 1][m][tx] = ex[m]; S.sPend[par ^ 1][6 + m][tx] = Fy[m]; }
-  }
-  if (ty == 0 && !first) { // row y0-1: its low faces and x faces were the step before's, its high face is this thread's low face
-    if (x < A.nx && !psolid) {
-      const unsigned vo = lane_off((unsigned)((y0 - 1) * A.nx + x) << 2);
-#pragma unroll
-      for (int m = 0; m < 6; m++) gst(dpl + m * ds4, vo, S.sPend[par][m][tx] * inv_dx + (Fy[m] - S.sPend[par][6 + m][tx]) * inv_dy);
-    }
-  }
-}
-
-// stage window rows [k_lo, k_lo + nrows) (relative to yc - 3; nrows <= MYT) of MXT + 6 columns: decoded primitives (+ solid bytes).
-// A thread takes one cell of the strip's own columns and, the first 6 nrows threads, one of the six halo columns.  Both cells'
-// loads are issued before either is decoded: one round trip to memory per step (taken one after the other, the halo cells' loads
-// left the whole workgroup waiting at the barrier for a second one behind wave 0).
-struct StageCell { float e[6]; int li; int kind; bool sol; };   // kind 0: nothing, 1: interior, 2: outflow ghost (from column nx-1), 3: inflow ghost
-__device__ __forceinline__ void stage_issue(const Args &A, StageCell &c, bool valid, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gy,
-                                            int zg, int li, bool with_ss) {
-  c.li = li; c.kind = 0; c.sol = false;
-  if (!valid) return;
-  if (gx < 0) {
-    c.kind = 3;
-    if (with_ss) c.sol = sdf_solid(A, gx, gy, zg);
-  } else {
-    const bool ghost = gx >= A.nx;
-    const unsigned vo = lane_off((unsigned)(gy * A.nx + (ghost ? A.nx - 1 : gx)) << 2);
-#pragma unroll
-    for (int m = 0; m < 6; m++) c.e[m] = gld(qpl + m * fs4, vo);
-    c.kind = ghost ? 2 : 1;
-    if (with_ss) c.sol = ghost ? sdf_solid(A, gx, gy, zg) : spl[vo >> 2] != 0;
-  }
-}
-__device__ __forceinline__ void stage_finish(const Args &A, XmLds &S, const StageCell &c, float uref, bool with_ss) {
-  if (c.kind == 0) return;
-  Prim p;
-  if (c.kind == 3) p = inflow_prim(A);
-  else {
-#pragma unroll
-    for (int m = 0; m < 6; m++) p.q[m] = decode_field_w(uref, m, c.e[m]);
-    if (c.kind == 2) p = outflow_prim(A, p);
-  }
-#pragma unroll
-  for (int m = 0; m < 6; m++) S.sP[m][c.li] = p.q[m];
-  if (with_ss) S.sS[c.li] = c.sol ? 1 : 0;
-}
-__device__ __forceinline__ void march_stage(const Args &A, XmLds &S, float uref, const GChar *qpl, size_t fs4, const uint8_t *spl, int bx0, int yc, int zg,
-                                            int k_lo, int nrows, bool with_ss) {
-  const int tid = threadIdx.x;
-  const bool ynear = A.ny >= MYT + HALO;   // every row index lies in [-ny, 2 ny): one conditional add / subtract wraps it
-  const bool w0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;   // the halo cells (6 nrows <= 48) all sit on wave 0: a scalar branch for the others
-  static_assert(2 * HALO * MYT <= 64, "halo cells of a step: one wave");
-  StageCell a, b;
-  {
-    const int r = tid / MXT, lx = HALO + (tid - r * MXT);
-    const int k = k_lo + r;
-    stage_issue(A, a, r < nrows, qpl, fs4, spl, bx0 + lx - HALO, wrap_near(yc - HALO + k, A.ny, ynear), zg, (k % MWR) * MPXS + lx, with_ss);
-  }
-  if (w0) {
-    const int r = tid / (2 * HALO), c = tid - r * (2 * HALO);
-    const int lx = c < HALO ? c : c + MXT;
-    const int k = k_lo + r;
-    stage_issue(A, b, r < nrows, qpl, fs4, spl, bx0 + lx - HALO, wrap_near(yc - HALO + k, A.ny, ynear), zg, (k % MWR) * MPXS + lx, with_ss);
-  }
-  stage_finish(A, S, a, uref, with_ss);
-  if (w0) stage_finish(A, S, b, uref, with_ss);
-}
-
-template <bool FAST> __device__ __forceinline__ void flux_xy_march(const Args &A, XmLds &S, unsigned bid) {
-  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
-  unsigned b = tau::xcd_swizzle(bid, nb);
-  const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
-  const int cy = (int)(b % (unsigned)A.nty);
-  const int bz = (int)(b / (unsigned)A.nty);
-  const int z = (bz >= A.nzc1) ? A.zl_lo2 + (bz - A.nzc1) : A.zl_lo + bz;
-  const int bx0 = bx * MXT, yc = cy * MCH, y_end = min(yc + MCH, A.ny);
-  const int nsteps = (y_end - yc + MYT - 1) / MYT;
-  const int nsy = (A.ny + MYT - 1) / MYT;             // step tiles per column strip (the flags' row count)
-  // per step tile: 0 no solid cell in the tile + its 3-cell x/y halo, 1 some, 2 the whole tile solid; the chunk stages solid bytes
-  // iff any of its steps is flagged
-  const unsigned *fl = A.xyflag ? A.xyflag + ((size_t)z * nsy + (size_t)cy * (MCH / MYT)) * A.ntx + bx : nullptr;
-  bool chunk_ss = fl == nullptr;
-  if (fl) for (int s = 0; s < nsteps; s++) chunk_ss |= fl[(size_t)s * A.ntx] != 0u;
-  const Gas G = gas_vgpr(A);
-  const float uref = vreg(A.u_ref);
-  const int zh = z + HALO, zg = wrapi(A.z0 + z, A.nz);
-  const size_t plane_n = (size_t)A.nx * A.ny;
-  const GChar *const qpl = (const GChar *)(A.in0 + (size_t)zh * plane_n);
-  const uint8_t *const spl = A.solid + (size_t)zh * plane_n;
-  const size_t fs4 = (size_t)A.fstride << 2;
-  march_stage(A, S, uref, qpl, fs4, spl, bx0, yc, zg, 0, 2 * HALO, chunk_ss);
-  unsigned prev = 2u;
-  for (int s = 0; s < nsteps; s++) {
-    march_stage(A, S, uref, qpl, fs4, spl, bx0, yc, zg, s * MYT + 2 * HALO, MYT, chunk_ss);
-    __syncthreads();
-    const unsigned tflag = fl ? fl[(size_t)s * A.ntx] : 1u;
-    // A step whose every cell is solid takes no divergence, and what it would leave behind nobody uses: the next step's lowest
-    // faces see solid cells within three rows and take their states from the cells themselves.  But the step BEFORE it left its top
-    // row pending — fluid cells, possibly, right under the body — and that row's high face is this step's lowest face: only a
-    // solid step behind another solid step (or at the chunk's start) is skipped.
-    bool skip = tflag == 2u && prev == 2u;
-#ifdef TAU3D_EXP_STAGE_ONLY   // instruction-count / timing build (TAU_EXPERIMENT): staging and barriers only — wrong results
-    skip = true;
-#endif
-    if (skip) __syncthreads();    // (the window's rows are not reused before every wave is past this step)
-    else if (tflag == 0u) march_step<FAST, false>(A, S, G, bx0, yc, y_end, s, z, s == 0, s == nsteps - 1);
-    else march_step<FAST, true>(A, S, G, bx0, yc, y_end, s, z, s == 0, s == nsteps - 1);
-    prev = tflag;
-  }
-}
-
 #ifndef TAU3D_XY_WAVES
 #define TAU3D_XY_WAVES 6
 #endif
@@ -1690,18 +1338,9 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_march(const Args &A
 // as a safety net — a small resident grid that strides over the tiles.  Each leaves at once when the device's range says the
 // other form is due, so exactly one of the two does the work, whatever the host guessed: a wrong guess costs time (an empty full
 // grid, then the strided kernel), never correctness.  STRIDE = false is the launch of rounds 2-3, one tile per workgroup.
-#ifndef TAU3D_XY_MARCH
-#define TAU3D_XY_MARCH 1    // 0: the tile kernel of rounds 2-5 (kept for the bit-identity test of the march against it)
-#endif
-#if TAU3D_XY_MARCH
-using XyShared = XmLds;
-constexpr int XYNT = MNT;
-template <bool FAST> __device__ __forceinline__ void xy_body(const Args &A, XyShared &S, unsigned b) { flux_xy_march<FAST>(A, S, b); }
-#else
 using XyShared = XyLds;
 constexpr int XYNT = XNT;
 template <bool FAST> __device__ __forceinline__ void xy_body(const Args &A, XyShared &S, unsigned b) { flux_xy_body<FAST>(A, S, b); }
-#endif
 template <bool FAST, bool STRIDE> __global__ __launch_bounds__(XYNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyShared S;
   if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;
@@ -2112,26 +1751,13 @@ __global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes
 }
 
 // geometry of k_flux_xy's work items and of its flags, as the host needs it (both translation units see the constants)
-#ifndef TAU3D_XY_MARCH
-#define TAU3D_XY_MARCH 1
-#endif
-#ifndef TAU3D_MXT
-#define TAU3D_MXT 64
-#endif
-#ifndef TAU3D_MYT
-#define TAU3D_MYT 8
-#endif
-#ifndef TAU3D_MCH
-#define TAU3D_MCH 128
-#endif
-constexpr bool XY_MARCH = TAU3D_XY_MARCH != 0;
-constexpr int XY_FX = XY_MARCH ? TAU3D_MXT : XT, XY_FY = XY_MARCH ? TAU3D_MYT : YT;     // flag tile
-constexpr int XY_WX = XY_FX, XY_WY = XY_MARCH ? TAU3D_MCH : YT;                          // work item: a column strip x a chunk of rows / a tile
+constexpr int XY_FX = XT, XY_FY = YT;      // flag tile
+constexpr int XY_WX = XT, XY_WY = YT;      // work item: one tile
 // k_flux_xy's tile flags: one word per (local plane, tile row, tile column), non-zero where the tile or its 3-cell x / y halo
 // holds a solid cell — exactly the cells whose solid byte the kernel would look at (ghost columns left of x = 0 and right of
 // x = nx-1 by the SDF, as fetch_cell_e classifies them).  One workgroup per flag; runs when the mask is built.
 __global__ __launch_bounds__(256) void k_xy_flags(Args A, const uint8_t *solid, unsigned *flags) {
-  constexpr int XT = XY_FX, YT = XY_FY;   // (the flag tile: the march's step, or the tile kernel's tile)
+
   const int ntx = (A.nx + XT - 1) / XT, nty = (A.ny + YT - 1) / YT;
   unsigned b = blockIdx.x;
   const int bx = (int)(b % (unsigned)ntx); b /= (unsigned)ntx;
