@@ -517,10 +517,11 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   // must round alike.
   const float keL = 0.5f * (L.q[IU] * L.q[IU] + L.q[IV] * L.q[IV] + L.q[IW] * L.q[IW]);
   const float keR = 0.5f * (R.q[IU] * R.q[IU] + R.q[IV] * R.q[IV] + R.q[IW] * R.q[IW]);
-  // e_th = p / max((gamma-1) r, floor): the floor only bites below r = 1e-29
-  const float gL = A.gm1 * rL, gR = A.gm1 * rR;
-  const float ethL = (gL >= RHO_P_FLOOR) ? pL * irL * A.inv_gm1 : pL * (1.f / RHO_P_FLOOR);
-  const float ethR = (gR >= RHO_P_FLOOR) ? pR * irR * A.inv_gm1 : pR * (1.f / RHO_P_FLOOR);
+  // e_th = p / max((gamma-1) r, floor) = p min(1 / ((gamma-1) r), 1 / floor): the floor only bites below r = 1e-29.  One v_min
+  // where a compare and a select stood (both half rate on gfx950, like the v_min: profiles/r06/valu_calib_r06.txt)
+  // (both products formed, the smaller taken: the same bits as  g >= floor ? p / r / (gamma-1) : p / floor  of rounds 2-5)
+  const float ethL = fminf(pL * irL * A.inv_gm1, pL * (1.f / RHO_P_FLOOR));
+  const float ethR = fminf(pR * irR * A.inv_gm1, pR * (1.f / RHO_P_FLOOR));
   const float hL = (keL + ethL) + L.q[IE];   // E / r, :234-245
   const float EL = rL * hL;
   // Every face of the wave supersonic to the right (:431 s_L >= 0 -> F_L) — the x faces of the free stream and of most of the
@@ -565,7 +566,9 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
     const float dr = fabsf(rR - rL) * sp * inv;
     alpha = clampf(5.f * (0.5f * (dp + dr)), 0.f, 1.f) * align;
   }
-  const float ihll = rcp(denom_guard(sR - sL));
+  // s_R - s_L >= 0 always (s_R is a max over un + a, s_L a min over un - a, rounding is monotonic, and the entropy fix keeps the
+  // signs and moves magnitudes up): the sign-preserving guard (:147-150) is a plain floor here
+  const float ihll = rcp(fmaxf(sR - sL, DENOM_EPS));
 
   // which side: the supersonic exits (:431-434: s_L >= 0 -> F_L, else s_R <= 0 -> F_R) are the star branch's own choice of K
   // with alpha = 0 and no star correction
@@ -989,7 +992,14 @@ template <bool FAST> __device__ __forceinline__ void step_body(const Args &A, St
         }
         float a = soundspeed(A, p1, r1); // :1345-1351
         float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * A.inv_dz;
-        if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
+        // :1338-1356 takes ssum into the maximum if it is finite and positive.  It is a sum of non-negative terms: as an unsigned integer
+  // its bit pattern orders like the value, with +inf and the NaNs on top — (bits - 0x7f800000) >> 31 (arithmetic) is all ones exactly
+  // for the finite ones; three full-rate integer instructions and one v_max_u32 for two compares, a class test and a select
+  {
+    const unsigned sb = __float_as_uint(ssum);
+    const unsigned keep = (unsigned)((int)(sb - 0x7f800000u) >> 31) & ~(unsigned)((int)sb >> 31);   // finite, sign bit clear
+    smax = __uint_as_float(max(__float_as_uint(smax), sb & keep));
+  }
         fmx = fmaxf(fmaxf(fmx, r1), fabsf(u1));            // three v_max3_f32 (a balanced tree of fmaxf compiles to six v_max_f32)
         fmx = fmaxf(fmaxf(fmx, fabsf(v1)), fabsf(w1));
         fmx = fmaxf(fmaxf(fmx, p1), ev1);
@@ -1405,7 +1415,7 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
     float ke = 0.5f * (u0 * u0 + v0 * v0 + w0 * w0);
     // r e_th = r p / max((gamma - 1) r, floor) = p / (gamma - 1) wherever the floor does not bite (r >= 1e-29): no reciprocal
     // (hllc forms its conserved states the same way)
-    const float reth = (K.gm1 * r0 >= RHO_P_FLOOR) ? p0 * K.inv_gm1 : (p0 * r0) * (1.f / RHO_P_FLOOR);
+    const float reth = fminf(p0 * K.inv_gm1, (p0 * r0) * (1.f / RHO_P_FLOOR));   // (one v_min for a compare and a select; the same bits)
     U0[4] = r0 * (ke + e0) + reth;
     U0[5] = r0 * e0;
   }
@@ -1422,10 +1432,19 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
   float ev1 = fmaxf(U1[5] * ir1, 0.f);
   float e_th = fmaxf(U1[4] * ir1 - ke - ev1, THERMAL_ENERGY_FLOOR);
   float p1 = fmaxf(K.gm1 * r1 * e_th, RHO_P_FLOOR);
-  const bool bad = !(__builtin_isfinite(r1) && __builtin_isfinite(p1) && __builtin_isfinite(u1) &&
-                     __builtin_isfinite(v1) && __builtin_isfinite(w1) && __builtin_isfinite(ev1)) ||
-                   r1 <= 0.f || p1 <= 0.f || ev1 < 0.f;
-  if (bad) { r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; ir1 = rcp(r1); }
+  // :1300-1309 resets a cell whose new state holds a non-finite value or a non-positive density / pressure.  r1, p1, ev1 come out of
+  // fmaxf against a positive floor / zero (never NaN, never below it), so the sign tests cannot fire and what is left is "all six
+  // finite" — the largest |bit pattern| of the six below the exponent-all-ones patterns (infinities and NaNs sort above every finite
+  // value as unsigned integers): two v_max3_u32 and one compare where six class tests and three compares stood.
+  const unsigned amask = __float_as_uint(K.absmask);
+  const unsigned hi6 = tau::max3u(tau::max3u(__float_as_uint(r1), __float_as_uint(p1), __float_as_uint(ev1)),
+                                  __float_as_uint(u1) & amask, __float_as_uint(v1) & amask) ;
+  const bool bad = max(hi6, __float_as_uint(w1) & amask) >= 0x7f800000u;
+  float r1e = r1, p1e = p1;   // what the encode takes the logarithm of: floored already, except after the reset (inflow values as given)
+  if (bad) {
+    r1 = A.in_r; u1 = A.in_u; v1 = A.in_v; w1 = A.in_w; p1 = A.in_p; ev1 = A.in_ev; ir1 = rcp(r1);
+    r1e = fmaxf(r1, RHO_P_FLOOR); p1e = fmaxf(p1, RHO_P_FLOOR);
+  }
   {   // evib_eq(T), T = p / (r R), :206-211: theta_v / max(T, floor) = theta_v r R / max(p, floor r R) — one reciprocal for T and 1 / T
     const float rR = r1 * A.R;
     const float av = (A.theta_v * rR) * rcp(fmaxf(p1, NEWTON_TEMP_FLOOR * rR));
@@ -1444,6 +1463,7 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
     w1 = w1 + k * (gain * A.in_w - w1);
     ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
     ir1 = rcp(r1);
+    r1e = r1; p1e = p1;
   }
   if (A.sponge_out_n > 0 && x >= (A.nx - A.sponge_out_n)) {
     int xo2 = x - (A.nx - A.sponge_out_n);
@@ -1457,19 +1477,27 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
     w1 = w1 + k * (0.0f - w1);
     ev1 = fmaxf(ev1 + k * (A.in_ev - ev1), 0.f);
     ir1 = rcp(r1);
+    r1e = r1; p1e = p1;
   }
   float a = fsqrt(fmaxf(K.gamma * p1 * ir1, DENOM_EPS));   // soundspeed, :264-266 (1 / r: the update's own, re-formed only where a sponge or the reset changed r)
   float ssum = (fabsf(u1) + a) * A.inv_dx + (fabsf(v1) + a) * A.inv_dy + (fabsf(w1) + a) * inv_dz;
-  if (__builtin_isfinite(ssum) && ssum > 0.f) smax = fmaxf(smax, ssum);
+  // :1338-1356 takes ssum into the maximum if it is finite and positive.  It is a sum of non-negative terms: as an unsigned integer
+  // its bit pattern orders like the value, with +inf and the NaNs on top — (bits - 0x7f800000) >> 31 (arithmetic) is all ones exactly
+  // for the finite ones; three full-rate integer instructions and one v_max_u32 for two compares, a class test and a select
+  {
+    const unsigned sb = __float_as_uint(ssum);
+    const unsigned keep = (unsigned)((int)(sb - 0x7f800000u) >> 31) & ~(unsigned)((int)sb >> 31);   // finite, sign bit clear
+    smax = __uint_as_float(max(__float_as_uint(smax), sb & keep));
+  }
   fmx = fmaxf(fmaxf(fmx, r1), fabsf(u1));            // three v_max3_f32 (a balanced tree of fmaxf compiles to six v_max_f32)
   fmx = fmaxf(fmaxf(fmx, fabsf(v1)), fabsf(w1));
   fmx = fmaxf(fmaxf(fmx, p1), ev1);
 
-  E[0] = flog(fmaxf(r1, RHO_P_FLOOR));
+  E[0] = flog(r1e);
   E[1] = fasinh(u1 * K.inv_u_ref, K.absmask);
   E[2] = fasinh(v1 * K.inv_u_ref, K.absmask);
   E[3] = fasinh(w1 * K.inv_u_ref, K.absmask);
-  E[4] = flog(fmaxf(p1, RHO_P_FLOOR));
+  E[4] = flog(p1e);
   E[5] = flog(fmaxf(ev1, RHO_P_FLOOR));
 }
 

@@ -86,6 +86,7 @@ __device__ __forceinline__ void gst(GChar *sbase, unsigned voff, float v) {
   asm volatile("" : "+s"(sbase));
   *(GFloat *)(sbase + voff) = v;
 }
+__device__ __forceinline__ unsigned max3u(unsigned a, unsigned b, unsigned c) { return max(max(a, b), c); }   // v_max3_u32
 __device__ __forceinline__ unsigned lane_off(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 
 } // namespace tau
