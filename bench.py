@@ -137,6 +137,7 @@ def input_variants(f, torch, dev, n, steps=20):
         e.step_async(warm)
         ms = _event_timed(torch, stream, lambda: e.step_async(steps), e.sync)
         c = e.clock()
+        ut = e.uniform_tiles()
         fr = e.field_range()
         out[name] = {"value": round(float(n) ** 3 * steps / ms / 1e6, 3), "unit": "Gcell-updates/s", "steps": steps, "warmup": warm,
                      "timing": "HIP events on the handle's stream", "weno_form": "fast (common denominator)" if fr[2] else "reciprocal",

@@ -96,6 +96,10 @@ struct Args {
   float *dxy[6];
   float *send[2];            // Z-slab ring: packed send buffers the step writes its new boundary planes into (or null)
   const unsigned *xyflag;    // k_flux_xy: [local plane][tile row][tile column] != 0 where the tile + its x/y halo holds a solid cell (or null: assume so)
+  unsigned *dzero;           // uniform-region exits (round 6): [local plane][tile row][tile column], written by k_flux_xy every step — 1: every cell of
+                             // the tile and of its x/y halo holds the same state, the tile's x/y divergence is exactly zero and was NOT stored;
+                             // read by k_update_z in place of the divergence.  null: exits off (TAU3D_UNIFORM_EXITS=0)
+  int dz_ntx, dz_nty;        // its tile grid (k_flux_xy's tiles: XT x YT)
   // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
   const float *in0;
   float *out0;
@@ -707,9 +711,11 @@ using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::
 
 // fetch_cell through a scalar plane base.  epl: field 0 of the encoded state at plane zh; fs4: bytes between fields; spl:
 // the solid mask at plane zh
+// test: eq = the six ENCODED values equal eqref[0..5] (an interior cell; ghost columns never do)
 __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
-                                             int zg, float (&q)[6], bool &sol) {
+                                             int zg, float (&q)[6], bool &sol, bool test, const float (&eqref)[6], bool &eq) {
   Prim p;
+  eq = false;
   if (gx < 0) {
     p = inflow_prim(A);
     sol = sdf_solid(A, gx, gyw, zg);
@@ -728,6 +734,7 @@ __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GC
 #pragma unroll
     for (int m = 0; m < 6; m++) e[m] = gld(qpl + m * fs4, vo);
     sol = spl[vo >> 2] != 0;
+    if (test) eq = (e[0] == eqref[0]) & (e[1] == eqref[1]) & (e[2] == eqref[2]) & (e[3] == eqref[3]) & (e[4] == eqref[4]) & (e[5] == eqref[5]);
 #pragma unroll
     for (int m = 0; m < 6; m++) p.q[m] = decode_field_w(uref, m, e[m]);
   }
@@ -1092,6 +1099,7 @@ struct XyLds {
   float sRxT[6][YT];            // right state of the far x faces (ring cell x = XT)
   float sRyT[6][XT];            // right state of the far y faces (ring cell y = YT)
   float sFxT[6][YT];            // flux through the far x faces
+  unsigned wuni[XNW];           // uniform-region exit: per wave, 1 when every cell it staged equals the tile's first cell
 };
 __device__ __forceinline__ float lane_above(float x) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /* wave_shl:1 */, 0xF, 0xF, false));
@@ -1125,10 +1133,26 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   const uint8_t *const spl = A.solid + (size_t)zh * plane_n;
   const size_t fs4 = (size_t)A.fstride << 2;
   bool own_solid = false;
+  // Uniform-region exit (round 6).  Upstream of the bow shock a supersonic flow IS the inflow state, cell for cell and bit for bit
+  // (the same arithmetic runs on the same operands in every such cell, every step), and so is everything the disturbance has not
+  // reached yet.  A tile whose cells and x/y halo cells all hold one encoded state has one state at every face: the reconstruction
+  // returns the cell value exactly (all differences zero), every face takes the same flux, and the divergence is (F - F) / dx +
+  // (F - F) / dy = +0 in every cell — exactly what the code below would compute and store.  Such a tile writes one flag instead
+  // (A.dzero, read by k_update_z in place of the six zeros per cell) and leaves.  The test: every staged cell's six ENCODED values
+  // against the tile's first cell's (a scalar load); ghost columns never pass, tiles near the body are not asked (SOLID).
+  const bool utest = !SOLID && A.dzero != nullptr;
+  const size_t tile_i = ((size_t)z * A.nty + by) * A.ntx + bx;
+  float uref6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (utest) {
+    const float *const rp = A.in0 + (size_t)zh * plane_n + (size_t)wrap_near(by0, A.ny, ynear) * A.nx + bx0;
+#pragma unroll
+    for (int m = 0; m < 6; m++) uref6[m] = rp[(size_t)m * A.fstride];
+  }
+  bool ueq = false;
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
     bool osol;
-    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, osol);
+    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, osol, utest, uref6, ueq);
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     if (SOLID) { own_solid = osol; sS[lc] = osol ? 1 : 0; }
@@ -1157,15 +1181,31 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
       }
       const int gx = bx0 + lx - HALO;
       const int gy = wrap_near(by0 + ly - HALO, A.ny, ynear);
-      bool sol;
-      fetch_cell_e(A, uref, qpl, fs4, spl, gx, gy, zg, q, sol);
+      bool sol, heq;
+      fetch_cell_e(A, uref, qpl, fs4, spl, gx, gy, zg, q, sol, utest, uref6, heq);
+      ueq = ueq && heq;
       const int li = ly * XPXS + lx;
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
       if (SOLID) sS[li] = sol ? 1 : 0;
     }
   }
+  if (utest) {
+    const bool wave_uni = __builtin_amdgcn_ballot_w64(!ueq) == 0ull;
+    if (lane == 0) S.wuni[wave] = wave_uni ? 1u : 0u;
+  }
   __syncthreads();
+  if (utest) {
+    unsigned all = 1u;
+#pragma unroll
+    for (int w = 0; w < XNW; w++) all &= S.wuni[w];
+    if (all) {      // (the same word for every thread: the workgroup leaves together)
+      if (tid == 0) A.dzero[tile_i] = 1u;
+      C.in_xy = false;
+      return;
+    }
+  }
+  if (A.dzero != nullptr && tid == 0) A.dzero[tile_i] = 0u;
   // ---- edge states of the own cell; ring cells
   // One variable at a time.  Left alone, hipcc runs the six variables breadth-first (all first differences, then all
   // smoothness indicators, ...) and needs ~140 VGPRs for it; occupancy is worth more than that ILP here.  The empty asm
@@ -1314,7 +1354,10 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   const int z = (bz >= A.nzc1) ? A.zl_lo2 + (bz - A.nzc1) : A.zl_lo + bz;   // here a "chunk" is one plane
   // one scalar load, one scalar branch: ~90 % of the tiles of the 512^3 sphere case hold no solid cell
   const unsigned tflag = A.xyflag == nullptr ? 1u : A.xyflag[((size_t)z * A.nty + by) * A.ntx + bx];
-  if (tflag == 2u) return;   // the tile is inside the body: no cell of it takes a divergence (4 % of the tiles of the 512^3 sphere case)
+  if (tflag == 2u) {         // the tile is inside the body: no cell of it takes a divergence (4 % of the tiles of the 512^3 sphere case)
+    if (A.dzero != nullptr && threadIdx.x == 0) A.dzero[((size_t)z * A.nty + by) * A.ntx + bx] = 0u;
+    return;
+  }
   const bool any_solid = tflag != 0u;
 #ifdef TAU3D_EXP_NOSOLID   // timing experiment only: the kernel without its solid-aware body, on an input without a body
   flux_xy_core<FAST, false>(A, S, C, bx, by, z);
@@ -1584,6 +1627,25 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     for (int m = 0; m < 6; m++) Fz_lo[m] = F.c[m];
   }
 
+  // Uniform-region exits (round 6; see flux_xy_core).  urun = how many of the newest planes in the ring equal their predecessor
+  // in EVERY lane of the wave (all six decoded values).  With the four newest comparisons true the five planes of the z stencil
+  // hold one state per lane: the reconstruction returns that state exactly (all differences zero: weno_cell's weighted sum is
+  // +0), so it is read instead of recomputed.  Two such windows in a row, no solid cell in the stencil and w = 0 exactly (the free
+  // stream) make the face's two states equal with no normal velocity: the blended HLLC flux is then (0, 0, 0, p, 0, 0) to the bit
+  // (s_M = 0, g = 0, alpha = 0: every coefficient of hllc()'s sum is 0 or 1) — written down instead of evaluated.
+  const bool uex = A.dzero != nullptr;
+  int urun = 0;
+  bool prev_wuni = false;
+  if (uex) {   // planes zc_lo-1 .. zc_lo+2 against their predecessors (slots 0 .. 4 hold planes zc_lo-2 .. zc_lo+2)
+#pragma unroll
+    for (int k = 1; k < 5; k++) {
+      bool eq = true;
+#pragma unroll
+      for (int m = 0; m < 6; m++) eq = eq && (ring[k][m][tid] == ring[k - 1][m][tid]);
+      urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
+    }
+  }
+
   float smax = 0.f, fmx = 0.f;
   // Plane z+3 of the first iteration takes over slot 0 (plane zc_lo-2 is done).  From then on every iteration issues the loads
   // of the plane the NEXT one needs right at its top and consumes them (writes them into the ring) at its very END, after its
@@ -1591,6 +1653,12 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   // the twelve stores of the trip before (measured: no difference either way — the stores have long completed by then).
   float Nx[6];
   unsigned nsol = load_own(6, Nx);
+  if (uex) {   // plane zc_lo+3 against plane zc_lo+2 (slot 4)
+    bool eq = true;
+#pragma unroll
+    for (int m = 0; m < 6; m++) eq = eq && (Nx[m] == ring[4][m][tid]);
+    urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
+  }
 #pragma unroll
   for (int m = 0; m < 6; m++) ring[0][m][tid] = Nx[m];
   ws = (ws >> 1) | (nsol << 5);
@@ -1602,6 +1670,9 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   GChar *const outB = (GChar *)(A.out0 + (size_t)(zc_lo + HALO) * plane_n);
   const GChar *const dB = (const GChar *)(A.d0 + (size_t)zc_lo * plane_n);                 // plane z, no halo
   unsigned vo = col4;
+  // k_flux_xy's "divergence is zero, not stored" flag of this lane's tile (two tiles per wave at most), one word per plane
+  const unsigned *dzp = uex ? A.dzero + ((size_t)zc_lo * A.dz_nty + (size_t)(min(y, A.ny - 1) / YT)) * A.dz_ntx + (size_t)(min(x, A.nx - 1) / XT) : nullptr;
+  const size_t dz_plane = (size_t)A.dz_nty * A.dz_ntx;
 
   for (int z = zc_lo; z < zc_hi; z++) {
     const bool more = z + 1 < zc_hi;
@@ -1612,7 +1683,9 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       for (int m = 0; m < 6; m++) Nx[m] = gld(qN + m * f4, vo);   // encoded: decoded where the plane enters the ring
       nsol = solN[vo >> 2] != 0 ? 1u : 0u;
     }
+    const unsigned dzf = uex ? *dzp : 0u;
     const bool own_solid = (ws >> 2) & 1u;
+    const bool wuni = uex && urun >= 4;   // (scalar) planes z-1 .. z+3 hold one state per lane
 
     float Fz_hi[6];
     float D[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1639,27 +1712,36 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       // were re-formed for every variable: 30 half-rate adds)
       int a0 = s0 * (24 * ZNT) + t4, a1 = s1 * (24 * ZNT) + t4, a2 = s2 * (24 * ZNT) + t4, a3 = s3 * (24 * ZNT) + t4,
           a4 = s4 * (24 * ZNT) + t4;
+      if (wuni) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) {
-        const float w0 = rd(a0, m), w1 = rd(a1, m), w2 = rd(a2, m), w3 = rd(a3, m), w4 = rd(a4, m);
-        weno_cell<FAST>(w0, w1, w2, w3, w4, Lz[m], R.q[m]);
-        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(Lz[m]), "+v"(R.q[m]));
+        for (int m = 0; m < 6; m++) { const float w2 = rd(a2, m); Lz[m] = w2; R.q[m] = w2; }
+      } else {
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const float w0 = rd(a0, m), w1 = rd(a1, m), w2 = rd(a2, m), w3 = rd(a3, m), w4 = rd(a4, m);
+          weno_cell<FAST>(w0, w1, w2, w3, w4, Lz[m], R.q[m]);
+          asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(Lz[m]), "+v"(R.q[m]));
+        }
       }
       // Latencies behind work: the next plane (loads issued at the top of the trip) has had the reconstruction to arrive
       // and takes over slot s0, which nothing reads any more; its six registers then carry the x/y divergence of THIS
       // plane, fetched behind the z face.  (Loaded right where the update needs it, every trip stalled a full HBM round
       // trip: 3.9 cycles per instruction against 3.1 for the mix.)
       if (more) {
+        bool eq = true;
 #pragma unroll
-        for (int m = 0; m < 6; m++) ring[s0][m][tid] = ZDEC(uref, m, Nx[m]);
+        for (int m = 0; m < 6; m++) {
+          const float nv = ZDEC(uref, m, Nx[m]);
+          if (uex) eq = eq && (nv == rd(a4, m));     // plane z+4 against plane z+3
+          ring[s0][m][tid] = nv;
+        }
+        if (uex) urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
       }
-#ifndef TAU3D_EXP_NOD   // (timing experiment: the step without the divergence read — wrong results)
-      if (in_xy && !own_solid) {
+      if (in_xy && !own_solid && dzf == 0u) {   // (a flagged tile's divergence is +0 in every cell and was not stored)
         const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
       }
-#endif
       if (ws != 0u) {   // rare: the cells either side of the face, from the ring
         float lo[6], hi[6];
 #pragma unroll
@@ -1668,10 +1750,18 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       }
       prim_floor(L);
       prim_floor(R);
-      Cons F = hllc(G, L, R, 2);
+      // (this window and the one before uniform: L, the left state the last trip left behind, is plane z's value = plane z+1's = R)
+      const bool zdirect = wuni && prev_wuni && __builtin_amdgcn_ballot_w64(ws != 0u || !(R.q[IW] == 0.f)) == 0ull;
+      if (zdirect) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
+        for (int m = 0; m < 6; m++) Fz_hi[m] = (m == 3) ? R.q[IP] : 0.f;
+      } else {
+        Cons F = hllc(G, L, R, 2);
+#pragma unroll
+        for (int m = 0; m < 6; m++) Fz_hi[m] = F.c[m];
+      }
     }
+    prev_wuni = wuni;
 
     if (in_xy) {
       float E[6];          // the cell's new encoded state
@@ -1717,6 +1807,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     }
 #pragma unroll
     for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+    if (uex) dzp += dz_plane;
     vo += plane4;
     if (more) {   // plane z+4 has replaced plane z-1; the window slides
       ws = (ws >> 1) | (nsol << 5);
@@ -2091,6 +2182,8 @@ struct tau3d {
   bool split;               // step = k_flux_xy + k_update_z (else the fused k_step)
   uint8_t *solid;
   unsigned *xyflag = nullptr;   // split step: k_flux_xy's solid-free tile flags (h3d::k_xy_flags)
+  unsigned *dzero = nullptr;    // split step, uniform-region exits: k_flux_xy's "this tile's divergence is zero" flags (h3d::Args::dzero)
+  bool uniform_exits = true;    // TAU3D_UNIFORM_EXITS=0 (read at tau3d_create): every tile and every plane takes the full path
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
   bool end_pending;         // the controller update of the last tau3d_step_async step has not run yet
@@ -2212,6 +2305,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     for (int sd = 0; sd < 2; sd++) TAU_HIP(hipMalloc(&h->xbuf[k][sd], 6 * (size_t)h3d::HALO * h->plane_n * sizeof(float)));
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
+  if (const char *e = getenv("TAU3D_UNIFORM_EXITS")) h->uniform_exits = atoi(e) != 0;   // 0: the full path everywhere (same bits; the A/B of the exits)
   fill_consts(h);
   h->expect_fast = h->base.in_fmax <= 3.0e38f;   // (TAU3D_WENO_RCP=1 or an inflow state beyond the fast window: the reciprocal form for good)
   if (h->expect_fast) h->expect_fast = h3d::fast_form(0.f, h->base.in_fmax);
@@ -2240,6 +2334,7 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipFree(h->dxy[0]);
   hipFree(h->solid);
   hipFree(h->xyflag);
+  hipFree(h->dzero);
   hipFree(h->clk);
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
   for (int k = 0; k < 2; k++)
@@ -2396,6 +2491,8 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.in0 = h->buf[h->cur][0]; A.out0 = h->buf[h->cur ^ 1][0];
   A.d0 = h->dxy[0]; A.fstride = (unsigned)h->field_stride; A.dstride = (unsigned)h->dxy_stride;
   A.xyflag = h->xyflag;
+  A.dzero = h->uniform_exits ? h->dzero : nullptr;
+  A.dz_ntx = (A.nx + h3d::XY_FX - 1) / h3d::XY_FX; A.dz_nty = (A.ny + h3d::XY_FY - 1) / h3d::XY_FY;
   A.wrap_halo = (h->wrap_now && lo == 0 && hi == h->nzl && lo2 >= hi2) ? 1 : 0;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s, bool fix = false) {   // x/y faces: one plane per workgroup
@@ -2755,6 +2852,29 @@ extern "C" int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max
   h->expect_fast = h3d::fast_form(fmaxf(c.fmax_in, __builtin_bit_cast(float, c.fmax_bits)), h->base.in_fmax);
   return 0;
 }
+/* uniform-region exits of the split step: how many of k_flux_xy's tiles (32 x 16 cells, per local plane) the LAST step found to
+ * hold one state — their x/y divergence is exactly zero and was neither computed nor stored; *enabled = 0 when the exits are off
+ * (TAU3D_UNIFORM_EXITS=0) or the handle runs the fused kernel */
+extern "C" int tau3d_uniform_tiles(tau3d_t *h, long *uniform, long *tiles, int *enabled) {
+  if (!h) return tau::fail("tau3d_uniform_tiles: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  const bool on = h->split && h->uniform_exits && h->dzero;
+  if (enabled) *enabled = on ? 1 : 0;
+  const size_t n = (size_t)((h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;
+  if (tiles) *tiles = (long)n;
+  long u = 0;
+  if (on) {
+    unsigned *host = (unsigned *)malloc(n * sizeof(unsigned));
+    if (!host) return tau::fail("tau3d_uniform_tiles: out of host memory");
+    hipError_t e = hipMemcpyAsync(host, h->dzero, n * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) { free(host); return tau::fail("tau3d_uniform_tiles: %s", hipGetErrorString(e)); }
+    for (size_t i = 0; i < n; i++) u += host[i] == 1u;
+    free(host);
+  }
+  if (uniform) *uniform = u;
+  return 0;
+}
 extern "C" int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *device, void **stream) {
   if (!h) return tau::fail("tau3d_slab_info: null handle");
   if (z0) *z0 = h->z0;
@@ -2772,6 +2892,11 @@ static int split_buffers(tau3d *h) {   // what the kernel pair needs beside the 
   if (!h->dxy[0]) {
     TAU_HIP(hipMalloc(&h->dxy[0], 6 * h->dxy_stride * sizeof(float)));
     for (int f = 1; f < 6; f++) h->dxy[f] = h->dxy[0] + f * h->dxy_stride;
+  }
+  if (!h->dzero) {   // written by every k_flux_xy launch for the planes it covers before k_update_z reads them: no initial value needed — zeroed all the same
+    const size_t ntiles = (size_t)((p->nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((p->ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;
+    TAU_HIP(hipMalloc(&h->dzero, ntiles * sizeof(unsigned)));
+    TAU_HIP(hipMemsetAsync(h->dzero, 0, ntiles * sizeof(unsigned), h->stream));
   }
   if (!h->xyflag && !(getenv("TAU3D_XY_NOFLAGS") && atoi(getenv("TAU3D_XY_NOFLAGS")))) {
     const size_t ntiles = (size_t)((p->nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((p->ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;

@@ -148,6 +148,7 @@ def load():
         "tau3d_state_written": ([vp], i32),
         "tau3d_palette_indices": ([vp, f32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "tau3d_field_range": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)], i32),
+        "tau3d_uniform_tiles": ([vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(i32)], i32),
         "tau3d_sync": ([vp], i32),
         "tau_device_count": ([C.POINTER(i32)], i32),
         "tau_guided_chunks": ([i32, i32, i32, i32, i32, C.POINTER(i32), i32, C.POINTER(i32)], i32),
@@ -531,6 +532,12 @@ class Tau3D:
     def debug_set_fmax_in(self, v):
         """test hook: the field-range word an x/y flux launch issued ahead of the clock reads (tau3d_debug_set_fmax_in)"""
         _ck(self._L.tau3d_debug_set_fmax_in(self._h, C.c_float(v)))
+
+    def uniform_tiles(self):
+        """(flagged, tiles, enabled) — tau3d_uniform_tiles: k_flux_xy tiles the last step found uniform (divergence exactly zero)"""
+        u, n, on = C.c_long(), C.c_long(), C.c_int()
+        _ck(self._L.tau3d_uniform_tiles(self._h, C.byref(u), C.byref(n), C.byref(on)))
+        return u.value, n.value, bool(on.value)
 
     def field_range(self):
         """(read_max, written_max, fast_form) — see tau3d_field_range"""

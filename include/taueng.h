@@ -167,6 +167,13 @@ int tau3d_max_ptr(tau3d_t *h, float **p);
  * *written_max = the largest it (or init / upload since) wrote, *fast_form = 1 if that launch took the
  * common-denominator WENO weights, 0 if the reciprocal form (input range above 2.5e3).  Any pointer may be NULL. */
 int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast_form);
+/* Uniform-region exits of the kernel pair (round 6): a tile of k_flux_xy whose cells and x/y halo cells all hold one encoded state
+ * has a divergence of exactly +0 in every cell (every face takes the same flux) and writes a flag instead of computing it; a wave
+ * of k_update_z whose five stencil planes hold one state per column reads the reconstruction's result (that state, exactly)
+ * instead of recomputing it.  Same bits as the full path (tests/test_gpu_tau3d.py: exits on == exits off, byte for byte); the
+ * reference has no counterpart — its k_step (tau_hypersonic_3d_cuda.cu:987-1359) evaluates every face everywhere.
+ * TAU3D_UNIFORM_EXITS=0 at tau3d_create switches them off.  tau3d_uniform_tiles: the tiles the LAST step flagged / all tiles. */
+int tau3d_uniform_tiles(tau3d_t *h, long *uniform, long *tiles, int *enabled);
 /* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state (or the solid mask) through them
  * says so here before the next step (tau3d_init / tau3d_upload_* do it themselves): the field range is measured again and
  * the static solid-free tile flags of the x/y flux kernel are rebuilt from the mask. */

@@ -497,3 +497,37 @@ def test_floored_density_face_keeps_the_energy_flux_finite(eng, oracle_built, sp
         # to the usual bound
         assert d[:, [0, 1, 2, 3, 6, 7, 8, 9], :].max() <= (2e-3 if name in ("lam", "zet") else 1e-5), (name, float(d.max()))
         assert d[:, 4:6, :].max() <= (5e-2 if name in ("lam", "zet") else 1e-4), (name, float(d[:, 4:6, :].max()))
+
+
+@pytest.mark.parametrize("shape,mode,steps", [((96, 64, 32), 1, 25), ((160, 128, 96), 1, 30), ((256, 192, 128), 1, 40), ((130, 70, 20), 0, 12),
+                                              ((256, 256, 64), 0, 300)])
+def test_uniform_region_exits_change_no_bit(eng, monkeypatch, shape, mode, steps):
+    """The split step's uniform-region exits (include/taueng.h: tau3d_uniform_tiles) against the same kernels with the exits switched
+    off (TAU3D_UNIFORM_EXITS=0): every field of every cell and the clock after every batch of steps, byte for byte — on starts
+    that are uniform almost everywhere (the exits take most tiles), on developing bow shocks, and on the ramped start."""
+    def run(on):
+        if on:
+            monkeypatch.delenv("TAU3D_UNIFORM_EXITS", raising=False)
+        else:
+            monkeypatch.setenv("TAU3D_UNIFORM_EXITS", "0")
+        e = eng.Tau3D(*shape)
+        e.set_split(True)
+        e.init(mode)
+        if mode:
+            e.set_clock(0.02, 1e-4)
+        out = []
+        for k in (1, 2, steps - 3):
+            e.step(k)
+            c = e.clock()
+            out.append((e.download(), (c.t, c.d_tau, c.maxs), e.uniform_tiles()))
+        e.close()
+        return out
+    a, b = run(True), run(False)
+    for (sa, ca, ua), (sb, cb, ub) in zip(a, b):
+        assert ca == cb
+        for x, y in zip(sa, sb):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        assert ua[2] is True and ub[2] is False and ub[0] == 0
+    frac = [u[0] / u[1] for _, _, u in a]
+    print(shape, "mode", mode, "uniform tiles after 1 / 3 /", steps, "steps:", ["%.3f" % f for f in frac])
+    assert frac[0] > 0.2            # the exits were taken: the comparison is not between two runs of the full path
