@@ -100,10 +100,6 @@ struct Args {
                              // the tile and of its x/y halo holds the same state, the tile's x/y divergence is exactly zero and was NOT stored;
                              // read by k_update_z in place of the divergence.  null: exits off (TAU3D_UNIFORM_EXITS=0)
   int dz_ntx, dz_nty;        // its tile grid (k_flux_xy's tiles: XT x YT)
-  const unsigned *dpre;      // dzero's layout: k_tile_class's pre-flags for THIS step's k_flux_xy (1: leave at once, the tile is uniform), or null
-  float *urec;               // [local plane][row][32-column segment][8]: written by k_update_z for the state it WRITES — {1.0 if the segment's 32 cells
-                             // hold one encoded state, that state's six values, pad}; k_tile_class turns them into the next step's pre-flags
-  int ur_nseg;               // segments per row
   // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
   const float *in0;
   float *out0;
@@ -1362,12 +1358,6 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
     if (A.dzero != nullptr && threadIdx.x == 0) A.dzero[((size_t)z * A.nty + by) * A.ntx + bx] = 0u;
     return;
   }
-  // pre-classified by k_tile_class from the row records the last k_update_z wrote: the tile and its halo hold one state — its
-  // divergence is zero; the flag k_update_z reads is set and the workgroup leaves (one scalar load; no cell is read)
-  if (A.dpre != nullptr && A.dpre[((size_t)z * A.nty + by) * A.ntx + bx] == 1u) {
-    if (threadIdx.x == 0) A.dzero[((size_t)z * A.nty + by) * A.ntx + bx] = 1u;
-    return;
-  }
   const bool any_solid = tflag != 0u;
 #ifdef TAU3D_EXP_NOSOLID   // timing experiment only: the kernel without its solid-aware body, on an input without a body
   flux_xy_core<FAST, false>(A, S, C, bx, by, z);
@@ -1789,33 +1779,6 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #pragma unroll
         for (int m = 0; m < 6; m++) gst(outB + m * f4, vb, E[m]);
       }
-      if (uex && A.urec != nullptr) {
-        // The row record of the NEW state: does each 32-column half of the wave hold one encoded state?  Every lane against its
-        // left neighbour (a wave shift; the first lane of a half is exempt; a lane beyond the grid is switched off here and its
-        // right neighbour then reads 0 — "no", as it should).  Lanes 0 and 32 write {flag, the six values}.  Only asked where the
-        // wave's own step was uniform (z window one state per column, zero divergence in every lane): elsewhere the answer is no,
-        // and "no" is always a safe record.
-        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-        const bool ask = wuni && __builtin_amdgcn_ballot_w64(dzf != 0u) == act;
-        float *const r = A.urec + (((size_t)z * A.ny + y) * A.ur_nseg + (size_t)(x >> 5)) * 8;
-        if (!ask) {
-          if ((lx & 31) == 0) r[0] = 0.f;
-        } else {
-          bool eq = true;
-#pragma unroll
-          for (int m = 0; m < 6; m++) {
-            const float lb = lane_below(E[m]);   // (unconditional: behind `(lx & 31) == 0 ||` its source lane would be switched off)
-            eq = eq & (((lx & 31) == 0) | (E[m] == lb));
-          }
-          const unsigned long long ne = __builtin_amdgcn_ballot_w64(!eq);
-          if ((lx & 31) == 0) {
-            const unsigned bad = (lx == 0) ? ((unsigned)ne | ~(unsigned)act) : ((unsigned)(ne >> 32) | ~(unsigned)(act >> 32));
-            r[0] = bad == 0u ? 1.f : 0.f;
-#pragma unroll
-            for (int m = 0; m < 6; m++) r[1 + m] = E[m];
-          }
-        }
-      }
       // Z-slab ring: the first / last three local planes of the NEW state go straight into the packed send buffers
       // (what k_halo_pack would copy afterwards): wave-uniform branch, one dispatch less per step
       auto send_plane = [&](float *buf, int zrel) {
@@ -1937,39 +1900,6 @@ __global__ __launch_bounds__(256) void k_xy_flags(Args A, const uint8_t *solid, 
   // 0: no solid cell in reach; 1: some; 2: every cell of the tile is solid — solid cells are copied through by k_update_z and take
   // no divergence (the reference's threads return at once there, :1063-1072), so k_flux_xy has nothing to produce for the tile
   if (threadIdx.x == 0) flags[blockIdx.x] = !any ? 0u : (fluid_own ? 1u : 2u);
-}
-
-// The next step's pre-flags from the row records k_update_z just wrote (planes [lo, hi) and [lo2, hi2)): a tile is flagged when its
-// own 32-column segment AND the segments left and right of it (which hold its three halo columns) carry one state in each of the
-// 22 rows of the tile and its y halo, the same state in all of them.  Stricter than k_flux_xy's own test (which looks at the 38
-// columns it stages, and still runs for the tiles this one leaves unflagged), never wrong.  One thread per tile.
-__global__ __launch_bounds__(256) void k_tile_class(Args A, int lo, int hi, int lo2, int hi2) {
-  static_assert(XY_FX == 32, "a tile is one record segment wide");
-  const int per_plane = A.dz_ntx * A.dz_nty;
-  const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)per_plane * (n1 + n2)) return;
-  const int pz = (int)(i / per_plane), t = (int)(i - (long)pz * per_plane);
-  const int z = pz < n1 ? lo + pz : lo2 + (pz - n1);
-  const int by = t / A.dz_ntx, bx = t - by * A.dz_ntx;
-  const size_t ti = ((size_t)z * A.dz_nty + by) * A.dz_ntx + bx;
-  unsigned flag = 0u;
-  const bool inner = bx >= 1 && (bx + 2) * XY_FX <= A.nx;          // segments bx-1, bx, bx+1 exist in full: no ghost column in reach
-  if (inner && A.xyflag != nullptr && A.xyflag[ti] == 0u) {
-    const float *const rp = A.urec + (size_t)z * A.ny * A.ur_nseg * 8;
-    const float *const r0 = rp + ((size_t)wrapi(by * XY_FY, A.ny) * A.ur_nseg + bx) * 8;
-    const float e0 = r0[1], e1 = r0[2], e2 = r0[3], e3 = r0[4], e4 = r0[5], e5 = r0[6];
-    bool ok = true;
-    for (int r = -HALO; r < XY_FY + HALO && ok; r++) {
-      const float *const row = rp + (size_t)wrapi(by * XY_FY + r, A.ny) * A.ur_nseg * 8;
-      for (int sgm = bx - 1; sgm <= bx + 1; sgm++) {
-        const float *const q = row + (size_t)sgm * 8;
-        ok = ok && q[0] == 1.f && q[1] == e0 && q[2] == e1 && q[3] == e2 && q[4] == e3 && q[5] == e4 && q[6] == e5;
-      }
-    }
-    flag = ok ? 1u : 0u;
-  }
-  const_cast<unsigned *>(A.dpre)[ti] = flag;
 }
 
 struct InitVals { float f[6]; float s[6]; }; // encoded fluid / solid cell values (host-computed, libm)
@@ -2253,8 +2183,6 @@ struct tau3d {
   uint8_t *solid;
   unsigned *xyflag = nullptr;   // split step: k_flux_xy's solid-free tile flags (h3d::k_xy_flags)
   unsigned *dzero = nullptr;    // split step, uniform-region exits: k_flux_xy's "this tile's divergence is zero" flags (h3d::Args::dzero)
-  unsigned *dpre = nullptr;     // ... k_tile_class's pre-flags for the next k_flux_xy (h3d::Args::dpre)
-  float *urec = nullptr;        // ... and k_update_z's row records of the state it wrote (h3d::Args::urec)
   bool uniform_exits = true;    // TAU3D_UNIFORM_EXITS=0 (read at tau3d_create): every tile and every plane takes the full path
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
@@ -2407,8 +2335,6 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipFree(h->solid);
   hipFree(h->xyflag);
   hipFree(h->dzero);
-  hipFree(h->dpre);
-  hipFree(h->urec);
   hipFree(h->clk);
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
   for (int k = 0; k < 2; k++)
@@ -2441,18 +2367,7 @@ extern "C" int tau3d_get_clock(tau3d_t *h, tau3d_clock *out) {
 
 // The state was written from outside the step kernel: fold its largest |primitive| into fmax_bits (`fresh`: the
 // whole local state was replaced, forget what was there).  The next clock_begin commits it.
-// The state was replaced from outside the step (init, uploads, tau3d_state_written): the pre-flags k_tile_class derived from the last
-// step's row records describe a state that is gone — cleared, so that the next k_flux_xy looks at every tile itself (its own test
-// re-flags the uniform ones).
-static int exits_invalidate(tau3d_t *h) {
-  if (h->dpre) {
-    const size_t ntiles = (size_t)((h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;
-    TAU_HIP(hipMemsetAsync(h->dpre, 0, ntiles * sizeof(unsigned), h->stream));
-  }
-  return 0;
-}
-static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {   // (every path that replaces state from outside the step comes through here)
-  if (exits_invalidate(h)) return 1;
+static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
   if (fresh) TAU_HIP(hipMemsetAsync(&h->clk->fmax_bits, 0, sizeof(unsigned), h->stream));
   h3d::Args a = h->base;
   for (int f = 0; f < 6; f++) a.in[f] = h->buf[h->cur][f];
@@ -2578,8 +2493,6 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.xyflag = h->xyflag;
   A.dzero = h->uniform_exits ? h->dzero : nullptr;
   A.dz_ntx = (A.nx + h3d::XY_FX - 1) / h3d::XY_FX; A.dz_nty = (A.ny + h3d::XY_FY - 1) / h3d::XY_FY;
-  A.urec = h->uniform_exits ? h->urec : nullptr; A.ur_nseg = (A.nx + 31) / 32;
-  A.dpre = h->uniform_exits ? h->dpre : nullptr;
   A.wrap_halo = (h->wrap_now && lo == 0 && hi == h->nzl && lo2 >= hi2) ? 1 : 0;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s, bool fix = false) {   // x/y faces: one plane per workgroup
@@ -2615,11 +2528,6 @@ static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipS
   if (pack) { Z.send[0] = h->xbuf[0][0]; Z.send[1] = h->xbuf[0][1]; }
   h3d::launch_update_z((unsigned)(tz * Z.nzc), s, Z, h->expect_fast);
   TAU_LAUNCH_CHECK("k_update_z");
-  if (Z.dpre && Z.urec && h->xyflag) {   // the next step's pre-flags for the planes just written
-    const long tiles = (long)Z.dz_ntx * Z.dz_nty * (n1 + n2);
-    hipLaunchKernelGGL(h3d::k_tile_class, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, s, Z, lo, hi, lo2, hi2);
-    TAU_LAUNCH_CHECK("k_tile_class");
-  }
   return 0;
 }
 
@@ -2990,12 +2898,6 @@ static int split_buffers(tau3d *h) {   // what the kernel pair needs beside the 
     TAU_HIP(hipMalloc(&h->dzero, ntiles * sizeof(unsigned)));
     TAU_HIP(hipMemsetAsync(h->dzero, 0, ntiles * sizeof(unsigned), h->stream));
   }
-  if (!h->dpre) {
-    const size_t ntiles = (size_t)((p->nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((p->ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;
-    TAU_HIP(hipMalloc(&h->dpre, ntiles * sizeof(unsigned)));
-    TAU_HIP(hipMemsetAsync(h->dpre, 0, ntiles * sizeof(unsigned), h->stream));
-  }
-  if (!h->urec) TAU_HIP(hipMalloc(&h->urec, (size_t)h->nzl * p->ny * ((p->nx + 31) / 32) * 8 * sizeof(float)));
   if (!h->xyflag && !(getenv("TAU3D_XY_NOFLAGS") && atoi(getenv("TAU3D_XY_NOFLAGS")))) {
     const size_t ntiles = (size_t)((p->nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((p->ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;
     TAU_HIP(hipMalloc(&h->xyflag, ntiles * sizeof(unsigned)));
