@@ -119,18 +119,26 @@ def input_variants(f, torch, dev, n, steps=20):
     # forced_reciprocal_weights: the headline input with TAU3D_WENO_RCP=1 — the general-form bodies flux_xy_body<false> /
     # update_z_body<false> a state beyond |primitive| 2.5e3 would take (no sane 512^3 state does).
     late_warm = 2500 if n >= 512 else 400
-    for name, mode, warm, body, rcp in (("reference_ic_50_warmup", 0, 50, True, False), ("developed_no_body", 1, 10, False, False),
-                                        ("developed_late", 0, late_warm, True, False), ("forced_reciprocal_weights", 1, 25, True, True)):
+    # headline_uniform_exits_off: the headline input with TAU3D_UNIFORM_EXITS=0 — every face of every cell evaluated, as the reference
+    # does; the uniform-region exits (include/taueng.h: tau3d_uniform_tiles) give the same bits in less time wherever the flow is still
+    # the undisturbed inflow state.  developed_late_exits_off: the same for the late state.
+    for name, mode, warm, body, rcp, exits in (("reference_ic_50_warmup", 0, 50, True, False, True), ("developed_no_body", 1, 10, False, False, True),
+                                               ("developed_late", 0, late_warm, True, False, True), ("forced_reciprocal_weights", 1, 25, True, True, True),
+                                               ("headline_uniform_exits_off", 1, 10, True, False, False),
+                                               ("developed_late_exits_off", 0, late_warm, True, False, False)):
         p = f.Tau3DParams()
         f.load().tau3d_params_default(ctypes.byref(p), n, n, n)
         if not body:
             p.sdf_r = -1.0
         if rcp:
             os.environ["TAU3D_WENO_RCP"] = "1"       # read by tau3d_create
+        if not exits:
+            os.environ["TAU3D_UNIFORM_EXITS"] = "0"  # read by tau3d_create
         try:
             e = f.Tau3D(n, n, n, params=p, stream=sp)
         finally:
             os.environ.pop("TAU3D_WENO_RCP", None)
+            os.environ.pop("TAU3D_UNIFORM_EXITS", None)
         e.init(mode)
         if mode:
             e.set_clock(0.02, 1e-4)
@@ -143,7 +151,8 @@ def input_variants(f, torch, dev, n, steps=20):
                      "timing": "HIP events on the handle's stream", "weno_form": "fast (common denominator)" if fr[2] else "reciprocal",
                      "max_abs_primitive": round(float(max(fr[0], fr[1])), 1) if max(fr[0], fr[1]) < 3e38 else "inf",
                      "state_sane": bool(fr[2] or rcp) and math.isfinite(float(c.maxs)) and float(max(fr[0], fr[1])) <= 6e4,
-                     "t": c.t, "gain": round(c.gain, 4)}
+                     "t": c.t, "gain": round(c.gain, 4),
+                     "uniform_exits": bool(ut[2]), "uniform_tile_fraction": round(ut[0] / max(ut[1], 1), 4)}
         e.close()
     return out
 
@@ -563,6 +572,7 @@ def main():
 
     clk = get_clock()
     frange = h.field_range()
+    utiles = h.uniform_tiles()
 
     # ---- the ring run proves itself: slab == single domain, byte for byte (SURVEY 8e's parity oracle, on the hardware and with
     # the transport that was just timed).  The grid fits one GPU, so EVERY rank recomputes warmup + steps single-domain steps from
@@ -685,7 +695,11 @@ def main():
                           # the impulsive start runs away after ~55 steps (in the reference's kernel as here): a timed window that
                           # crosses into the runaway is not the workload — state at the END of the window: fast form still
                           # taken, finite wavespeed, every |primitive| <= 6e4
-                          "state_sane": state_sane},
+                          "state_sane": state_sane,
+                          # uniform-region exits (include/taueng.h): the share of k_flux_xy's tiles (rank 0's planes) whose cells all held
+                          # the undisturbed inflow state in the last timed step — their x/y divergence is exactly zero and was not
+                          # computed; other_inputs.headline_uniform_exits_off is the same input with every face evaluated
+                          "uniform_exits": bool(utiles[2]), "uniform_tile_fraction": round(utiles[0] / max(utiles[1], 1), 4)},
                "roofline": roof}
         if out_valu:
             out["roofline_valu"] = out_valu
@@ -706,6 +720,9 @@ def main():
                 if late:   # the harder number, always beside the headline: the late developed state (ramped start, 2500 steps)
                     out["value_late"] = late["value"]
                     out["value_late_state_sane"] = late.get("state_sane")
+                off = out["other_inputs"].get("headline_uniform_exits_off")
+                if off:    # every face of every cell evaluated (what the reference's k_step does): the number the exits do not touch
+                    out["value_uniform_exits_off"] = off["value"]
             except Exception as e:  # extras never take the headline down
                 out["other_inputs"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline and not use_ring:
