@@ -105,12 +105,7 @@ __device__ __forceinline__ float minmod(float a, float b) { // :216-220
 // v_med3_f32 is one instruction: two of them instead of min, min, mul, compare, select, sign copy (8 limiters per cell; +3 %).
 // (Differs from the product test only where dl * dr underflows to 0, i.e. slopes below 1e-22.)
 __device__ __forceinline__ float mc(float dl, float dc, float dr) {
-#ifdef TAU_H2_MC_SELECT
-  const float m = fminf(fminf(fabsf(dl), fabsf(dr)), fabsf(dc));
-  return (dl * dr > 0.0f) ? copysignf(m, dl) : 0.0f;
-#else
   return __builtin_amdgcn_fmed3f(__builtin_amdgcn_fmed3f(dl, dr, 0.0f), dc, 0.0f);
-#endif
 }
 
 // state tile in LDS
@@ -228,14 +223,7 @@ __device__ __forceinline__ C4 hllc(const Args &A, P4 L, P4 R, int ax) {
   float unL = ax ? L.v : L.u, unR = ax ? R.v : R.u, utL = ax ? L.u : L.v, utR = ax ? R.u : R.v;
   float aL = sound(A, L), aR = sound(A, R);
   float SL = fminf(unL - aL, unR - aR), SR = fmaxf(unL + aL, unR + aR);
-#ifndef TAU_H2_SUPER_WAVE
-#define TAU_H2_SUPER_WAVE 0   // measured, not kept: 60.07 against 60.61 Gcell/s at 4096^2 (round 5)
-#endif
-#if TAU_H2_SUPER_WAVE
-  // every face of the wave supersonic to the right (the x faces ahead of and through most of the bow shock): the left flux alone,
-  // before the right state's conserved vector and flux exist (round 5; the per-lane return below leaves them computed)
-  if (__builtin_amdgcn_ballot_w64(!(SL >= 0.0f)) == 0ull) return flux_p(A, L, p2c(A, L), ax);
-#endif
+  // (a wave-uniform supersonic exit before the right state's flux was measured in round 5 and not kept: 60.07 against 60.61 Gcell/s, profiles/r05/ab2d_euler_hllc.txt)
   C4 UL = p2c(A, L), UR = p2c(A, R);
   C4 FL = flux_p(A, L, UL, ax), FR = flux_p(A, R, UR, ax);
   // (round 5, measured and not kept: the ladder of returns below flattened into one straight-line star-state path with a single
@@ -456,6 +444,9 @@ __global__ __launch_bounds__(NT, 7) void k_step(const Args A) {
 // (columns left of x = 0 hold the inflow state, columns right of W-1 a copy of cell W-1, rows are clamped, all
 // with the mask cleared / taken from the clamped cell), applied where a row is loaded.
 constexpr int MCOLS = 60;
+#if !defined(TAU_EXPERIMENT) && (defined(TAU_H2_VREG_CONSTS) || defined(TAU_H2_LDS_WAVES))
+#error "TAU_H2_* tuning overrides need -DTAU_EXPERIMENT (scripts/variant_build_file.sh sets it)"
+#endif
 #ifndef TAU_H2_VREG_CONSTS
 #define TAU_H2_VREG_CONSTS 2   // gas constants (1) and dt (2) of the LDS-window march in VGPRs: +0.5 % (round 4; 0 = SGPR operands)
 #endif
@@ -566,25 +557,13 @@ __global__ __launch_bounds__(256) void k_march(const Args A, int rows, int nstri
     }
     P4 xlo, xhi, ylo, yhi;
     predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
-#ifdef TAU_H2_SERIAL
-    // phase by phase: hipcc otherwise interleaves the two predictors and the two faces for ILP and needs 164 VGPRs (three
-    // waves per SIMD); a wave issues at most every ~6 cycles whatever its ILP (profiles/r02/valu_calib.txt), so occupancy
-    // is worth more.  The empty asm makes the next phase's inputs wait for this phase's results.
-    asm volatile("" : "+v"(xlo.r), "+v"(xlo.p), "+v"(xhi.r), "+v"(xhi.p), "+v"(pd.r), "+v"(pu.r));
-#endif
     predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
-#ifdef TAU_H2_SERIAL
-    asm volatile("" : "+v"(ylo.r), "+v"(ylo.p), "+v"(yhi.r), "+v"(yhi.p), "+v"(xhi.u), "+v"(xlo.u));
-#endif
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     P4 xhi_l;
     xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
     const C4 Fx = face_from(A, l1, xhi_l, w3, xlo, 0);
     const C4 dFx_p{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my, __shfl_down(Fx.E, 1, 64) - Fx.E};
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
-#ifdef TAU_H2_SERIAL
-    { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
-#endif
     const C4 Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
     // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175
     const int j = a - 2;
@@ -747,17 +726,8 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
     P4 xlo{1.f, 0.f, 0.f, 1.f}, xhi{1.f, 0.f, 0.f, 1.f}, ylo, yhi;
     if (row_x) {
       predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
-#ifdef TAU_H2_SERIAL
-      // phase by phase: hipcc otherwise interleaves the two predictors and the two faces for ILP and needs 164 VGPRs (three
-      // waves per SIMD); a wave issues at most every ~6 cycles whatever its ILP (profiles/r02/valu_calib.txt), so occupancy
-      // is worth more.  The empty asm makes the next phase's inputs wait for this phase's results.
-      asm volatile("" : "+v"(xlo.r), "+v"(xlo.p), "+v"(xhi.r), "+v"(xhi.p), "+v"(pd.r), "+v"(pu.r));
-#endif
     }
     predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
-#ifdef TAU_H2_SERIAL
-    asm volatile("" : "+v"(ylo.r), "+v"(ylo.p), "+v"(yhi.r), "+v"(yhi.p), "+v"(xhi.u), "+v"(xlo.u));
-#endif
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
     C4 dFx_p{0.f, 0.f, 0.f, 0.f};
     if (row_x) {
@@ -767,9 +737,6 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
       dFx_p = C4{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my, __shfl_down(Fx.E, 1, 64) - Fx.E};
     }
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
-#ifdef TAU_H2_SERIAL
-    { float t0 = dFx_p.r, t1 = dFx_p.E; asm volatile("" : "+v"(t0), "+v"(t1), "+v"(ylo.u), "+v"(yhi_prev.u)); }
-#endif
     C4 Gy{0.f, 0.f, 0.f, 0.f};
     if (a > j0) Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
     // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175

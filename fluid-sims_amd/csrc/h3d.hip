@@ -34,6 +34,14 @@
 #include <new>
 #include <type_traits>
 
+// Tuning overrides (tile shapes, wave caps, LDS strides) are for scripts/variant_build.sh, which defines TAU_EXPERIMENT: a product
+// build line that carries one of them by accident stops here instead of shipping another kernel.  (No macro of this file changes
+// WHAT is computed any more: the wrong-result timing variants of rounds 3-5 are gone, their A/Bs are under profiles/.)
+#if !defined(TAU_EXPERIMENT) && (defined(TAU3D_STEP_WAVES) || defined(TAU3D_TY) || defined(TAU3D_XY_TY) || defined(TAU3D_XPXS) || \
+    defined(TAU3D_XY_WAVES) || defined(TAU3D_Z_WAVES) || defined(TAU3D_FAST_ONLY))
+#error "TAU3D_* tuning overrides need -DTAU_EXPERIMENT (scripts/variant_build.sh sets it)"
+#endif
+
 namespace h3d {
 
 #ifndef TAU3D_STEP_WAVES
@@ -471,9 +479,6 @@ __device__ __forceinline__ float vreg(float s) {
 __device__ __forceinline__ Gas gas_sgpr(const Args &A) { return Gas{A.gamma, A.gm1, A.inv_gm1}; }
 __device__ __forceinline__ Gas gas_vgpr(const Args &A) { return Gas{vreg(A.gamma), vreg(A.gm1), vreg(A.inv_gm1)}; }
 __device__ __forceinline__ float rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-#ifndef TAU3D_EFIX_WAVE
-#define TAU3D_EFIX_WAVE 1
-#endif
 __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R, int axis) {
   const float rL = L.q[IR], rR = R.q[IR], pL = L.q[IP], pR = R.q[IP];
   const float irL = rcp(rL), irR = rcp(rR);
@@ -491,11 +496,9 @@ __device__ __forceinline__ Cons hllc(const Gas &A, const Prim &L, const Prim &R,
   { // entropy_fix_speed, :366-374  (1/max(0.1 a, eps) == 10/a)
     const float d = 0.1f * aRef;
     float asl = fabsf(sL), asr = fabsf(sR);
-#if TAU3D_EFIX_WAVE
     // the fix touches a signal speed within a tenth of the sound speed of zero — the sonic lines; a wave none of whose 64 faces
     // is there skips its arithmetic and selects (round 5; same values: the selects below keep sL / sR wherever the test fails)
     if (__builtin_amdgcn_ballot_w64(!(asl >= d) || !(asr >= d)) != 0ull)
-#endif
     {
       const float id = 10.f * iaRef;
       float fl = 0.5f * (asl * asl * id + d), fr = 0.5f * (asr * asr * id + d);
@@ -690,23 +693,11 @@ __device__ __forceinline__ void fetch_cell(const Args &A, int gx, int gyw, int z
 __device__ __forceinline__ float decode_field(float u_ref, int m, float e) {
   return (m >= 1 && m <= 3) ? u_ref * fsinh(e) : fexp(e);
 }
-#ifndef TAU3D_DECODE_WAVE
-#define TAU3D_DECODE_WAVE 1
-#endif
 // decode_field for the split step's kernels: fsinh_wave (bit-identical values)
 __device__ __forceinline__ float decode_field_w(float u_ref, int m, float e) {
-#if TAU3D_DECODE_WAVE
   return (m >= 1 && m <= 3) ? u_ref * fsinh_wave(e) : fexp(e);
-#else
-  return decode_field(u_ref, m, e);
-#endif
 }
-// (timing experiment only, DESIGN §8: what k_update_z would save if it read decoded primitives instead of decoding — wrong results)
-#ifdef TAU3D_EXP_NODECODE_Z
-#define ZDEC(u, m, e) (e)
-#else
 #define ZDEC(u, m, e) decode_field_w(u, m, e)
-#endif
 using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::lane_off;   // tau_common.h: scalar base + 32-bit lane offset
 
 // fetch_cell through a scalar plane base.  epl: field 0 of the encoded state at plane zh; fs4: bytes between fields; spl:
@@ -1156,14 +1147,6 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     if (SOLID) { own_solid = osol; sS[lc] = osol ? 1 : 0; }
-#ifdef TAU3D_EXP_XY_STORES   // timing experiment only: what six more stores per cell cost k_flux_xy (a decoded-primitive cache)
-    if (in_xy) {
-      GChar *const opl = (GChar *)(A.out0 + (size_t)zh * plane_n);
-      const unsigned vox = lane_off((unsigned)(yw * A.nx + x) << 2);
-#pragma unroll
-      for (int m = 0; m < 6; m++) gst(opl + m * fs4, vox, q[m]);
-    }
-#endif
     constexpr int NROWS = 2 * HALO * XT;
     constexpr int NHALO = NROWS + YT * 2 * HALO;
     if (tid < NHALO) {
@@ -1225,12 +1208,7 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
 #pragma unroll
     for (int m = 0; m < 6; m++) S.sLxT[m][ty] = Lxo[m];
   }
-#ifndef TAU3D_XY_ROT
-#define TAU3D_XY_ROT 0
-#endif
-#ifndef TAU3D_XY_WC
-#define TAU3D_XY_WC 2
-#endif
+  constexpr int TAU3D_XY_ROT = 0, TAU3D_XY_WC = 2;   // (rotation with the tile as well, and other wave offsets: measured in round 5, profiles/r05/ab_xy_rotation_waves.txt)
   // the waves that take the extra rounds rotate with the plane AND (TAU3D_XY_ROT) with the tile: the workgroups resident on a CU
   // at one time are tiles of one or two planes, and the extra rounds of all of them sat on the same two SIMDs
   const int wA = (int)((unsigned)(z + TAU3D_XY_ROT * (bx + 3 * by)) % (unsigned)XNW), wC = (wA + TAU3D_XY_WC) % XNW;
@@ -1359,12 +1337,8 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
     return;
   }
   const bool any_solid = tflag != 0u;
-#ifdef TAU3D_EXP_NOSOLID   // timing experiment only: the kernel without its solid-aware body, on an input without a body
-  flux_xy_core<FAST, false>(A, S, C, bx, by, z);
-#else
   if (any_solid) flux_xy_core<FAST, true>(A, S, C, bx, by, z);
   else flux_xy_core<FAST, false>(A, S, C, bx, by, z);
-#endif
   if (C.in_xy && !C.own_solid) {
     GChar *const dpl = (GChar *)(A.d0 + (size_t)C.z * ((size_t)A.nx * A.ny));
     const size_t ds4 = (size_t)A.dstride << 2;

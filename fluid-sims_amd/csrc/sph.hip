@@ -401,6 +401,9 @@ __device__ __forceinline__ Stage make_stage(const Args &A, int k0, int ppw, int 
 // quad reduction.  The masks in LDS and in nbrMask are indexed by particle either way.
 //
 // iterate the set bits of this lane's mask words (column `pl` of sM) in ascending candidate order
+#if !defined(TAU_EXPERIMENT) && (defined(TAUSPH_NH_D) || defined(TAUSPH_NH_F))
+#error "tuning overrides need -DTAU_EXPERIMENT (scripts/variant_build_file.sh sets it)"
+#endif
 #ifndef TAUSPH_NH_D
 #define TAUSPH_NH_D 2   // pair evaluations per trip, density pass
 #endif

@@ -50,6 +50,9 @@ struct Args {
 
 // The per-cell coefficients as VGPR values: a VALU instruction with an SGPR operand issues at half rate on gfx950
 // (profiles/r02/valu_calib.txt); the viscosity cells have four to six such operands among their ~20 instructions.  Same arithmetic.
+#if !defined(TAU_EXPERIMENT) && (defined(TAU_ST2_VREG))
+#error "tuning overrides need -DTAU_EXPERIMENT (scripts/variant_build_file.sh sets it)"
+#endif
 #ifndef TAU_ST2_VREG
 #define TAU_ST2_VREG 1
 #endif

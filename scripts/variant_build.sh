@@ -3,7 +3,7 @@
 # A tuning build of libtaueng.so with other macro settings for the 3D step: only h3d.o / h3d_split.o are recompiled, the other
 # objects come from the in-tree build.  Output: build_var/NAME/libtaueng.so (load it with TAUENG_LIB; scripts/ab3d.py).
 set -eu
-NAME=$1; DEFS=${2:-}
+NAME=$1; DEFS="-DTAU_EXPERIMENT ${2:-}"   # (the sources refuse tuning overrides without it)
 cd "$(dirname "$0")/../fluid-sims_amd"
 make -s >/dev/null
 OUT=../build_var/$NAME; mkdir -p "$OUT"

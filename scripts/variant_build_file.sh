@@ -3,7 +3,7 @@
 # stencil2d, flow2d, lbm) recompiled under other flags / macros, the other objects from the in-tree build.
 # Output: build_var/NAME/libtaueng.so (TAUENG_LIB; scripts/ab2d.py).
 set -eu
-NAME=$1; F=$2; DEFS=${3:-}
+NAME=$1; F=$2; DEFS="-DTAU_EXPERIMENT ${3:-}"   # (the sources refuse tuning overrides without it)
 cd "$(dirname "$0")/../fluid-sims_amd"
 make -s >/dev/null
 OUT=../build_var/$NAME; mkdir -p "$OUT"
