@@ -28,6 +28,7 @@ CSRC = os.path.join(HERE, "..", "fluid-sims_amd", "csrc")
 
 PROBES = r'''
 #define TAU3D_SPLIT_TU
+#define TAU_EXPERIMENT
 #define TAU3D_FAST_ONLY
 #include "h3d.hip"
 namespace h3d {
