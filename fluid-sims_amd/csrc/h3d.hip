@@ -285,7 +285,7 @@ __device__ __forceinline__ int wrap_near(int i, int n, bool nearby) {
 // all-reduced with it across slabs) — that is exactly the largest value the next step reads — and the next launch
 // takes the FAST body only when that and the inflow state are within W_FLIM; otherwise the reciprocal form.  The
 // choice is one scalar branch at the top of the kernel, identical for every workgroup and every slab of a step.
-// Mach-100 flow (stagnation pressure 1.3e4) runs FAST.
+// (Mach-100 runs stay below |primitive| 700 until the reference scheme itself runs away: FAST throughout.)
 // Round 5: the kernel pair's weno_cell carries t unscaled (one multiply less per measure; derivation at weno_cell), which
 // closes its fast window at 2 760 — W_FLIM is the one window every kernel uses, so the fused kernel's scaled forms, good to
 // 6e4, switch at 2.5e3 as well.  Mach-100 runs stay below 700 until the reference scheme itself runs away.
@@ -2157,6 +2157,7 @@ struct tau3d {
   uint8_t *solid;
   unsigned *xyflag = nullptr;   // split step: k_flux_xy's solid-free tile flags (h3d::k_xy_flags)
   unsigned *dzero = nullptr;    // split step, uniform-region exits: k_flux_xy's "this tile's divergence is zero" flags (h3d::Args::dzero)
+  bool debug_no_xy_fix = false; // TAU3D_DEBUG_NO_XY_FIX at tau3d_create (tests): tau3d_slab_xy_fix_async does nothing
   bool uniform_exits = true;    // TAU3D_UNIFORM_EXITS=0 (read at tau3d_create): every tile and every plane takes the full path
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
@@ -2279,6 +2280,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     for (int sd = 0; sd < 2; sd++) TAU_HIP(hipMalloc(&h->xbuf[k][sd], 6 * (size_t)h3d::HALO * h->plane_n * sizeof(float)));
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
+  h->debug_no_xy_fix = getenv("TAU3D_DEBUG_NO_XY_FIX") != nullptr;
   if (const char *e = getenv("TAU3D_UNIFORM_EXITS")) h->uniform_exits = atoi(e) != 0;   // 0: the full path everywhere (same bits; the A/B of the exits)
   fill_consts(h);
   h->expect_fast = h->base.in_fmax <= 3.0e38f;   // (TAU3D_WENO_RCP=1 or an inflow state beyond the fast window: the reciprocal form for good)
@@ -2687,7 +2689,7 @@ extern "C" int tau3d_slab_xy_fix_async(tau3d_t *h) {
   if (!h) return tau::fail("tau3d_slab_xy_fix: null handle");
   TAU_HIP(hipSetDevice(h->device));
   if (!h->split) return 0;
-  if (getenv("TAU3D_DEBUG_NO_XY_FIX")) return 0;   // tests only: the control run that shows a wrong-form launch is visible
+  if (h->debug_no_xy_fix) return 0;   // tests only (TAU3D_DEBUG_NO_XY_FIX, read once at tau3d_create): the control run that shows a wrong-form launch is visible
   return split_xy(h, 0, h->nzl, 0, 0, h->stream, true);
 }
 /* test hook: the range word an x/y flux launch ahead of the clock reads (the next commit overwrites it) */
