@@ -1103,8 +1103,7 @@ struct XyCell { float d[6]; bool in_xy, own_solid; int x, yw, z, lc; };
 // static mask: tau3d_create / tau3d_init) — no solid bytes are staged or read and the faces take the WENO states as they are.
 template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(const Args &A, XyLds &S, XyCell &C, int bx, int by, int z) {
   auto &sP = S.sP; auto &sS = S.sS;
-  int tid = threadIdx.x;
-  asm volatile("" : "+v"(tid));   // (opaque per tile: what is derived from it is re-formed for every tile of a group, not kept in registers across the loop)
+  const int tid = threadIdx.x;
   const int tx = tid & (XT - 1), ty = tid >> 5;
   const int lane = tid & 63, wave = tid >> 6;
   const Gas G = gas_vgpr(A);
@@ -1323,50 +1322,10 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   }
   C.in_xy = in_xy; C.own_solid = own_solid; C.x = x; C.yw = yw; C.z = z; C.lc = lc;
 }
-template <bool FAST> __device__ __forceinline__ void flux_xy_tile(const Args &A, XyLds &S, unsigned b);
-// One workgroup = A.zchunk consecutive tiles (a run along x), taken one after the other.  The argument block is read afresh for
-// every tile through the kernarg segment pointer (scalar loads, behind an empty asm the compiler cannot hoist them over): kept live
-// across the loop its ~60 SGPRs overflowed into VGPR lanes and from there into scratch (80 VGPRs + 104 B against 70 + 0), and a
-// tile took 1.67x as long (profiles/r06/ab_xy_march.txt).
-typedef const Args __attribute__((address_space(4))) *KArgsPtr;
-#if defined(__HIP_DEVICE_COMPILE__)
-// member by member (no type punning: the copy dissolves into scalar registers), from the kernarg segment
-__device__ __forceinline__ void copy_args(Args &A, KArgsPtr k) {
-#define CPA(f) A.f = k->f
-#pragma unroll
-  for (int m = 0; m < 6; m++) { CPA(in[m]); CPA(out[m]); CPA(dxy[m]); }
-  CPA(send[0]); CPA(send[1]);
-  CPA(solid); CPA(clk); CPA(xyflag); CPA(dzero); CPA(dz_ntx); CPA(dz_nty); CPA(in0); CPA(out0); CPA(d0); CPA(fstride); CPA(dstride);
-  CPA(nx); CPA(ny); CPA(nz); CPA(nzl); CPA(z0); CPA(zl_lo); CPA(zl_hi); CPA(zl_lo2); CPA(zl_hi2); CPA(nzc1); CPA(zchunk); CPA(wrap_halo);
-  CPA(ntx); CPA(nty); CPA(nzc); CPA(dx); CPA(dy); CPA(dz); CPA(inv_dx); CPA(inv_dy); CPA(inv_dz);
-  CPA(u_ref); CPA(inv_u_ref); CPA(R); CPA(gamma); CPA(gm1); CPA(inv_gm1); CPA(Twall); CPA(theta_v); CPA(Rtheta); CPA(inv_tau_vib);
-  CPA(sdf_cx); CPA(sdf_cy); CPA(sdf_cz); CPA(sdf_r); CPA(in_r); CPA(in_u); CPA(in_v); CPA(in_w); CPA(in_p); CPA(in_ev); CPA(in_fmax);
-  CPA(sponge_n); CPA(sponge_out_n); CPA(sponge_strength); CPA(sponge_out_strength);
-#undef CPA
-}
-#endif
-template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A0, XyLds &S, unsigned bid) {
-  const unsigned nb = (unsigned)(A0.ntx * A0.nty * A0.nzc), G = (unsigned)A0.zchunk, ng = (nb + G - 1) / G;
-  const unsigned g = tau::xcd_swizzle(bid, ng);
-  bool dirty = false;
-  for (unsigned k = 0; k < G; k++) {
-    const unsigned b = g * G + k;
-    if (b >= nb) break;
-    Args A;
-#if defined(__HIP_DEVICE_COMPILE__)
-    KArgsPtr kp = (KArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    copy_args(A, kp);
-#else
-    A = A0;
-#endif
-    if (dirty) __syncthreads();   // (the next tile's staging must not overtake what slow waves of the last one still read)
-    flux_xy_tile<FAST>(A, S, b);
-    dirty = true;
-  }
-}
-template <bool FAST> __device__ __forceinline__ void flux_xy_tile(const Args &A, XyLds &S, unsigned b) {
+template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S, unsigned bid) {
   XyCell C;
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
+  unsigned b = tau::xcd_swizzle(bid, nb);
   const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
   const int by = (int)(b % (unsigned)A.nty);
   const int bz = (int)(b / (unsigned)A.nty);
@@ -1413,7 +1372,7 @@ template <bool FAST, bool STRIDE> __global__ __launch_bounds__(XYNT, TAU3D_XY_WA
   __shared__ XyShared S;
   if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;
   if (!STRIDE) { xy_body<FAST>(A, S, blockIdx.x); return; }
-  const unsigned nb = ((unsigned)(A.ntx * A.nty * A.nzc) + (unsigned)A.zchunk - 1u) / (unsigned)A.zchunk;   // groups of tiles
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
     xy_body<FAST>(A, S, b);
     __syncthreads();   // the next tile's staging overwrites what slow waves of this one still read
@@ -1427,7 +1386,7 @@ __global__ __launch_bounds__(XYNT, TAU3D_XY_WAVES) void k_flux_xy_fix(const Args
   __shared__ XyShared S;
   if (A.clk->form_flip == 0u) return;
   const bool fast = fast_form(A.clk->fmax_in, A.in_fmax);
-  const unsigned nb = ((unsigned)(A.ntx * A.nty * A.nzc) + (unsigned)A.zchunk - 1u) / (unsigned)A.zchunk;   // groups of tiles
+  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
   for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) {
     if (fast) xy_body<true>(A, S, b); else xy_body<false>(A, S, b);
     __syncthreads();
@@ -2516,13 +2475,10 @@ static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s,
   h3d::Args X;
   split_args(h, X, lo, hi, lo2, hi2);
   const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
-  static const int group = [] { const char *e = getenv("TAU3D_XY_GROUP"); const int g = e ? atoi(e) : 1; return g >= 1 ? g : 1; }();
-  X.zchunk = group;   // (k_flux_xy's use of the field: consecutive tiles taken by one workgroup)
-  X.nzc1 = n1; X.nzc = n1 + n2;
+  X.zchunk = 1; X.nzc1 = n1; X.nzc = n1 + n2;
   X.ntx = (X.nx + h3d::XY_WX - 1) / h3d::XY_WX; X.nty = (X.ny + h3d::XY_WY - 1) / h3d::XY_WY;
-  const unsigned ngroups = ((unsigned)(X.ntx * X.nty * X.nzc) + (unsigned)group - 1u) / (unsigned)group;
-  if (fix) h3d::launch_flux_xy_fix(ngroups, s, X);
-  else h3d::launch_flux_xy(ngroups, s, X, h->expect_fast);
+  if (fix) h3d::launch_flux_xy_fix((unsigned)(X.ntx * X.nty * X.nzc), s, X);
+  else h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X, h->expect_fast);
   TAU_LAUNCH_CHECK("k_flux_xy");
   return 0;
 }
