@@ -206,16 +206,28 @@ def other_configs(f, torch, dev):
     stream = torch.cuda.Stream(dev)
     sp = C.c_void_p(stream.cuda_stream)
 
-    # ---- C2: tau_hypersonic_cuda 2D 4096^2 fp32, k_init geometry scaled to the grid, 50 warm-up + 200 timed steps
+    # ---- C2: tau_hypersonic_cuda 2D 4096^2 fp32, k_init geometry scaled to the grid, 50 warm-up + 200 timed steps — the
+    #      engine as it ships (uniform-region exits: a trip of the march whose five-row window holds one state skips its predictors
+    #      and faces, same bits), the same input with every trip evaluated (TAUH2_UNIFORM_EXITS=0), and the state 3000 steps later,
+    #      when the shock layer has grown across the domain
     n = 4096
-    e = f.Hypersonic2D(n, n, stream=sp)
-    e.init()
-    e.step_async(50)
-    ms = _event_timed(torch, stream, lambda: e.step_async(200), e.sync)
-    out.append({"config": f"tau_hypersonic_cuda 2D {n}x{n} fp32 (one fused kernel per step)", "steps": 200, "warmup": 50,
-                "value": round(n * n * 200 / ms / 1e6, 3), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 200, 5),
-                "roofline": _roof("h2d::k_march_lds<1>", ms / 200, n * n, 33, "valu", traffic_keys=["h2d::k_march_lds<1>"])})
-    e.close()
+    for label, exits, warm in (("", True, 50), (", every trip evaluated (TAUH2_UNIFORM_EXITS=0)", False, 50), (", after 3000 steps", True, 3000)):
+        if not exits:
+            os.environ["TAUH2_UNIFORM_EXITS"] = "0"     # read by tauh2_create
+        try:
+            e = f.Hypersonic2D(n, n, stream=sp)
+        finally:
+            os.environ.pop("TAUH2_UNIFORM_EXITS", None)
+        e.init()
+        e.step_async(warm)
+        ms = _event_timed(torch, stream, lambda: e.step_async(200), e.sync)
+        kname = "h2d::k_march_lds<1, true>" if exits else "h2d::k_march_lds<1, false>"
+        out.append({"config": f"tau_hypersonic_cuda 2D {n}x{n} fp32 (one fused kernel per step){label}", "steps": 200, "warmup": warm,
+                    "value": round(n * n * 200 / ms / 1e6, 3), "unit": "Gcell-updates/s", "ms_per_step": round(ms / 200, 5),
+                    "uniform_exits": exits,
+                    "roofline": _roof(kname, ms / 200, n * n, 33, "valu" if not exits else "valu in the shock layer, load latency in the free stream",
+                                      traffic_keys=[kname] if warm == 50 else None)})
+        e.close()
 
     # ---- C3: tau_gray_scott 8192^2, init_pattern(seed 1337), 1000 steps: four time levels per pass (the default), and the
     #      single-step kernel (one launch per step)

@@ -56,6 +56,7 @@ struct Args {
   float visc_nu, visc_rho, visc_e;
   float in_r, in_u, in_p;  // inflow_state(), :230-238
   C4 in_c;
+  int uniform_exits;       // k_march_lds: trips whose five-row window holds one state skip the predictors and the faces (TAUH2_UNIFORM_EXITS=0: off)
 };
 
 __device__ __forceinline__ float vreg(float s) {   // a wave-uniform value moved into a VGPR
@@ -643,7 +644,10 @@ struct MRing {
   __device__ __forceinline__ bool flag(int slot, int d) const { return __float_as_int(w[slot][4][min(max(lane - d, 0), 63)]) & 1; }
   __device__ __forceinline__ float fld(int slot, int f, int ln, int d) const { return w[slot][f][min(max(ln - d, 0), 63)]; }
 };
-template <int WPB>   // waves per workgroup: the waves of a workgroup share nothing, WPB only sets the granularity of dispatch
+// UEX: with the uniform-region exits (below).  Their bookkeeping costs the kernel six registers it does not have (122 -> 128 VGPRs and
+// 44 B of scratch: 60.3 -> 57.4 Gcell/s where no trip is skipped), so the kernel without them is its own instantiation
+// (TAUH2_UNIFORM_EXITS=0), untouched.
+template <int WPB, bool UEX>   // WPB waves per workgroup: the waves of a workgroup share nothing, WPB only sets the granularity of dispatch
 __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const Args A0, int rows, int nstrips, int nchunks, const int *__restrict__ crow) {
   __shared__ float sW[WPB][5][5][64];
 #if TAU_H2_VREG_CONSTS >= 1
@@ -696,11 +700,29 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
   const float in_sp = cell_speed(A, A.in_c);      // the inflow column's speed (its state is overwritten on load)
   MCell nxt = march_load(A, gx, j0, row0);
   P4 q3 = c2p(A, R.cons(s3)), q4 = c2p(A, R.cons(s4)), q2 = q3;   // primitives of rows a-2, a-1, a (after the slide): each row is converted once
+  // Uniform-region exits (round 6; the 3D step's are described in h3d.hip: flux_xy_core).  ucnt = how many of the newest rows of the
+  // window are FLAT — the same conserved state in all 64 lanes, every lane a cell of the domain outside the body — and equal to the
+  // row before them.  With five, the whole stencil of row a-2's update holds one state: the x fluxes of a row are one value (their
+  // difference +0), the y fluxes below and above the row are one value (difference +0), and predictors and faces are not evaluated;
+  // the update itself (diffusion stencil, repairs, wavespeed) runs as always — its operands are what the full path would hand it.
+  // What the skipped trips would have left for the next one (the predicted high-y state of row a-2, the y flux below it) is
+  // recomputed from that one state when the stretch ends (`stale`): the same calls on the same operands.
+  int ucnt = 0;
+  bool stale = false;
+  float ur0 = 0.f, ur1 = 0.f, ur2 = 0.f, ur3 = 0.f;
   for (int a = j0; a <= j1 + 1; a++) {
     { const int t = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = t; }   // window = rows a-4 .. a in slots s0 .. s4
     R.put(s4, nxt);
     q2 = q3; q3 = q4; q4 = c2p(A, nxt.c);
     const bool m4 = nxt.m;
+    if (UEX) {   // row a enters the window
+      auto first = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };   // (the builtin takes an int: bits, not a value conversion)
+      const float r0 = first(nxt.c.r), r1 = first(nxt.c.mx), r2 = first(nxt.c.my), r3 = first(nxt.c.E);
+      const bool flat = __builtin_amdgcn_ballot_w64(!(nxt.c.r == r0) | !(nxt.c.mx == r1) | !(nxt.c.my == r2) | !(nxt.c.E == r3) | nxt.m | !nxt.in) == 0ull;
+      const bool same = (r0 == ur0) & (r1 == ur1) & (r2 == ur2) & (r3 == ur3);
+      ucnt = flat ? ((same && ucnt > 0) ? ucnt + 1 : 1) : 0;
+      ur0 = r0; ur1 = r1; ur2 = r2; ur3 = r3;
+    }
     if (a < j1 + 1) nxt = march_load(A, gx, a + 1, row0);
     // ---- predict row p = a-1 (centre w3) along x and y
     const P4 qc = q3;
@@ -723,13 +745,30 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
     // y faces below row j0 / above row j1-1) — their x predictor and x faces, and the y face below row j0-1, are skipped
     // (wave-uniform branches; with ~16-row chunks the two warm-up trips were 11 % of the kernel).
     const bool row_x = a > j0 && a <= j1;
-    P4 xlo{1.f, 0.f, 0.f, 1.f}, xhi{1.f, 0.f, 0.f, 1.f}, ylo, yhi;
+    const int j = a - 2;
+    // the whole window one state, and an interior trip of the chunk (rows a-4 .. a all loaded as themselves, row a-2 completed here)
+    const bool uni = UEX && ucnt >= 5 && row_x && j >= j0 && j < j1;
+    P4 xlo{1.f, 0.f, 0.f, 1.f}, xhi{1.f, 0.f, 0.f, 1.f}, ylo{1.f, 0.f, 0.f, 1.f}, yhi{1.f, 0.f, 0.f, 1.f};
+    C4 dFx_p{0.f, 0.f, 0.f, 0.f};
+    C4 Gy{0.f, 0.f, 0.f, 0.f};
+    if (uni) {
+      // nothing to evaluate: dFx of row a-2 is +0 (one x flux in every lane), Gy - Gy_lo is +0 (one y flux either side of row a-2)
+      dFx = C4{0.f, 0.f, 0.f, 0.f}; Gy_lo = C4{0.f, 0.f, 0.f, 0.f};
+      stale = true;
+    } else {
+    if (UEX && stale) {   // the stretch has ended: rows a-4 .. a-1 still hold its state; what the last (skipped) trip would have left behind
+      P4 lo_u, hi_u;
+      predict_from(A, q2, q2, q2, 1, half, lo_u, hi_u);                 // row a-2 along y, between two rows equal to itself
+      yhi_prev = hi_u;
+      Gy_lo = face_from(A, R.get(s1, 0), hi_u, w2, lo_u, 1);            // the y face between rows a-3 and a-2 (row a-3 predicts the same states)
+      dFx = C4{0.f, 0.f, 0.f, 0.f};
+      stale = false;
+    }
     if (row_x) {
       predict_from(A, qc, pl, pr, 0, half, xlo, xhi);
     }
     predict_from(A, qc, pd, pu, 1, half, ylo, yhi);
     // ---- x-face fluxes of row p: low face from the lane below, high face = the low face of the lane above
-    C4 dFx_p{0.f, 0.f, 0.f, 0.f};
     if (row_x) {
       P4 xhi_l;
       xhi_l.r = __shfl_up(xhi.r, 1, 64); xhi_l.u = __shfl_up(xhi.u, 1, 64); xhi_l.v = __shfl_up(xhi.v, 1, 64); xhi_l.p = __shfl_up(xhi.p, 1, 64);
@@ -737,10 +776,9 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
       dFx_p = C4{__shfl_down(Fx.r, 1, 64) - Fx.r, __shfl_down(Fx.mx, 1, 64) - Fx.mx, __shfl_down(Fx.my, 1, 64) - Fx.my, __shfl_down(Fx.E, 1, 64) - Fx.E};
     }
     // ---- y-face flux between rows a-2 (w2) and a-1 (w3)
-    C4 Gy{0.f, 0.f, 0.f, 0.f};
     if (a > j0) Gy = face_from(A, w2, yhi_prev, w3, ylo, 1);
+    }
     // ---- complete row j = a-2 (centre w2): update + separable 4th-order diffusion + repairs, :1096-1175
-    const int j = a - 2;
     if (j >= j0 && j < j1) {   // wave-uniform
       const C4 Uc = w2.c;
       C4 Un = Uc;
@@ -947,6 +985,7 @@ struct tauh2 {
   unsigned *rmm;            // min / max keys
   int *crow = nullptr;      // chunk schedule of the march (h2_schedule)
   int crow_n = 0;
+  bool uniform_exits = true;   // TAUH2_UNIFORM_EXITS=0 at tauh2_create: every trip of the march evaluates its predictors and faces (same bits)
 };
 
 namespace {
@@ -1018,6 +1057,7 @@ extern "C" int tauh2_create(tauh2_t **out, const tauh2_params *p, int device, vo
   if (!h) return tau::fail("tauh2_create: out of host memory");
   tau::HandleGuard<tauh2> guard{h, tauh2_destroy};
   h->p = *p; h->device = device; h->cur = 0; h->maxs_valid = false;
+  if (const char *e = getenv("TAUH2_UNIFORM_EXITS")) h->uniform_exits = atoi(e) != 0;
   h->own_stream = (stream == nullptr);
   if (h->own_stream) TAU_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   else h->stream = (hipStream_t)stream;
@@ -1110,6 +1150,8 @@ static int h2_launch_step(tauh2 *h, float dt_explicit) {
   h2d::Args A = h->base;
   for (int f = 0; f < 4; f++) { A.in[f] = h->buf[h->cur][f]; A.out[f] = h->buf[h->cur ^ 1][f]; }
   A.slot = h->slot; A.dt_explicit = dt_explicit;
+  const bool uexits = h->uniform_exits;
+  A.uniform_exits = uexits ? 1 : 0;
   if (!h->maxs_valid) { // first step after init / upload: one reduction pass
     TAU_HIP(hipMemsetAsync(h->st->maxs_bits, 0, sizeof(h->st->maxs_bits), h->stream));
     hipLaunchKernelGGL(h2d::k_maxspeed, dim3(2048), dim3(256), 0, h->stream, A);
@@ -1138,9 +1180,10 @@ static int h2_launch_step(tauh2 *h, float dt_explicit) {
     const int *crow = nullptr;
     if (lds_win && rows_env < 1 && h2_schedule(h, &nchunks, &crow)) return 1;
     const unsigned nwork = (unsigned)(nstrips * nchunks);
-    if (lds_win && wpb == 1) hipLaunchKernelGGL(h2d::k_march_lds<1>, dim3(nwork), dim3(64), 0, h->stream, A, rows, nstrips, nchunks, crow);
-    else if (lds_win && wpb == 2) hipLaunchKernelGGL(h2d::k_march_lds<2>, dim3((nwork + 1) / 2), dim3(128), 0, h->stream, A, rows, nstrips, nchunks, crow);
-    else if (lds_win) hipLaunchKernelGGL(h2d::k_march_lds<4>, dim3((nwork + 3) / 4), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    if (lds_win && wpb == 1 && uexits) hipLaunchKernelGGL((h2d::k_march_lds<1, true>), dim3(nwork), dim3(64), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    else if (lds_win && wpb == 1) hipLaunchKernelGGL((h2d::k_march_lds<1, false>), dim3(nwork), dim3(64), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    else if (lds_win && wpb == 2) hipLaunchKernelGGL((h2d::k_march_lds<2, false>), dim3((nwork + 1) / 2), dim3(128), 0, h->stream, A, rows, nstrips, nchunks, crow);
+    else if (lds_win) hipLaunchKernelGGL((h2d::k_march_lds<4, false>), dim3((nwork + 3) / 4), dim3(256), 0, h->stream, A, rows, nstrips, nchunks, crow);
     else hipLaunchKernelGGL(h2d::k_march, dim3((unsigned)((nstrips * nchunks + 3) / 4)), dim3(256), 0, h->stream, A, rows, nstrips, nchunks);
   } else {
     hipLaunchKernelGGL(h2d::k_step, dim3((unsigned)(A.ntx * A.nty)), dim3(h2d::NT), 0, h->stream, A);

@@ -208,3 +208,28 @@ def test_neighbor_lookups_on_the_reference_field(eng):
     want = [1.0, infl_mx, 1.0, 7.0, -3.0, 1.0, infl_mx, -3.0, 1.0]
     np.testing.assert_allclose(got, want, rtol=2e-7, atol=0)   # fp32 engine: the reference's 1e-12 at double becomes 1 ulp
     e.close()
+
+
+@pytest.mark.parametrize("W,H,steps", [(2100, 1100, 30), (4096, 2048, 60), (1500, 1500, 200)])
+def test_uniform_row_exits_change_no_bit(eng, tmp_path, W, H, steps):
+    """k_march_lds skips the predictors and the faces of a trip whose five-row window holds one state in all 64 lanes (the free stream
+    ahead of and beside the bow shock: almost every trip of the BASELINE input's first hundreds of steps) and recomputes what the
+    skipped trips would have handed on when the stretch ends.  TAUH2_UNIFORM_EXITS=0 evaluates everything: every field of every cell
+    and the clock must be byte-identical, on grids that run the march by default, early (mostly free stream) and late (shock layer
+    grown) in a run."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import fluid_sims_amd as f, numpy as np\n"
+            "h = f.Hypersonic2D(%d, %d); h.init(); t = h.step(%d)\n"
+            "st = h.download(); np.savez(sys.argv[1], *st, t=np.float64(t if t is not None else 0.0))\n" % (root, W, H, steps))
+    outs = []
+    for ex in ("1", "0"):
+        out = tmp_path / f"x{ex}.npz"
+        r = subprocess.run([sys.executable, "-c", code, str(out)], capture_output=True, text=True, env=dict(os.environ, TAUH2_UNIFORM_EXITS=ex))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(np.load(out))
+    a, b = outs
+    assert float(a["t"]) == float(b["t"])
+    for k in ("arr_0", "arr_1", "arr_2", "arr_3"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    assert float(np.abs(a["arr_1"] - a["arr_1"][0, -1]).max()) > 1.0      # a shock layer exists: not two runs of pure free stream
