@@ -1348,8 +1348,12 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   }
 }
 
+// Round 6: 8 waves per SIMD = FOUR workgroups per CU (4 x 37.9 KB of LDS fits the 160 KB).  The kernel needed 67 VGPRs under the cap of
+// 80 (six waves, three workgroups); asked for 64 it takes 63 without a spill, and the fourth resident workgroup is worth 4 % with the
+// uniform-region exits on or off (same box, interleaved, twice: headline 33.5 -> 34.8-35.0, late state 29.5 -> 30.4-30.8, every face
+// evaluated 25.0-25.7 -> 26.3-26.9 Gcell/s) — a short-lived workgroup spends most of its life waiting for its staging loads.
 #ifndef TAU3D_XY_WAVES
-#define TAU3D_XY_WAVES 6
+#define TAU3D_XY_WAVES 8
 #endif
 // The two kernels of the split step are compiled in a translation unit of their own (this file again with -DTAU3D_SPLIT_TU,
 // Makefile: build/h3d_split.o) under `-mllvm -amdgpu-sched-strategy=max-ilp`: the ILP-first list scheduler is worth 1.5-2 % on
