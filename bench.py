@@ -152,9 +152,17 @@ def input_variants(f, torch, dev, n, steps=20):
                      "max_abs_primitive": round(float(max(fr[0], fr[1])), 1) if max(fr[0], fr[1]) < 3e38 else "inf",
                      "state_sane": bool(fr[2] or rcp) and math.isfinite(float(c.maxs)) and float(max(fr[0], fr[1])) <= 6e4,
                      "t": c.t, "gain": round(c.gain, 4),
-                     "uniform_exits": bool(ut[2]), "uniform_tile_fraction": round(ut[0] / max(ut[1], 1), 4)}
+                     "uniform_exits": bool(ut[2]), "uniform_tile_fraction": round(ut[0] / max(ut[1], 1), 4),
+                     "tile_list": _tile_list(e)}
         e.close()
     return out
+
+
+def _tile_list(e):
+    """predicted-uniform tile list (include/taueng.h: tau3d_tile_list_stats): the share of k_flux_xy's tiles the step after the last
+    timed one would have launched — the others were flagged uniform from the flags of the step before, without being read"""
+    mode, listed, tiles, _, _ = e.tile_list_stats()
+    return {"mode": mode, "listed_tile_fraction": round(listed / max(tiles, 1), 4) if mode == 1 and listed >= 0 else None}
 
 
 def _event_timed(torch, stream, enqueue, sync):
@@ -585,6 +593,7 @@ def main():
     clk = get_clock()
     frange = h.field_range()
     utiles = h.uniform_tiles()
+    tlist = _tile_list(h)
 
     # ---- the ring run proves itself: slab == single domain, byte for byte (SURVEY 8e's parity oracle, on the hardware and with
     # the transport that was just timed).  The grid fits one GPU, so EVERY rank recomputes warmup + steps single-domain steps from
@@ -711,7 +720,10 @@ def main():
                           # uniform-region exits (include/taueng.h): the share of k_flux_xy's tiles (rank 0's planes) whose cells all held
                           # the undisturbed inflow state in the last timed step — their x/y divergence is exactly zero and was not
                           # computed; other_inputs.headline_uniform_exits_off is the same input with every face evaluated
-                          "uniform_exits": bool(utiles[2]), "uniform_tile_fraction": round(utiles[0] / max(utiles[1], 1), 4)},
+                          "uniform_exits": bool(utiles[2]), "uniform_tile_fraction": round(utiles[0] / max(utiles[1], 1), 4),
+                          # ... and of the tiles that ARE uniform, most are known to be from the flags of the step before
+                          # (tau3d_tile_list_stats): k_flux_xy is launched over the list of the others.  Single-domain handles only
+                          "tile_list": tlist},
                "roofline": roof}
         if out_valu:
             out["roofline_valu"] = out_valu

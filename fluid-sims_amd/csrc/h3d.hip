@@ -108,6 +108,20 @@ struct Args {
                              // the tile and of its x/y halo holds the same state, the tile's x/y divergence is exactly zero and was NOT stored;
                              // read by k_update_z in place of the divergence.  null: exits off (TAU3D_UNIFORM_EXITS=0)
   int dz_ntx, dz_nty;        // its tile grid (k_flux_xy's tiles: XT x YT)
+  // Predicted-uniform tiles (round 6): k_flux_xy records, per tile, whether it found tile + halo uniform and with which encoded state
+  // (uflag_w / uref_w: this step's, written; [tile] and [tile][8]); after k_update_z, k_tile_predict reads them (uflag_r / uref_r) and
+  // decides which tiles of the NEXT state can only be uniform again — every tile around them, seven planes deep, held the same one
+  // state — sets their dzero flag itself and lists the others (ulist, ucount): the next k_flux_xy is launched over the LIST.
+  unsigned *uflag_w; float *uref_w;
+  const unsigned *uflag_r; const float *uref_r;
+  unsigned *pflag; float *pref;           // k_tile_predict: the NEXT step's flags / states, written where it predicts (pred_commit: and dzero)
+  unsigned *ulist; unsigned *ucount;      // the list and its length (k_tile_predict appends; k_flux_xy_list reads)
+  unsigned *ucount_other;                 // the length word of the step before: k_tile_predict zeroes it for the step after
+  unsigned *ucount_host;                  // k_flux_xy_list: the length again, in mapped host memory (the host sizes later launches by it)
+  unsigned list_grid; int list_fast;      // k_flux_xy_list_rest: the main launch's grid and weight form
+  int z_pred;                             // k_update_z: bit 1 of a dzero word is this step's prediction (k_tile_predict ran before it) — 0: no,
+                                          // 1: report the new state of predicted tiles (pref), 2: and skip what a run of them repeats
+  int pred_commit;                        // 0: the verifying mode — flags into a scratch pair, the next k_flux_xy still runs every tile
   // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
   const float *in0;
   float *out0;
@@ -702,7 +716,7 @@ using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::
 
 // fetch_cell through a scalar plane base.  epl: field 0 of the encoded state at plane zh; fs4: bytes between fields; spl:
 // the solid mask at plane zh
-// test: eq = the six ENCODED values equal eqref[0..5] (an interior cell; ghost columns never do)
+// test: eq = the six ENCODED values are eqref[0..5] bit for bit (an interior cell; ghost columns never are)
 __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
                                              int zg, float (&q)[6], bool &sol, bool test, const float (&eqref)[6], bool &eq) {
   Prim p;
@@ -725,7 +739,13 @@ __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GC
 #pragma unroll
     for (int m = 0; m < 6; m++) e[m] = gld(qpl + m * fs4, vo);
     sol = spl[vo >> 2] != 0;
-    if (test) eq = (e[0] == eqref[0]) & (e[1] == eqref[1]) & (e[2] == eqref[2]) & (e[3] == eqref[3]) & (e[4] == eqref[4]) & (e[5] == eqref[5]);
+    // BIT patterns (round 6): +0 and -0 compare equal as numbers, and a tile at the edge of the disturbance can hold both in v or w.
+    // The exit itself survives that (a flagged tile's +0 divergence absorbs the sign), the predictions built on the flags do not:
+    // k_update_z stores one new state for every cell of a run of predicted planes.  (Also cheaper: xor / or at full rate, one compare.)
+    if (test) {
+      auto x = [&](int m) { return __float_as_uint(e[m]) ^ __float_as_uint(eqref[m]); };
+      eq = ((x(0) | x(1) | x(2)) | (x(3) | x(4) | x(5))) == 0u;
+    }
 #pragma unroll
     for (int m = 0; m < 6; m++) p.q[m] = decode_field_w(uref, m, e[m]);
   }
@@ -1183,12 +1203,19 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
 #pragma unroll
     for (int w = 0; w < XNW; w++) all &= S.wuni[w];
     if (all) {      // (the same word for every thread: the workgroup leaves together)
-      if (tid == 0) A.dzero[tile_i] = 1u;
+      if (tid == 0) {
+        A.dzero[tile_i] = 1u;
+        if (A.uflag_w != nullptr) {
+          A.uflag_w[tile_i] = 1u;
+#pragma unroll
+          for (int m = 0; m < 6; m++) A.uref_w[tile_i * 8 + m] = uref6[m];
+        }
+      }
       C.in_xy = false;
       return;
     }
   }
-  if (A.dzero != nullptr && tid == 0) A.dzero[tile_i] = 0u;
+  if (A.dzero != nullptr && tid == 0) { A.dzero[tile_i] = 0u; if (A.uflag_w != nullptr) A.uflag_w[tile_i] = 0u; }
   // ---- edge states of the own cell; ring cells
   // One variable at a time.  Left alone, hipcc runs the six variables breadth-first (all first differences, then all
   // smoothness indicators, ...) and needs ~140 VGPRs for it; occupancy is worth more than that ILP here.  The empty asm
@@ -1322,10 +1349,16 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   }
   C.in_xy = in_xy; C.own_solid = own_solid; C.x = x; C.yw = yw; C.z = z; C.lc = lc;
 }
+template <bool FAST> __device__ __forceinline__ void flux_xy_tile(const Args &A, XyLds &S, unsigned b);
 template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A, XyLds &S, unsigned bid) {
+  flux_xy_tile<FAST>(A, S, tau::xcd_swizzle(bid, (unsigned)(A.ntx * A.nty * A.nzc)));
+}
+// list mode: work item i of *A.ucount is tile A.ulist[i] (a whole-slab launch: the tile index IS (plane, tile row, tile column))
+template <bool FAST> __device__ __forceinline__ void flux_xy_listed(const Args &A, XyLds &S, unsigned i) {
+  flux_xy_tile<FAST>(A, S, A.ulist[i]);
+}
+template <bool FAST> __device__ __forceinline__ void flux_xy_tile(const Args &A, XyLds &S, unsigned b) {
   XyCell C;
-  const unsigned nb = (unsigned)(A.ntx * A.nty * A.nzc);
-  unsigned b = tau::xcd_swizzle(bid, nb);
   const int bx = (int)(b % (unsigned)A.ntx); b /= (unsigned)A.ntx;
   const int by = (int)(b % (unsigned)A.nty);
   const int bz = (int)(b / (unsigned)A.nty);
@@ -1333,7 +1366,10 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
   // one scalar load, one scalar branch: ~90 % of the tiles of the 512^3 sphere case hold no solid cell
   const unsigned tflag = A.xyflag == nullptr ? 1u : A.xyflag[((size_t)z * A.nty + by) * A.ntx + bx];
   if (tflag == 2u) {         // the tile is inside the body: no cell of it takes a divergence (4 % of the tiles of the 512^3 sphere case)
-    if (A.dzero != nullptr && threadIdx.x == 0) A.dzero[((size_t)z * A.nty + by) * A.ntx + bx] = 0u;
+    if (A.dzero != nullptr && threadIdx.x == 0) {
+      A.dzero[((size_t)z * A.nty + by) * A.ntx + bx] = 0u;
+      if (A.uflag_w != nullptr) A.uflag_w[((size_t)z * A.nty + by) * A.ntx + bx] = 0u;
+    }
     return;
   }
   const bool any_solid = tflag != 0u;
@@ -1371,7 +1407,35 @@ template <bool FAST> __device__ __forceinline__ void flux_xy_body(const Args &A,
 // grid, then the strided kernel), never correctness.  STRIDE = false is the launch of rounds 2-3, one tile per workgroup.
 using XyShared = XyLds;
 constexpr int XYNT = XNT;
-template <bool FAST> __device__ __forceinline__ void xy_body(const Args &A, XyShared &S, unsigned b) { flux_xy_body<FAST>(A, S, b); }
+template <bool FAST> __device__ __forceinline__ void xy_body(const Args &A, XyShared &S, unsigned b) {
+  flux_xy_body<FAST>(A, S, b);
+}
+// The launch over the list of tiles k_tile_predict could not clear.  The host sizes the grid from the length of an earlier list plus
+// a margin (split_xy); one tile per workgroup and NO loop — a loop over tiles costs this kernel its allocation (hoisted index
+// arithmetic: 64 VGPRs + 176 B of scratch against 63 + 0).  What a short grid leaves, and the whole list when the device's field
+// range says the other weight form is due, is k_flux_xy_list_rest's: a small resident grid that strides, both bodies behind a
+// branch, empty on every step of a sane run.
+template <bool FAST> __global__ __launch_bounds__(XYNT, TAU3D_XY_WAVES) void k_flux_xy_list(const Args A) {
+  __shared__ XyShared S;
+  const unsigned n = *A.ucount;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *(volatile unsigned *)A.ucount_host = n;
+  if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;
+  // (k_tile_predict appends in roughly ascending tile order: an XCD takes a contiguous eighth of the list, neighbours share its L2)
+  // (the swizzle over the part of the grid that has work: over a grid with a margin of idle workgroups it would hand the first XCDs
+  // all of the list and the last ones none — measured with a grid of twice the list: 1.27 -> 2.36 ms)
+  const unsigned i = tau::xcd_swizzle(blockIdx.x, n < gridDim.x ? n : gridDim.x);
+  if (i < n) flux_xy_listed<FAST>(A, S, i);
+}
+__global__ __launch_bounds__(XYNT, TAU3D_XY_WAVES) void k_flux_xy_list_rest(const Args A) {
+  __shared__ XyShared S;
+  const unsigned n = *A.ucount;
+  const bool fast = fast_form(A.clk->fmax_in, A.in_fmax);
+  const unsigned first = (fast == (A.list_fast != 0)) ? A.list_grid : 0u;   // the main launch ran this form: it did [0, list_grid)
+  for (unsigned i = first + blockIdx.x; i < n; i += gridDim.x) {
+    if (fast) flux_xy_listed<true>(A, S, i); else flux_xy_listed<false>(A, S, i);
+    __syncthreads();
+  }
+}
 template <bool FAST, bool STRIDE> __global__ __launch_bounds__(XYNT, TAU3D_XY_WAVES) void k_flux_xy(const Args A) {
   __shared__ XyShared S;
   if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;
@@ -1413,7 +1477,15 @@ void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast
   }
 #endif
 }
+void launch_flux_xy_list(unsigned nwg, hipStream_t s, const Args &A0, bool expect_fast) {
+  Args A = A0;
+  A.list_grid = nwg; A.list_fast = expect_fast ? 1 : 0;
+  if (expect_fast) hipLaunchKernelGGL((k_flux_xy_list<true>), dim3(nwg), dim3(XYNT), 0, s, A);
+  else hipLaunchKernelGGL((k_flux_xy_list<false>), dim3(nwg), dim3(XYNT), 0, s, A);
+  hipLaunchKernelGGL(k_flux_xy_list_rest, dim3(768), dim3(XYNT), 0, s, A);
+}
 #else
+void launch_flux_xy_list(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // the same over k_tile_predict's list
 void launch_flux_xy(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // XNT threads per workgroup; both weight forms, see k_flux_xy
 void launch_flux_xy_fix(unsigned nwg, hipStream_t s, const Args &A);                 // the repeat of a launch that ran ahead of the clock
 #endif
@@ -1527,13 +1599,19 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
 // (ring of five, no barrier: a thread only ever reads what it wrote): in registers it costs 30 VGPRs and 24 moves
 // per plane to slide, and pushed the kernel to 148 VGPRs / three waves.
 constexpr int ZT_X = 64, ZT_Y = 4, ZNT = ZT_X * ZT_Y;
+static_assert(ZT_X == 2 * XT && YT % ZT_Y == 0, "k_update_z's prediction mask: a wave spans two k_flux_xy tiles of one tile row");
 typedef float ZRing[5][6][ZNT];
 template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring, unsigned bid) {
   const int tid = threadIdx.x;
   const int lx = tid & (ZT_X - 1), ly = tid >> 6;
   const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
   const unsigned nb = (unsigned)(nbx * nby * A.nzc);
-  unsigned b = tau::xcd_swizzle(bid, nb);
+  // Workgroup -> (column block, chunk).  Workgroup i runs on XCD i % 8, and the columns share nothing (no x / y halo here), so there
+  // is no locality to keep; what matters since the uniform-region exits is that an XCD's workgroups are a fair sample of the
+  // grid — with xcd_swizzle an XCD took one 64-plane layer, the ones through the bow shock all of the work (round 6, 512^3:
+  // 1.96 -> 1.87 ms, with the predictions' skipped planes 2.03 -> 1.84).  Each aligned group of eight is rotated by its number: an
+  // XCD sees every x block, tile row and chunk in turn.
+  unsigned b = bid < (nb & ~7u) ? ((bid & ~7u) | ((bid + (bid >> 3)) & 7u)) : bid;
   const int bx = (int)(b % (unsigned)nbx); b /= (unsigned)nbx;
   const int by = (int)(b % (unsigned)nby);
   const int bz = (int)(b / (unsigned)nby);
@@ -1550,8 +1628,10 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const float inv_dz = vreg(A.inv_dz);
   const float gain = A.clk->gain;
   const Gas G = gas_vgpr(A);
-  const float uref = vreg(A.u_ref);
-  const UpdK K = updk_vgpr(A, G);
+  // (u_ref and 1 / u_ref: three multiplies per plane each, as SGPR operands since round 6 — the prediction's kept state (memoE) needs
+  // their registers under the five-wave cap more than those six instructions need the full rate)
+  const float uref = A.u_ref;
+  const UpdK K = UpdK{G.gm1, G.inv_gm1, G.gamma, A.inv_u_ref, vlit(0x7fffffffu)};
 
   // Addressing (see gld / gst): scalar field bases at the chunk's first plane + one 32-bit byte offset per lane (with
   // 64-bit lane addresses: 61 half-rate adds per plane); the host keeps zchunk * plane bytes below 2^32.  The field
@@ -1649,19 +1729,51 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const GChar *const dB = (const GChar *)(A.d0 + (size_t)zc_lo * plane_n);                 // plane z, no halo
   unsigned vo = col4;
   // k_flux_xy's "divergence is zero, not stored" flag of this lane's tile (two tiles per wave at most), one word per plane
-  const unsigned *dzp = uex ? A.dzero + ((size_t)zc_lo * A.dz_nty + (size_t)(min(y, A.ny - 1) / YT)) * A.dz_ntx + (size_t)(min(x, A.nx - 1) / XT) : nullptr;
-  const size_t dz_plane = (size_t)A.dz_nty * A.dz_ntx;
+  // (bit 0: the divergence is zero; bit 1: k_tile_predict's prediction for this step, see below; a scalar base and a 32-bit lane offset)
+  unsigned dzo = (unsigned)(((size_t)zc_lo * A.dz_nty + (size_t)(min(y, A.ny - 1) / YT)) * A.dz_ntx + (size_t)(min(x, A.nx - 1) / XT)) << 2;
+  const unsigned dz_plane4 = (unsigned)(A.dz_nty * A.dz_ntx) << 2;
+  const GChar *const dzB = (const GChar *)A.dzero;
+  // Predicted-uniform tiles (k_tile_predict, which ran between k_flux_xy and this kernel): a plane of a predicted tile has one
+  // state S in every cell of its 3 x 3 tiles and in its own tile three planes either way, so this trip's window, divergence, face
+  // and update are the ones of the trip before if that was a predicted plane too: same operands, same bits.  The first such plane
+  // of a run takes the full path and keeps its result; the following ones store that (zskip: wave-uniform — both tiles a wave
+  // spans).  And where plane z+1 is predicted, plane z+4 — the one this trip would load, decode and put into the ring slot of plane
+  // z-1 — holds S like plane z-1 itself: the slot is right as it is (skipl).  A trip in the middle of a run is six stores.  The
+  // predictions of the chunk's planes for the wave's two tiles are read ONCE, lane l the words of plane zc_lo + l: the ballot is the
+  // chunk's mask (a flag load per trip is a dependent memory round trip per trip: measured, the skipped trips then cost what the
+  // full ones do).
+  const bool zpr = uex && A.z_pred != 0;
+  const bool zsk = uex && A.z_pred == 2;
+  float memoE[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  bool memo = false;
+  unsigned long long pmask = 0ull;
+  if (zsk) {
+    const int xa = bx * ZT_X, xb = xa + XT;              // the wave's two tiles start here (ZT_X = 2 XT)
+    const int zl = zc_lo + lx;                           // this lane's plane of the chunk
+    bool p = false;
+    if (zl < zc_hi && xb + XT <= A.nx && y < A.ny) {
+      const unsigned *const w = A.dzero + ((size_t)zl * A.dz_nty + (size_t)(y / YT)) * A.dz_ntx + (size_t)(xa / XT);
+      p = ((w[0] & w[1]) & 2u) != 0u;
+    }
+    pmask = __builtin_amdgcn_ballot_w64(p);
+  }
+  const bool pref_lane = ((x & (XT - 1)) == 0) && ((y & (YT - 1)) == 0);   // this lane's cell is its tile's first: it reports the new state of a predicted tile
 
   for (int z = zc_lo; z < zc_hi; z++) {
     const bool more = z + 1 < zc_hi;
     size_t f4 = fs4, d4 = ds4;
     asm volatile("" : "+s"(f4), "+s"(d4));
-    if (more) {
+    const bool wpred = (pmask & 1ull) != 0ull;          // this plane and (skipl) the next: predicted in both tiles of the wave
+    const bool skipl = more && (pmask & 2ull) != 0ull;
+    pmask >>= 1;
+    const bool zskip = wpred && memo;
+    const unsigned dzf = !uex ? 0u : zskip ? 3u : __float_as_uint(gld(dzB, dzo));
+    if (more && !skipl) {
 #pragma unroll
       for (int m = 0; m < 6; m++) Nx[m] = gld(qN + m * f4, vo);   // encoded: decoded where the plane enters the ring
       nsol = solN[vo >> 2] != 0 ? 1u : 0u;
     }
-    const unsigned dzf = uex ? *dzp : 0u;
+    if (skipl) nsol = 0u;
     const bool own_solid = (ws >> 2) & 1u;
     const bool wuni = uex && urun >= 4;   // (scalar) planes z-1 .. z+3 hold one state per lane
 
@@ -1674,8 +1786,21 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     // through (the reference's threads return at once there, :1063-1072), and the left state carried to the next face is
     // discarded there too — plane z+1 is in that face's stencil, so it takes the first-order / mirror form (solid_override).
     const bool face_dead = __builtin_amdgcn_ballot_w64(in_xy && ((ws >> 2) & 3u) != 3u) == 0ull;
+    if (zskip) {   // plane z+4 into the ring, nothing else: Lz, Fz_lo and the new state are the last trip's
+      if (skipl) urun++;
+      else if (more) {
+        bool eq = true;
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          const float nv = ZDEC(uref, m, Nx[m]);
+          eq = eq && (nv == rd(s4 * (24 * ZNT) + t4, m));
+          ring[s0][m][tid] = nv;
+        }
+        urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
+      }
+    } else
     if (face_dead) {
-      if (more) {
+      if (more && !skipl) {
 #pragma unroll
         for (int m = 0; m < 6; m++) ring[s0][m][tid] = ZDEC(uref, m, Nx[m]);
       }
@@ -1705,7 +1830,8 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
       // and takes over slot s0, which nothing reads any more; its six registers then carry the x/y divergence of THIS
       // plane, fetched behind the z face.  (Loaded right where the update needs it, every trip stalled a full HBM round
       // trip: 3.9 cycles per instruction against 3.1 for the mix.)
-      if (more) {
+      if (skipl) urun++;
+      else if (more) {
         bool eq = true;
 #pragma unroll
         for (int m = 0; m < 6; m++) {
@@ -1715,7 +1841,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         }
         if (uex) urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
       }
-      if (in_xy && !own_solid && dzf == 0u) {   // (a flagged tile's divergence is +0 in every cell and was not stored)
+      if (in_xy && !own_solid && (dzf & 1u) == 0u) {   // (a flagged tile's divergence is +0 in every cell and was not stored)
         const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
@@ -1743,14 +1869,28 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 
     if (in_xy) {
       float E[6];          // the cell's new encoded state
-      float own[6];        // the cell itself, back from the ring (carried from the reconstruction it cost six registers across the face)
+      if (zskip) {
 #pragma unroll
-      for (int m = 0; m < 6; m++) own[m] = rd(s1 * (24 * ZNT) + t4, m);
-      if (own_solid) { // :1063-1072 copy-through
-#pragma unroll
-        for (int m = 0; m < 6; m++) E[m] = *(const GFloat *)(inB + m * fs4 + vo);   // (rare path: plain addressing)
+        for (int m = 0; m < 6; m++) E[m] = memoE[m];
       } else {
-        update_cell(A, K, own, D, Fz_lo, Fz_hi, dt, inv_dz, gain, x, E, smax, fmx);
+        float own[6];        // the cell itself, back from the ring (carried from the reconstruction it cost six registers across the face)
+#pragma unroll
+        for (int m = 0; m < 6; m++) own[m] = rd(s1 * (24 * ZNT) + t4, m);
+        if (own_solid) { // :1063-1072 copy-through
+#pragma unroll
+          for (int m = 0; m < 6; m++) E[m] = *(const GFloat *)(inB + m * fs4 + vo);   // (rare path: plain addressing)
+        } else {
+          update_cell(A, K, own, D, Fz_lo, Fz_hi, dt, inv_dz, gain, x, E, smax, fmx);
+        }
+        if (wpred) {
+#pragma unroll
+          for (int m = 0; m < 6; m++) memoE[m] = E[m];
+        }
+      }
+      if (zpr && (dzf & 2u) != 0u && pref_lane) {   // the state k_flux_xy's test of this tile would take as its reference next step
+        float *const pr = A.pref + (size_t)(dzo >> 2) * 8;
+#pragma unroll
+        for (int m = 0; m < 6; m++) pr[m] = E[m];
       }
       {
         const unsigned vb = lane_off(vo);
@@ -1783,9 +1923,12 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         if (z >= A.nzl - HALO) wrap_plane(z - A.nzl + HALO);
       }
     }
+    if (!zskip) {
 #pragma unroll
-    for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
-    if (uex) dzp += dz_plane;
+      for (int m = 0; m < 6; m++) Fz_lo[m] = Fz_hi[m];
+    }
+    memo = wpred;
+    dzo += dz_plane4;
     vo += plane4;
     if (more) {   // plane z+4 has replaced plane z-1; the window slides
       ws = (ws >> 1) | (nsol << 5);
@@ -1878,6 +2021,91 @@ __global__ __launch_bounds__(256) void k_xy_flags(Args A, const uint8_t *solid, 
   // 0: no solid cell in reach; 1: some; 2: every cell of the tile is solid — solid cells are copied through by k_update_z and take
   // no divergence (the reference's threads return at once there, :1063-1072), so k_flux_xy has nothing to produce for the tile
   if (threadIdx.x == 0) flags[blockIdx.x] = !any ? 0u : (fluid_own ? 1u : 2u);
+}
+
+// Predicted-uniform tiles (round 6).  k_flux_xy's uniform-region exit makes a uniform tile cheap, not free: upstream of the shock
+// ~2/3 of the 512^3 case's 262 144 tiles stage their cells, find them equal and leave, and that launch is bound by the rate
+// workgroups are dispatched at (~1 ms for ~180 k of them).  Which tiles CAN only be uniform again is decidable from the flags of
+// the step before.  A cell's new state is a function of its own state, the states of the three cells either side of it along each
+// axis, the step's dt / inflow gain, and its position (sponge zones, ghost columns, solids).  If tile T's 3 x 3 neighbourhood in
+// its plane and T itself in the three planes either side were all flagged uniform WITH THE SAME STATE S at step n (a flag covers
+// the tile and its 3-cell x / y halo, and implies no solid cell in reach), then every cell of T and of its halo at step n + 1 had
+// nothing but S in its stencil, took +0 as its x/y divergence (the flag) and F - F as its z difference: one arithmetic on one set
+// of operands, so one encoded result — provided no such cell lies in a sponge zone (ghost columns and solids are excluded by the
+// flags themselves).  k_flux_xy's test of T at step n + 1 would pass, with the new state of T's first cell as the reference: this
+// kernel writes the flag the exit would (the "divergence is zero" word is 1 already and stays), k_update_z the state, and the next
+// k_flux_xy never sees T: every other tile goes on the list k_flux_xy_list runs over.  It is launched BETWEEN this step's
+// k_flux_xy and k_update_z, because the latter gains as much: in a predicted tile the new state is the same in every cell, so a
+// lane marching through a run of predicted planes computes it once (update_z_body: zskip).  One thread per tile.
+constexpr int PREDICT_NT = 1024;
+__global__ __launch_bounds__(PREDICT_NT) void k_tile_predict(const Args A) {
+  __shared__ unsigned s_cnt, s_base;
+  const int ntx = A.dz_ntx, nty = A.dz_nty;
+  const unsigned nt = (unsigned)(ntx * nty * A.nzl);
+  const unsigned t = blockIdx.x * (unsigned)PREDICT_NT + threadIdx.x;
+  if (threadIdx.x == 0) s_cnt = 0u;
+  __syncthreads();
+  if (t == 0u) *A.ucount_other = 0u;
+  const bool valid = t < nt;
+  bool ok = false;
+  if (valid) {
+    const int bx = (int)(t % (unsigned)ntx);
+    const int by = (int)((t / (unsigned)ntx) % (unsigned)nty);
+    const int z = (int)(t / (unsigned)(ntx * nty));
+    const int x_lo = bx * XT - HALO, x_hi = bx * XT + XT + HALO;   // the cells the flag of T covers: [x_lo, x_hi)
+    ok = bx >= 1 && bx <= ntx - 2 && A.xyflag != nullptr && A.xyflag[t] == 0u && A.uflag_r[t] != 0u &&
+         (A.sponge_n <= 0 || x_lo >= A.sponge_n) && (A.sponge_out_n <= 0 || x_hi <= A.nx - A.sponge_out_n);
+    if (ok) {
+      const uint4 *const rp = reinterpret_cast<const uint4 *>(A.uref_r);
+      const uint4 c0 = rp[(size_t)t * 2], c1 = rp[(size_t)t * 2 + 1];
+      auto same = [&](unsigned n) -> bool {
+        if (A.uflag_r[n] == 0u) return false;
+        const uint4 a0 = rp[(size_t)n * 2], a1 = rp[(size_t)n * 2 + 1];
+        return a0.x == c0.x && a0.y == c0.y && a0.z == c0.z && a0.w == c0.w && a1.x == c1.x && a1.y == c1.y;
+      };
+      const int ym = by == 0 ? nty - 1 : by - 1, yp = by == nty - 1 ? 0 : by + 1;
+      const unsigned pl = (unsigned)(z * nty) * (unsigned)ntx;
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++) {
+        ok = ok && same(pl + (unsigned)(ym * ntx + bx + dx)) && same(pl + (unsigned)(yp * ntx + bx + dx));
+        if (dx != 0) ok = ok && same(pl + (unsigned)(by * ntx + bx + dx));
+      }
+      for (int dz = -HALO; dz <= HALO && ok; dz++) {
+        if (dz == 0) continue;
+        int zz = z + dz;
+        if (zz < 0) zz += A.nzl; else if (zz >= A.nzl) zz -= A.nzl;   // (the list needs the whole periodic domain in the handle)
+        ok = same((unsigned)(zz * nty + by) * (unsigned)ntx + (unsigned)bx);
+      }
+    }
+    // (bit 0 of the tile's "divergence is zero" word is set already — the tile was flagged this step — and stays: the next k_flux_xy
+    //  does not come here.  The state of the new tile is k_update_z's to report: it has not been computed yet.)
+    A.pflag[t] = ok ? 1u : 0u;
+    A.dzero[t] = ok ? 3u : (A.dzero[t] & 1u);   // bit 1: k_update_z's copy of the prediction (a k_flux_xy that runs the tile writes 0 or 1)
+  }
+  // the others: one LDS atomic per wave, one global atomic per workgroup (same-address atomics cost ~12 ns each at the L2: a launch of
+  // 4096 waves would spend 50 us on them); a wave's tiles in ascending order
+  const unsigned long long need = __builtin_amdgcn_ballot_w64(valid && !ok);
+  const unsigned lane = __lane_id();
+  unsigned wbase = 0u;
+  if (need != 0ull) {
+    if (lane == (unsigned)__builtin_ctzll(need)) wbase = atomicAdd(&s_cnt, (unsigned)__builtin_popcountll(need));
+    wbase = (unsigned)__builtin_amdgcn_readlane((int)wbase, __builtin_ctzll(need));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) s_base = s_cnt != 0u ? atomicAdd(A.ucount, s_cnt) : 0u;
+  __syncthreads();
+  if (valid && !ok) A.ulist[s_base + wbase + (unsigned)__builtin_popcountll(need & ((1ull << lane) - 1ull))] = t;
+}
+// the verifying mode (TAU3D_TILE_LIST=2): the step after a prediction ran every tile all the same; each predicted tile must have
+// come out flagged, with the predicted state.  Counts the ones that did not.
+__global__ __launch_bounds__(256) void k_tile_predict_check(const unsigned *pflag, const float *pref, const unsigned *uflag, const float *uref,
+                                                            unsigned nt, unsigned *bad, unsigned *npred) {
+  const unsigned t = blockIdx.x * 256u + threadIdx.x;
+  if (t >= nt || pflag[t] == 0u) return;
+  atomicAdd(npred, 1u);
+  bool same = uflag[t] != 0u;
+  for (int m = 0; m < 6 && same; m++) same = __float_as_uint(pref[(size_t)t * 8 + m]) == __float_as_uint(uref[(size_t)t * 8 + m]);
+  if (!same) atomicAdd(bad, 1u);
 }
 
 struct InitVals { float f[6]; float s[6]; }; // encoded fluid / solid cell values (host-computed, libm)
@@ -2163,6 +2391,22 @@ struct tau3d {
   unsigned *dzero = nullptr;    // split step, uniform-region exits: k_flux_xy's "this tile's divergence is zero" flags (h3d::Args::dzero)
   bool debug_no_xy_fix = false; // TAU3D_DEBUG_NO_XY_FIX at tau3d_create (tests): tau3d_slab_xy_fix_async does nothing
   bool uniform_exits = true;    // TAU3D_UNIFORM_EXITS=0 (read at tau3d_create): every tile and every plane takes the full path
+  // predicted-uniform tiles (h3d::k_tile_predict): TAU3D_TILE_LIST (read at tau3d_create) 0: off, 1 (default): k_flux_xy runs over the list
+  // of the tiles that could not be predicted, 2: predictions are made and CHECKED against a k_flux_xy over every tile (tests)
+  int tile_list = 1;
+  bool z_skip = true;              // TAU3D_Z_SKIP=0 (read at tau3d_create): k_update_z does not use the predictions
+  unsigned list_margin_div = 8;   // k_flux_xy_list's grid: the last length seen + 1 / this of it + 512
+  unsigned *uflag[2] = {nullptr, nullptr};   // per tile: found (or predicted) uniform; [step parity]
+  float *uref[2] = {nullptr, nullptr};       // ... and with which encoded state (8 floats per tile, 6 used)
+  unsigned *vflag = nullptr; float *vref = nullptr;   // mode 2: the predictions
+  unsigned *ulist = nullptr;                 // tile indices
+  unsigned *ucount = nullptr;                // [0], [1]: list length by step parity; [2]: mode 2's mismatches; [3]: mode 2's predictions checked
+  unsigned *ucount_host = nullptr;           // mapped host word: the length the last k_flux_xy_list to run saw
+  hipEvent_t list_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded after each whole-domain step of a handle that keeps the list (see split_xy)
+  unsigned long list_step = 0;               // such steps issued
+  int upar = 0;                              // this step's parity
+  bool list_ok = false;                      // the list (mode 2: the prediction) made after the last step describes buf[list_cur] ...
+  int list_cur = 0;                          // ... and nothing wrote the state since
   h3d::DevClock *clk;
   int cur;                  // which side holds the current state
   bool end_pending;         // the controller update of the last tau3d_step_async step has not run yet
@@ -2277,6 +2521,11 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     TAU_HIP(hipMemsetAsync(h->buf[s][0], 0, 6 * h->field_stride * sizeof(float), h->stream));
     for (int f = 1; f < 6; f++) h->buf[s][f] = h->buf[s][0] + f * h->field_stride;
   }
+  h->debug_no_xy_fix = getenv("TAU3D_DEBUG_NO_XY_FIX") != nullptr;
+  if (const char *e = getenv("TAU3D_UNIFORM_EXITS")) h->uniform_exits = atoi(e) != 0;   // 0: the full path everywhere (same bits; the A/B of the exits)
+  if (const char *e = getenv("TAU3D_TILE_LIST")) { h->tile_list = atoi(e); if (h->tile_list < 0 || h->tile_list > 2) h->tile_list = 0; }
+  if (const char *e = getenv("TAU3D_Z_SKIP")) h->z_skip = atoi(e) != 0;
+  if (const char *e = getenv("TAU3D_TILE_LIST_MARGIN_DIV")) { const int v = atoi(e); if (v >= 1) h->list_margin_div = (unsigned)v; }
   if (h->split && split_buffers(h)) return 1;
   TAU_HIP(hipMalloc(&h->solid, h->field_n));
   TAU_HIP(hipMalloc(&h->clk, sizeof(h3d::DevClock)));
@@ -2284,8 +2533,6 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     for (int sd = 0; sd < 2; sd++) TAU_HIP(hipMalloc(&h->xbuf[k][sd], 6 * (size_t)h3d::HALO * h->plane_n * sizeof(float)));
   h->zchunk = 0; // 0 = pick per launch
   if (const char *e = getenv("TAU3D_ZCHUNK")) { int v = atoi(e); if (v >= 1) h->zchunk = v; }
-  h->debug_no_xy_fix = getenv("TAU3D_DEBUG_NO_XY_FIX") != nullptr;
-  if (const char *e = getenv("TAU3D_UNIFORM_EXITS")) h->uniform_exits = atoi(e) != 0;   // 0: the full path everywhere (same bits; the A/B of the exits)
   fill_consts(h);
   h->expect_fast = h->base.in_fmax <= 3.0e38f;   // (TAU3D_WENO_RCP=1 or an inflow state beyond the fast window: the reciprocal form for good)
   if (h->expect_fast) h->expect_fast = h3d::fast_form(0.f, h->base.in_fmax);
@@ -2315,6 +2562,10 @@ extern "C" void tau3d_destroy(tau3d_t *h) {
   hipFree(h->solid);
   hipFree(h->xyflag);
   hipFree(h->dzero);
+  hipFree(h->uflag[0]); hipFree(h->uflag[1]); hipFree(h->uref[0]); hipFree(h->uref[1]); hipFree(h->vflag); hipFree(h->vref);
+  hipFree(h->ulist); hipFree(h->ucount);
+  if (h->ucount_host) hipHostFree(h->ucount_host);
+  for (int i = 0; i < 4; i++) if (h->list_ev[i]) hipEventDestroy(h->list_ev[i]);
   hipFree(h->clk);
   hipFree(h->vis); hipFree(h->rgba); hipFree(h->scratch); hipFree(h->pidx);
   for (int k = 0; k < 2; k++)
@@ -2357,7 +2608,7 @@ static int measure_field(tau3d_t *h, int zl_lo, int zl_hi, bool fresh) {
 }
 
 extern "C" int tau3d_init(tau3d_t *h, int mode) {
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   TAU_HIP(hipSetDevice(h->device));
   const tau3d_params &P = h->p;
   if (build_solid(h)) return 1;
@@ -2383,7 +2634,7 @@ extern "C" int tau3d_init(tau3d_t *h, int mode) {
 }
 
 extern "C" int tau3d_upload_state(tau3d_t *h, const float *const host[6]) {
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   TAU_HIP(hipSetDevice(h->device));
   size_t n = h->plane_n * (size_t)h->nzl;
   for (int f = 0; f < 6; f++)
@@ -2413,7 +2664,7 @@ extern "C" int tau3d_download_solid(tau3d_t *h, uint8_t *host) {
   return 0;
 }
 static int planes_copy(tau3d_t *h, int zl_lo, int zl_hi, const float *const up[6], float *const down[6]) {
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   if (zl_lo < -h3d::HALO || zl_hi > h->nzl + h3d::HALO || zl_lo >= zl_hi)
     return tau::fail("tau3d planes: range [%d,%d) outside [-3,%d)", zl_lo, zl_hi, h->nzl + 3);
   TAU_HIP(hipSetDevice(h->device));
@@ -2473,14 +2724,36 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.xyflag = h->xyflag;
   A.dzero = h->uniform_exits ? h->dzero : nullptr;
   A.dz_ntx = (A.nx + h3d::XY_FX - 1) / h3d::XY_FX; A.dz_nty = (A.ny + h3d::XY_FY - 1) / h3d::XY_FY;
+  A.uflag_w = A.dzero ? h->uflag[h->upar] : nullptr; A.uref_w = h->uref[h->upar];   // (null unless the handle keeps a tile list)
+  A.uflag_r = h->uflag[h->upar]; A.uref_r = h->uref[h->upar];
+  const bool commit = h->tile_list == 1;
+  A.pflag = commit ? h->uflag[h->upar ^ 1] : h->vflag; A.pref = commit ? h->uref[h->upar ^ 1] : h->vref;
+  A.pred_commit = commit ? 1 : 0;
+  A.ulist = h->ulist;
+  A.ucount = nullptr; A.ucount_other = nullptr; A.z_pred = 0;   // (set by the launch that uses them)
+  A.ucount_host = h->ucount_host;
   A.wrap_halo = (h->wrap_now && lo == 0 && hi == h->nzl && lo2 >= hi2) ? 1 : 0;
 }
-static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s, bool fix = false) {   // x/y faces: one plane per workgroup
+static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s, bool fix = false, bool listed = false) {   // x/y faces: one plane per workgroup
   h3d::Args X;
   split_args(h, X, lo, hi, lo2, hi2);
   const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
   X.zchunk = 1; X.nzc1 = n1; X.nzc = n1 + n2;
   X.ntx = (X.nx + h3d::XY_WX - 1) / h3d::XY_WX; X.nty = (X.ny + h3d::XY_WY - 1) / h3d::XY_WY;
+  if (listed) {
+    // The grid: the length of the list as an earlier k_flux_xy_list reported it (a mapped host word), plus a margin — the
+    // disturbed region gains a few tiles a step.  A short grid costs time (k_flux_xy_list_rest takes what is left), never tiles; a
+    // long one costs the dispatch of empty workgroups.  For the length to be a recent one the host may not run far ahead of the
+    // device: a step waits for the step three before it (an event per step), which leaves the device two steps of queued work —
+    // the call stays asynchronous with a queue four steps deep.  No length seen yet: one workgroup per tile.
+    if (h->list_step >= 3) TAU_HIP(hipEventSynchronize(h->list_ev[(h->list_step - 3) & 3]));
+    const unsigned nt = (unsigned)(X.ntx * X.nty * X.nzc);
+    const unsigned seen = *(volatile unsigned *)h->ucount_host;
+    unsigned g = seen == 0xFFFFFFFFu ? nt : seen + seen / h->list_margin_div + 512u;
+    g = g < nt ? g : nt;
+    X.ucount = h->ucount + h->upar;
+    h3d::launch_flux_xy_list(g, s, X, h->expect_fast);
+  } else
   if (fix) h3d::launch_flux_xy_fix((unsigned)(X.ntx * X.nty * X.nzc), s, X);
   else h3d::launch_flux_xy((unsigned)(X.ntx * X.nty * X.nzc), s, X, h->expect_fast);
   TAU_LAUNCH_CHECK("k_flux_xy");
@@ -2488,9 +2761,10 @@ static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s,
 }
 // z faces + update: a wave marches a chunk of planes; ~4k workgroups (four rounds of the ~1k resident ones).
 // `pack`: the new boundary planes also go into the packed send buffers (Z-slab ring)
-static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipStream_t s) {
+static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipStream_t s, bool predicted = false) {
   h3d::Args Z;
   split_args(h, Z, lo, hi, lo2, hi2);
+  if (predicted) Z.z_pred = h->z_skip ? 2 : 1;   // k_tile_predict ran for this step
   const int n1 = hi - lo, n2 = lo2 < hi2 ? hi2 - lo2 : 0;
   const long tz = (long)((Z.nx + h3d::ZT_X - 1) / h3d::ZT_X) * ((Z.ny + h3d::ZT_Y - 1) / h3d::ZT_Y);
   // chunk length: ~4 k workgroups (16 k waves: three rounds of the ~5 k this kernel keeps resident, for load balance),
@@ -2526,9 +2800,34 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
     const bool tm = h->timing && h->n_ev < 4096;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s)); h->evm_set[h->n_ev] = false; }
-    if (split_xy(h, zl_lo, zl_hi, zl_lo2, zl_hi2, s)) return 1;
+    // predicted-uniform tiles: a whole-domain step of a handle that keeps the list (tile_list_buffers)
+    const bool can_list = h->uflag[0] != nullptr && h->uniform_exits && h->tile_list != 0 && zl_lo == 0 && zl_hi == h->nzl && !two;
+    const bool have_pred = can_list && h->list_ok && h->list_cur == h->cur;   // the last step's prediction describes this step's input
+    const bool use_list = have_pred && h->tile_list == 1;
+    h->list_ok = false;
+    if (can_list && !use_list) TAU_HIP(hipMemsetAsync(h->ucount, 0, 2 * sizeof(unsigned), s));
+    if (split_xy(h, zl_lo, zl_hi, zl_lo2, zl_hi2, s, false, use_list)) return 1;
+    if (have_pred && h->tile_list == 2) {
+      const unsigned nt = (unsigned)(((h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY)) * (unsigned)h->nzl;
+      hipLaunchKernelGGL(h3d::k_tile_predict_check, dim3((nt + 255u) / 256u), dim3(256), 0, s, (const unsigned *)h->vflag, (const float *)h->vref,
+                         (const unsigned *)h->uflag[h->upar], (const float *)h->uref[h->upar], nt, h->ucount + 2, h->ucount + 3);
+      TAU_LAUNCH_CHECK("k_tile_predict_check");
+    }
     if (tm) { TAU_HIP(hipEventRecord(h->evm[h->n_ev], s)); h->evm_set[h->n_ev] = true; }
-    if (split_z(h, zl_lo, zl_hi, zl_lo2, zl_hi2, false, s)) return 1;
+    if (can_list) {
+      h3d::Args P;
+      split_args(h, P, zl_lo, zl_hi, zl_lo2, zl_hi2);
+      P.ucount = h->ucount + (h->upar ^ 1); P.ucount_other = h->ucount + h->upar;
+      const unsigned nt = (unsigned)(P.dz_ntx * P.dz_nty) * (unsigned)h->nzl;
+      hipLaunchKernelGGL(h3d::k_tile_predict, dim3((nt + h3d::PREDICT_NT - 1) / h3d::PREDICT_NT), dim3(h3d::PREDICT_NT), 0, s, P);
+      TAU_LAUNCH_CHECK("k_tile_predict");
+    }
+    if (split_z(h, zl_lo, zl_hi, zl_lo2, zl_hi2, false, s, can_list)) return 1;
+    if (can_list) {
+      h->upar ^= 1; h->list_ok = true; h->list_cur = h->cur ^ 1;
+      TAU_HIP(hipEventRecord(h->list_ev[h->list_step & 3], s));
+      h->list_step++;
+    }
     if (tm) {
       TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
       h->n_ev++;
@@ -2679,7 +2978,7 @@ extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
 extern "C" int tau3d_slab_xy_async(tau3d_t *h) {
   if (!h) return tau::fail("tau3d_slab_xy: null handle");
   TAU_HIP(hipSetDevice(h->device));
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   if (!h->split) return 0;                               // fused kernel: everything happens in tau3d_slab_z_async
   const bool tm = h->timing && h->n_ev < 4096;
   if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream)); h->evm_set[h->n_ev] = false; }
@@ -2718,7 +3017,7 @@ extern "C" int tau3d_slab_z_async(tau3d_t *h) {
   return 0;
 }
 extern "C" int tau3d_slab_end_async(tau3d_t *h) {
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   h->cur ^= 1;             // std::swap x6, :1706-1711
   h->end_pending = true;   // the controller update (after the caller's all-reduce) rides on the next tau3d_slab_begin_async
   return 0;
@@ -2731,7 +3030,7 @@ extern "C" int tau3d_clock_begin_async(tau3d_t *h) {
   return 0;
 }
 extern "C" int tau3d_clock_end_async(tau3d_t *h) {
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   hipLaunchKernelGGL(h3d::k_clock_end, dim3(1), dim3(1), 0, h->stream, h->clk);
   TAU_LAUNCH_CHECK("k_clock_end");
   h->cur ^= 1; // std::swap x6, :1706-1711
@@ -2810,7 +3109,7 @@ extern "C" int tau3d_halo_buf_ptr(tau3d_t *h, int kind, int side, float **p, siz
   return 0;
 }
 extern "C" int tau3d_state_written(tau3d_t *h) {
-  h->halo_fresh = false;
+  h->halo_fresh = false; h->list_ok = false;
   TAU_HIP(hipSetDevice(h->device));
   if (h->xyflag) {   // tau3d_state_ptrs also hands out the solid mask: k_flux_xy's static tile flags are derived from it
     const int ntx = (h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX, nty = (h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY;
@@ -2849,10 +3148,29 @@ extern "C" int tau3d_uniform_tiles(tau3d_t *h, long *uniform, long *tiles, int *
     hipError_t e = hipMemcpyAsync(host, h->dzero, n * sizeof(unsigned), hipMemcpyDeviceToHost, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     if (e != hipSuccess) { free(host); return tau::fail("tau3d_uniform_tiles: %s", hipGetErrorString(e)); }
-    for (size_t i = 0; i < n; i++) u += host[i] == 1u;
+    for (size_t i = 0; i < n; i++) u += host[i] & 1u;
     free(host);
   }
   if (uniform) *uniform = u;
+  return 0;
+}
+// Predicted-uniform tiles: mode (0: the handle keeps no list — switched off, a slab, ragged tiles —, 1: k_flux_xy runs over the list,
+// 2: verifying), the length of the list the last whole-domain step made (the tiles the NEXT k_flux_xy runs), the tile count, and
+// in mode 2 the predictions checked so far and how many of them k_flux_xy did not confirm (must be 0).  Waits for the stream.
+extern "C" int tau3d_tile_list_stats(tau3d_t *h, int *mode, long *listed, long *tiles, long *checked, long *mismatches) {
+  if (!h) return tau::fail("tau3d_tile_list_stats: null handle");
+  TAU_HIP(hipSetDevice(h->device));
+  const bool on = h->split && h->uflag[0] != nullptr;
+  if (mode) *mode = on ? h->tile_list : 0;
+  if (tiles) *tiles = (long)((h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY) * (long)h->nzl;
+  unsigned c[4] = {0u, 0u, 0u, 0u};
+  if (on) {
+    TAU_HIP(hipMemcpyAsync(c, h->ucount, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    TAU_HIP(hipStreamSynchronize(h->stream));
+  }
+  if (listed) *listed = on && h->list_ok ? (long)c[h->upar] : -1;
+  if (checked) *checked = (long)c[3];
+  if (mismatches) *mismatches = (long)c[2];
   return 0;
 }
 extern "C" int tau3d_slab_info(tau3d_t *h, int *z0, int *nzl, int *nz, int *device, void **stream) {
@@ -2877,6 +3195,27 @@ static int split_buffers(tau3d *h) {   // what the kernel pair needs beside the 
     const size_t ntiles = (size_t)((p->nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((p->ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;
     TAU_HIP(hipMalloc(&h->dzero, ntiles * sizeof(unsigned)));
     TAU_HIP(hipMemsetAsync(h->dzero, 0, ntiles * sizeof(unsigned), h->stream));
+  }
+  // the tile list: a whole periodic domain in the handle, whole tiles, room for a 3 x 3 x 7 neighbourhood
+  if (!h->uflag[0] && h->tile_list && h->uniform_exits && h->nzl == p->nz && p->nx % h3d::XY_FX == 0 && p->ny % h3d::XY_FY == 0 &&
+      p->nx / h3d::XY_FX >= 3 && p->ny / h3d::XY_FY >= 3 && h->nzl >= 2 * h3d::HALO + 1) {
+    const size_t ntiles = (size_t)(p->nx / h3d::XY_FX) * (p->ny / h3d::XY_FY) * (size_t)h->nzl;
+    for (int i = 0; i < 2; i++) {
+      TAU_HIP(hipMalloc(&h->uflag[i], ntiles * sizeof(unsigned)));
+      TAU_HIP(hipMalloc(&h->uref[i], ntiles * 8 * sizeof(float)));
+      TAU_HIP(hipMemsetAsync(h->uflag[i], 0, ntiles * sizeof(unsigned), h->stream));
+      TAU_HIP(hipMemsetAsync(h->uref[i], 0, ntiles * 8 * sizeof(float), h->stream));
+    }
+    if (h->tile_list == 2) {
+      TAU_HIP(hipMalloc(&h->vflag, ntiles * sizeof(unsigned)));
+      TAU_HIP(hipMalloc(&h->vref, ntiles * 8 * sizeof(float)));
+    }
+    TAU_HIP(hipMalloc(&h->ulist, ntiles * sizeof(unsigned)));
+    TAU_HIP(hipMalloc(&h->ucount, 4 * sizeof(unsigned)));
+    TAU_HIP(hipMemsetAsync(h->ucount, 0, 4 * sizeof(unsigned), h->stream));
+    TAU_HIP(hipHostMalloc((void **)&h->ucount_host, 64, hipHostMallocMapped));
+    *h->ucount_host = 0xFFFFFFFFu;
+    for (int i = 0; i < 4; i++) TAU_HIP(hipEventCreateWithFlags(&h->list_ev[i], hipEventDisableTiming));
   }
   if (!h->xyflag && !(getenv("TAU3D_XY_NOFLAGS") && atoi(getenv("TAU3D_XY_NOFLAGS")))) {
     const size_t ntiles = (size_t)((p->nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((p->ny + h3d::XY_FY - 1) / h3d::XY_FY) * (size_t)h->nzl;

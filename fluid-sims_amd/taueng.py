@@ -149,6 +149,7 @@ def load():
         "tau3d_palette_indices": ([vp, f32, vp, C.POINTER(C.c_float), C.POINTER(C.c_float)], i32),
         "tau3d_field_range": ([vp, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(i32)], i32),
         "tau3d_uniform_tiles": ([vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(i32)], i32),
+        "tau3d_tile_list_stats": ([vp, C.POINTER(i32), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)], i32),
         "tau3d_sync": ([vp], i32),
         "tau_device_count": ([C.POINTER(i32)], i32),
         "tau_guided_chunks": ([i32, i32, i32, i32, i32, C.POINTER(i32), i32, C.POINTER(i32)], i32),
@@ -538,6 +539,12 @@ class Tau3D:
         u, n, on = C.c_long(), C.c_long(), C.c_int()
         _ck(self._L.tau3d_uniform_tiles(self._h, C.byref(u), C.byref(n), C.byref(on)))
         return u.value, n.value, bool(on.value)
+
+    def tile_list_stats(self):
+        """(mode, listed, tiles, checked, mismatches) — tau3d_tile_list_stats: the predicted-uniform tile list of the split step"""
+        m, l, n, c, b = C.c_int(), C.c_long(), C.c_long(), C.c_long(), C.c_long()
+        _ck(self._L.tau3d_tile_list_stats(self._h, C.byref(m), C.byref(l), C.byref(n), C.byref(c), C.byref(b)))
+        return m.value, l.value, n.value, c.value, b.value
 
     def field_range(self):
         """(read_max, written_max, fast_form) — see tau3d_field_range"""

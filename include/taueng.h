@@ -174,6 +174,12 @@ int tau3d_field_range(tau3d_t *h, float *read_max, float *written_max, int *fast
  * reference has no counterpart — its k_step (tau_hypersonic_3d_cuda.cu:987-1359) evaluates every face everywhere.
  * TAU3D_UNIFORM_EXITS=0 at tau3d_create switches them off.  tau3d_uniform_tiles: the tiles the LAST step flagged / all tiles. */
 int tau3d_uniform_tiles(tau3d_t *h, long *uniform, long *tiles, int *enabled);
+/* Predicted-uniform tiles (round 6; no reference counterpart): after a whole-domain step, the tiles whose neighbourhood held one
+ * encoded state are flagged for the next step without being looked at again, and k_flux_xy is launched over the LIST of the
+ * others.  TAU3D_TILE_LIST at tau3d_create: 0 off, 1 (default) on, 2 verify (predictions checked against a k_flux_xy over every
+ * tile).  mode: what this handle does (0 also for slabs / ragged tiles); listed: length of the list made by the last step (-1: none
+ * valid); checked / mismatches: mode 2's tally (mismatches must stay 0).  Waits for the stream.  Same bits in every mode. */
+int tau3d_tile_list_stats(tau3d_t *h, int *mode, long *listed, long *tiles, long *checked, long *mismatches);
 /* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state (or the solid mask) through them
  * says so here before the next step (tau3d_init / tau3d_upload_* do it themselves): the field range is measured again and
  * the static solid-free tile flags of the x/y flux kernel are rebuilt from the mask. */

@@ -531,3 +531,50 @@ def test_uniform_region_exits_change_no_bit(eng, monkeypatch, shape, mode, steps
     frac = [u[0] / u[1] for _, _, u in a]
     print(shape, "mode", mode, "uniform tiles after 1 / 3 /", steps, "steps:", ["%.3f" % f for f in frac])
     assert frac[0] > 0.2            # the exits were taken: the comparison is not between two runs of the full path
+
+
+@pytest.mark.parametrize("shape,mode,steps", [((96, 64, 32), 1, 25), ((160, 128, 96), 1, 30), ((256, 192, 128), 1, 40), ((256, 256, 64), 0, 120),
+                                              ((130, 70, 20), 0, 12)])
+def test_predicted_uniform_tile_list_changes_no_bit(eng, monkeypatch, shape, mode, steps):
+    """The predicted-uniform tile list (include/taueng.h: tau3d_tile_list_stats): k_flux_xy over the list of the tiles k_tile_predict could
+    not clear (TAU3D_TILE_LIST=1, the default) against a k_flux_xy over every tile (=0), and the verifying mode (=2: every prediction
+    checked against what k_flux_xy then found) — every field of every cell, the clock and the per-tile "divergence is zero" flags,
+    byte for byte; a cell overwritten through tau3d_upload_state in the middle of a predicted region must be seen (the list is
+    dropped).  The last shape has ragged tiles: the handle keeps no list and says so."""
+    ragged = shape[0] % 32 != 0 or shape[1] % 16 != 0
+    def run(tl):
+        monkeypatch.setenv("TAU3D_TILE_LIST", str(tl))
+        e = eng.Tau3D(*shape)
+        e.set_split(True)
+        e.init(mode)
+        if mode:
+            e.set_clock(0.02, 1e-4)
+        out = []
+        for i, k in enumerate((1, 2, steps - 3, 4, 6)):
+            e.step(k)
+            c = e.clock()
+            st = e.download()
+            out.append((st, (c.t, c.d_tau, c.maxs), e.uniform_tiles(), e.tile_list_stats()))
+            if i == 2:      # a dent in the far corner of the grid, away from the body and the sponges: uniform there on these starts
+                st = [f.copy() for f in st]
+                st[4][shape[2] - 5, shape[1] - 9, shape[0] // 2 + 7] += 0.25
+                e.upload(st)
+        e.close()
+        return out
+    a, b, v = run(1), run(0), run(2)
+    for (sa, ca, ua, la), (sb, cb, ub, lb), (sv, cv, uv, lv) in zip(a, b, v):
+        assert ca == cb == cv
+        for x, y, w in zip(sa, sb, sv):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+            assert np.array_equal(x.view(np.uint32), w.view(np.uint32))
+        assert ua == ub == uv
+        assert lb[0] == 0 and la[0] == (0 if ragged else 1) and lv[0] == (0 if ragged else 2)
+        assert lv[4] == 0, "a predicted tile did not come out uniform: %r" % (lv,)
+    if ragged:
+        return
+    la, lv = a[-1][3], v[-1][3]
+    print(shape, "mode", mode, "listed / tiles:", [(x[3][1], x[3][2]) for x in a], "checked", lv[3])
+    if shape[0] >= 160:                                # (three tiles across: the outer two touch ghost columns, the middle one has no flagged neighbour)
+        assert lv[3] > 0 and 0 <= min(x[3][1] for x in a) < la[2]   # predictions were made (and checked), a list was shorter than the grid
+    assert [x[3][1] for x in a] == [x[3][1] for x in v]   # the same list either way
+
