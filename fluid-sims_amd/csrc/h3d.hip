@@ -1746,16 +1746,21 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   const bool zsk = uex && A.z_pred == 2;
   float memoE[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool memo = false;
-  unsigned long long pmask = 0ull;
+  // Steady tiles (bit 2, see k_tile_predict): where the state k_update_z computes for a predicted plane is, bit for bit, the state
+  // the plane holds now AND held a step ago, the output buffer — the input of the step before — holds it already: no store (smask:
+  // the planes where both tiles are candidates; wsame: the wave's new state is its old one, found at the first plane of the run).
+  unsigned long long pmask = 0ull, smask = 0ull;
+  bool wsame = false;
   if (zsk) {
     const int xa = bx * ZT_X, xb = xa + XT;              // the wave's two tiles start here (ZT_X = 2 XT)
     const int zl = zc_lo + lx;                           // this lane's plane of the chunk
-    bool p = false;
+    unsigned both = 0u;
     if (zl < zc_hi && xb + XT <= A.nx && y < A.ny) {
       const unsigned *const w = A.dzero + ((size_t)zl * A.dz_nty + (size_t)(y / YT)) * A.dz_ntx + (size_t)(xa / XT);
-      p = ((w[0] & w[1]) & 2u) != 0u;
+      both = w[0] & w[1];
     }
-    pmask = __builtin_amdgcn_ballot_w64(p);
+    pmask = __builtin_amdgcn_ballot_w64((both & 2u) != 0u);
+    smask = __builtin_amdgcn_ballot_w64((both & 4u) != 0u);
   }
   const bool pref_lane = ((x & (XT - 1)) == 0) && ((y & (YT - 1)) == 0);   // this lane's cell is its tile's first: it reports the new state of a predicted tile
 
@@ -1765,7 +1770,8 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     asm volatile("" : "+s"(f4), "+s"(d4));
     const bool wpred = (pmask & 1ull) != 0ull;          // this plane and (skipl) the next: predicted in both tiles of the wave
     const bool skipl = more && (pmask & 2ull) != 0ull;
-    pmask >>= 1;
+    const bool cand = (smask & 1ull) != 0ull;
+    pmask >>= 1; smask >>= 1;
     const bool zskip = wpred && memo;
     const unsigned dzf = !uex ? 0u : zskip ? 3u : __float_as_uint(gld(dzB, dzo));
     if (more && !skipl) {
@@ -1885,6 +1891,14 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         if (wpred) {
 #pragma unroll
           for (int m = 0; m < 6; m++) memoE[m] = E[m];
+          wsame = false;
+          if (cand) {   // first plane of a run of predicted planes: is the new state the tile's present one?
+            const float *const sr = A.uref_r + (size_t)(dzo >> 2) * 8;
+            unsigned dif = 0u;
+#pragma unroll
+            for (int m = 0; m < 6; m++) dif |= __float_as_uint(sr[m]) ^ __float_as_uint(E[m]);
+            wsame = __builtin_amdgcn_ballot_w64(dif != 0u) == 0ull;
+          }
         }
       }
       if (zpr && (dzf & 2u) != 0u && pref_lane) {   // the state k_flux_xy's test of this tile would take as its reference next step
@@ -1892,7 +1906,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #pragma unroll
         for (int m = 0; m < 6; m++) pr[m] = E[m];
       }
-      {
+      if (!(wpred && cand && wsame)) {   // (else: the buffer holds these bits already)
         const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) gst(outB + m * f4, vb, E[m]);
@@ -2079,8 +2093,19 @@ __global__ __launch_bounds__(PREDICT_NT) void k_tile_predict(const Args A) {
     }
     // (bit 0 of the tile's "divergence is zero" word is set already — the tile was flagged this step — and stays: the next k_flux_xy
     //  does not come here.  The state of the new tile is k_update_z's to report: it has not been computed yet.)
-    A.pflag[t] = ok ? 1u : 0u;
-    A.dzero[t] = ok ? 3u : (A.dzero[t] & 1u);   // bit 1: k_update_z's copy of the prediction (a k_flux_xy that runs the tile writes 0 or 1)
+    // Steady tiles.  A tile predicted now AND by the step before (its flag is that prediction's 2, not a k_flux_xy's 1) whose state
+    // then (the word this prediction's state will replace: read here, before k_update_z writes it) has the bits of its state now
+    // held ONE state S at steps n - 1 and n.  The buffer k_update_z is about to write is the input of step n - 1: it holds S in every
+    // cell of the tile.  If the new state comes out as S once more — k_update_z compares — the store would change nothing (bit 2).
+    bool steady = false;
+    if (ok && A.pred_commit && A.uflag_r[t] == 2u) {
+      const uint4 *const rp = reinterpret_cast<const uint4 *>(A.uref_r), *const op = reinterpret_cast<const uint4 *>(A.pref);
+      const uint4 c0 = rp[(size_t)t * 2], c1 = rp[(size_t)t * 2 + 1], o0 = op[(size_t)t * 2], o1 = op[(size_t)t * 2 + 1];
+      steady = c0.x == o0.x && c0.y == o0.y && c0.z == o0.z && c0.w == o0.w && c1.x == o1.x && c1.y == o1.y;
+    }
+    A.pflag[t] = ok ? 2u : 0u;
+    // bit 1: k_update_z's copy of the prediction (a k_flux_xy that runs the tile writes 0 or 1)
+    A.dzero[t] = ok ? (steady ? 7u : 3u) : (A.dzero[t] & 1u);
   }
   // the others: one LDS atomic per wave, one global atomic per workgroup (same-address atomics cost ~12 ns each at the L2: a launch of
   // 4096 waves would spend 50 us on them); a wave's tiles in ascending order
