@@ -1,6 +1,6 @@
 #!/bin/bash
 # scripts/profile_3d.sh <tag> [passes...] — the 3D step's counter passes only (profile_round.sh without the secondary kernels);
-# TAUENG_LIB selects a variant build.  passes: stats sq lds fetch write (default: stats sq lds)
+# TAUENG_LIB selects a variant build.  passes: stats sq lds fetch write grbm (default: stats sq lds)
 set -u
 TAG=${1:-x}; shift
 PASSES=${*:-stats sq lds}
@@ -17,4 +17,5 @@ for p in $PASSES; do case $p in
   lds) run pmc_lds --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS;;
   fetch) run pmc_fetch --pmc FETCH_SIZE;;
   write) run pmc_write --pmc WRITE_SIZE;;
+  grbm) run pmc_grbm --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CU_CYCLES;;
 esac; done
