@@ -95,6 +95,8 @@ static_assert(offsetof(DevClock, maxs_bits) % 32 == 0 && offsetof(DevClock, fmax
               "tau3d_max_ptr hands out {maxs_bits, fmax_bits} as one aligned 2-word tensor");
 
 // kernel arguments (by value -> SGPRs)
+constexpr unsigned UF_ALL = 1u, UF_W = 2u, UF_E = 4u, UF_S = 8u, UF_N = 16u, UF_PRED = 32u;
+constexpr int UREC = 24, USTRIP = 6;   // floats per tile record; width of an edge strip = the reach of two steps' stencils (2 x HALO)
 struct Args {
   const float *in[6];
   float *out[6];
@@ -109,9 +111,12 @@ struct Args {
                              // read by k_update_z in place of the divergence.  null: exits off (TAU3D_UNIFORM_EXITS=0)
   int dz_ntx, dz_nty;        // its tile grid (k_flux_xy's tiles: XT x YT)
   // Predicted-uniform tiles (round 6): k_flux_xy records, per tile, whether it found tile + halo uniform and with which encoded state
-  // (uflag_w / uref_w: this step's, written; [tile] and [tile][8]); after k_update_z, k_tile_predict reads them (uflag_r / uref_r) and
+  // (uflag_w / uref_w: this step's, written; [tile] and [tile][UREC]); after k_update_z, k_tile_predict reads them (uflag_r / uref_r) and
   // decides which tiles of the NEXT state can only be uniform again — every tile around them, seven planes deep, held the same one
   // state — sets their dzero flag itself and lists the others (ulist, ucount): the next k_flux_xy is launched over the LIST.
+  // A flag word: UF_ALL — tile + halo hold ONE encoded state (record words 0-5: the tile's first cell); else UF_W / UF_S — its first six
+  // columns / rows do, with their 3-cell halo rows / columns (same record), UF_E / UF_N — its last six columns / rows (record words
+  // 8-13: the first row's last cell / 16-21: the last row's first cell); UF_PRED: flagged by k_tile_predict, not by a k_flux_xy.
   unsigned *uflag_w; float *uref_w;
   const unsigned *uflag_r; const float *uref_r;
   unsigned *pflag; float *pref;           // k_tile_predict: the NEXT step's flags / states, written where it predicts (pred_commit: and dzero)
@@ -718,9 +723,10 @@ using tau::GChar; using tau::GFloat; using tau::gld; using tau::gst; using tau::
 // the solid mask at plane zh
 // test: eq = the six ENCODED values are eqref[0..5] bit for bit (an interior cell; ghost columns never are)
 __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GChar *qpl, size_t fs4, const uint8_t *spl, int gx, int gyw,
-                                             int zg, float (&q)[6], bool &sol, bool test, const float (&eqref)[6], bool &eq) {
+                                             int zg, float (&q)[6], bool &sol, bool test, const float (&eqref)[6], bool strips,
+                                             const float (&refE)[6], const float (&refN)[6], unsigned &eq) {
   Prim p;
-  eq = false;
+  eq = 0u;   // bit 0: the cell is eqref, bit 1: it is refE, bit 2: refN (strips only)
   if (gx < 0) {
     p = inflow_prim(A);
     sol = sdf_solid(A, gx, gyw, zg);
@@ -743,8 +749,10 @@ __device__ __forceinline__ void fetch_cell_e(const Args &A, float uref, const GC
     // The exit itself survives that (a flagged tile's +0 divergence absorbs the sign), the predictions built on the flags do not:
     // k_update_z stores one new state for every cell of a run of predicted planes.  (Also cheaper: xor / or at full rate, one compare.)
     if (test) {
-      auto x = [&](int m) { return __float_as_uint(e[m]) ^ __float_as_uint(eqref[m]); };
-      eq = ((x(0) | x(1) | x(2)) | (x(3) | x(4) | x(5))) == 0u;
+      auto x = [&](const float (&r)[6], int m) { return __float_as_uint(e[m]) ^ __float_as_uint(r[m]); };
+      auto same = [&](const float (&r)[6]) { return ((x(r, 0) | x(r, 1) | x(r, 2)) | (x(r, 3) | x(r, 4) | x(r, 5))) == 0u; };
+      eq = same(eqref) ? 1u : 0u;
+      if (strips) eq |= (same(refE) ? 2u : 0u) | (same(refN) ? 4u : 0u);
     }
 #pragma unroll
     for (int m = 0; m < 6; m++) p.q[m] = decode_field_w(uref, m, e[m]);
@@ -1154,16 +1162,32 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
   const bool utest = !SOLID && A.dzero != nullptr;
   const size_t tile_i = ((size_t)z * A.nty + by) * A.ntx + bx;
   float uref6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // Edge strips (a handle that keeps the tile list, see k_tile_predict): a tile that is NOT uniform still says whether its first /
+  // last six columns and rows are — against its own corner cells — because that is all its neighbours' predictions need of it.
+  const bool strips = utest && A.uflag_w != nullptr;
+  float urefE[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, urefN[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (utest) {
     const float *const rp = A.in0 + (size_t)zh * plane_n + (size_t)wrap_near(by0, A.ny, ynear) * A.nx + bx0;
 #pragma unroll
     for (int m = 0; m < 6; m++) uref6[m] = rp[(size_t)m * A.fstride];
+    if (strips) {   // (whole tiles: both cells are inside the grid)
+      const float *const rn = A.in0 + (size_t)zh * plane_n + (size_t)wrap_near(by0 + YT - 1, A.ny, ynear) * A.nx + bx0;
+#pragma unroll
+      for (int m = 0; m < 6; m++) { urefE[m] = rp[(size_t)m * A.fstride + (XT - 1)]; urefN[m] = rn[(size_t)m * A.fstride]; }
+    }
   }
-  bool ueq = false;
+  unsigned ufail = 0u;   // which claims this thread's cells refute: UF_ALL, UF_W, UF_E, UF_S, UF_N
   { // ---- stage the plane: own cell + the halo cells (3 rows above / below, 3 columns left / right; no corners)
     float q[6];
     bool osol;
-    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, osol, utest, uref6, ueq);
+    unsigned eqm;
+    fetch_cell_e(A, uref, qpl, fs4, spl, x, yw, zg, q, osol, utest, uref6, strips, urefE, urefN, eqm);
+    ufail = (eqm & 1u) ? 0u : UF_ALL;
+    if (strips) {
+      const bool f0 = !(eqm & 1u), fe = !(eqm & 2u), fn = !(eqm & 4u);
+      ufail |= ((tx < USTRIP && f0) ? UF_W : 0u) | ((tx >= XT - USTRIP && fe) ? UF_E : 0u) | ((ty < USTRIP && f0) ? UF_S : 0u) |
+               ((ty >= YT - USTRIP && fn) ? UF_N : 0u);
+    }
 #pragma unroll
     for (int m = 0; m < 6; m++) sP[m][lc] = q[m];
     if (SOLID) { own_solid = osol; sS[lc] = osol ? 1 : 0; }
@@ -1184,38 +1208,61 @@ template <bool FAST, bool SOLID> __device__ __forceinline__ void flux_xy_core(co
       }
       const int gx = bx0 + lx - HALO;
       const int gy = wrap_near(by0 + ly - HALO, A.ny, ynear);
-      bool sol, heq;
-      fetch_cell_e(A, uref, qpl, fs4, spl, gx, gy, zg, q, sol, utest, uref6, heq);
-      ueq = ueq && heq;
+      bool sol;
+      fetch_cell_e(A, uref, qpl, fs4, spl, gx, gy, zg, q, sol, utest, uref6, strips, urefE, urefN, eqm);
+      ufail |= (eqm & 1u) ? 0u : UF_ALL;
+      if (strips) {   // a halo row belongs to the column strips it prolongs, a halo column to the row strips
+        const bool f0 = !(eqm & 1u), fe = !(eqm & 2u), fn = !(eqm & 4u);
+        const int c = lx - HALO, r = ly - HALO;
+        if (p < NROWS) ufail |= ((c < USTRIP && f0) ? UF_W : 0u) | ((c >= XT - USTRIP && fe) ? UF_E : 0u);
+        else ufail |= ((r < USTRIP && f0) ? UF_S : 0u) | ((r >= YT - USTRIP && fn) ? UF_N : 0u);
+      }
       const int li = ly * XPXS + lx;
 #pragma unroll
       for (int m = 0; m < 6; m++) sP[m][li] = q[m];
       if (SOLID) sS[li] = sol ? 1 : 0;
     }
   }
-  if (utest) {
-    const bool wave_uni = __builtin_amdgcn_ballot_w64(!ueq) == 0ull;
-    if (lane == 0) S.wuni[wave] = wave_uni ? 1u : 0u;
+  if (utest) {   // the claims no lane of this wave refutes
+    unsigned pass = __builtin_amdgcn_ballot_w64((ufail & UF_ALL) != 0u) == 0ull ? UF_ALL : 0u;
+    if (strips) {
+      pass |= (__builtin_amdgcn_ballot_w64((ufail & UF_W) != 0u) == 0ull ? UF_W : 0u) | (__builtin_amdgcn_ballot_w64((ufail & UF_E) != 0u) == 0ull ? UF_E : 0u) |
+              (__builtin_amdgcn_ballot_w64((ufail & UF_S) != 0u) == 0ull ? UF_S : 0u) | (__builtin_amdgcn_ballot_w64((ufail & UF_N) != 0u) == 0ull ? UF_N : 0u);
+    }
+    if (lane == 0) S.wuni[wave] = pass;
   }
   __syncthreads();
+  unsigned all = 0u;
   if (utest) {
-    unsigned all = 1u;
+    all = ~0u;
 #pragma unroll
     for (int w = 0; w < XNW; w++) all &= S.wuni[w];
-    if (all) {      // (the same word for every thread: the workgroup leaves together)
+    if (all & UF_ALL) {      // (the same word for every thread: the workgroup leaves together)
       if (tid == 0) {
         A.dzero[tile_i] = 1u;
         if (A.uflag_w != nullptr) {
-          A.uflag_w[tile_i] = 1u;
+          A.uflag_w[tile_i] = UF_ALL;
 #pragma unroll
-          for (int m = 0; m < 6; m++) A.uref_w[tile_i * 8 + m] = uref6[m];
+          for (int m = 0; m < 6; m++) A.uref_w[tile_i * UREC + m] = uref6[m];
         }
       }
       C.in_xy = false;
       return;
     }
   }
-  if (A.dzero != nullptr && tid == 0) { A.dzero[tile_i] = 0u; if (A.uflag_w != nullptr) A.uflag_w[tile_i] = 0u; }
+  if (A.dzero != nullptr && tid == 0) {
+    A.dzero[tile_i] = 0u;
+    if (A.uflag_w != nullptr) {
+      const unsigned sf = strips ? (all & (UF_W | UF_E | UF_S | UF_N)) : 0u;
+      A.uflag_w[tile_i] = sf;
+      if (sf != 0u) {
+#pragma unroll
+        for (int m = 0; m < 6; m++) {
+          A.uref_w[tile_i * UREC + m] = uref6[m]; A.uref_w[tile_i * UREC + 8 + m] = urefE[m]; A.uref_w[tile_i * UREC + 16 + m] = urefN[m];
+        }
+      }
+    }
+  }
   // ---- edge states of the own cell; ring cells
   // One variable at a time.  Left alone, hipcc runs the six variables breadth-first (all first differences, then all
   // smoothness indicators, ...) and needs ~140 VGPRs for it; occupancy is worth more than that ILP here.  The empty asm
@@ -1893,7 +1940,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
           for (int m = 0; m < 6; m++) memoE[m] = E[m];
           wsame = false;
           if (cand) {   // first plane of a run of predicted planes: is the new state the tile's present one?
-            const float *const sr = A.uref_r + (size_t)(dzo >> 2) * 8;
+            const float *const sr = A.uref_r + (size_t)(dzo >> 2) * UREC;
             unsigned dif = 0u;
 #pragma unroll
             for (int m = 0; m < 6; m++) dif |= __float_as_uint(sr[m]) ^ __float_as_uint(E[m]);
@@ -1902,7 +1949,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         }
       }
       if (zpr && (dzf & 2u) != 0u && pref_lane) {   // the state k_flux_xy's test of this tile would take as its reference next step
-        float *const pr = A.pref + (size_t)(dzo >> 2) * 8;
+        float *const pr = A.pref + (size_t)(dzo >> 2) * UREC;
 #pragma unroll
         for (int m = 0; m < 6; m++) pr[m] = E[m];
       }
@@ -2067,43 +2114,50 @@ __global__ __launch_bounds__(PREDICT_NT) void k_tile_predict(const Args A) {
     const int by = (int)((t / (unsigned)ntx) % (unsigned)nty);
     const int z = (int)(t / (unsigned)(ntx * nty));
     const int x_lo = bx * XT - HALO, x_hi = bx * XT + XT + HALO;   // the cells the flag of T covers: [x_lo, x_hi)
-    ok = bx >= 1 && bx <= ntx - 2 && A.xyflag != nullptr && A.xyflag[t] == 0u && A.uflag_r[t] != 0u &&
+    ok = bx >= 1 && bx <= ntx - 2 && A.xyflag != nullptr && A.xyflag[t] == 0u && (A.uflag_r[t] & UF_ALL) != 0u &&
          (A.sponge_n <= 0 || x_lo >= A.sponge_n) && (A.sponge_out_n <= 0 || x_hi <= A.nx - A.sponge_out_n);
     if (ok) {
+      // What the cells of T and its halo read in two steps' reach: T + halo itself (its own flag), six columns of the tiles east and
+      // west with their halo rows, six rows of the tiles north and south with their halo columns — a neighbour qualifies whole
+      // (UF_ALL) or by the edge strip that faces T (k_flux_xy's UF_W / UF_E / UF_S / UF_N, each with the state of the strip's own
+      // corner cell); the corners of the 3-cell box around T lie in those strips' halos, so no diagonal tile is asked.  A cell of
+      // a strip of a tile that is NOT uniform took a computed x/y divergence, not the flag's: with one bit pattern in its whole
+      // stencil that is (F - F) / dx + (F - F) / dy = +0 as well.
       const uint4 *const rp = reinterpret_cast<const uint4 *>(A.uref_r);
-      const uint4 c0 = rp[(size_t)t * 2], c1 = rp[(size_t)t * 2 + 1];
-      auto same = [&](unsigned n) -> bool {
-        if (A.uflag_r[n] == 0u) return false;
-        const uint4 a0 = rp[(size_t)n * 2], a1 = rp[(size_t)n * 2 + 1];
+      constexpr int Q = UREC / 4;   // uint4 per record
+      const uint4 c0 = rp[(size_t)t * Q], c1 = rp[(size_t)t * Q + 1];
+      auto same = [&](unsigned n, unsigned strip, int word4) -> bool {   // word4: where the strip's state sits in the record
+        const unsigned f = A.uflag_r[n];
+        const int w = (f & UF_ALL) ? 0 : word4;
+        if ((f & (UF_ALL | strip)) == 0u) return false;
+        const uint4 a0 = rp[(size_t)n * Q + w], a1 = rp[(size_t)n * Q + w + 1];
         return a0.x == c0.x && a0.y == c0.y && a0.z == c0.z && a0.w == c0.w && a1.x == c1.x && a1.y == c1.y;
       };
       const int ym = by == 0 ? nty - 1 : by - 1, yp = by == nty - 1 ? 0 : by + 1;
       const unsigned pl = (unsigned)(z * nty) * (unsigned)ntx;
-#pragma unroll
-      for (int dx = -1; dx <= 1; dx++) {
-        ok = ok && same(pl + (unsigned)(ym * ntx + bx + dx)) && same(pl + (unsigned)(yp * ntx + bx + dx));
-        if (dx != 0) ok = ok && same(pl + (unsigned)(by * ntx + bx + dx));
-      }
+      ok = same(pl + (unsigned)(by * ntx + bx + 1), UF_W, 0) && same(pl + (unsigned)(by * ntx + bx - 1), UF_E, 2) &&
+           same(pl + (unsigned)(yp * ntx + bx), UF_S, 0) && same(pl + (unsigned)(ym * ntx + bx), UF_N, 4);
       for (int dz = -HALO; dz <= HALO && ok; dz++) {
         if (dz == 0) continue;
         int zz = z + dz;
         if (zz < 0) zz += A.nzl; else if (zz >= A.nzl) zz -= A.nzl;   // (the list needs the whole periodic domain in the handle)
-        ok = same((unsigned)(zz * nty + by) * (unsigned)ntx + (unsigned)bx);
+        ok = same((unsigned)(zz * nty + by) * (unsigned)ntx + (unsigned)bx, 0u, 0);
       }
     }
     // (bit 0 of the tile's "divergence is zero" word is set already — the tile was flagged this step — and stays: the next k_flux_xy
     //  does not come here.  The state of the new tile is k_update_z's to report: it has not been computed yet.)
-    // Steady tiles.  A tile predicted now AND by the step before (its flag is that prediction's 2, not a k_flux_xy's 1) whose state
+    // Steady tiles.  A tile predicted now AND by the step before (its flag carries UF_PRED: not a k_flux_xy's) whose state
     // then (the word this prediction's state will replace: read here, before k_update_z writes it) has the bits of its state now
     // held ONE state S at steps n - 1 and n.  The buffer k_update_z is about to write is the input of step n - 1: it holds S in every
     // cell of the tile.  If the new state comes out as S once more — k_update_z compares — the store would change nothing (bit 2).
     bool steady = false;
-    if (ok && A.pred_commit && A.uflag_r[t] == 2u) {
+    if (ok && A.pred_commit && (A.uflag_r[t] & UF_PRED) != 0u) {
       const uint4 *const rp = reinterpret_cast<const uint4 *>(A.uref_r), *const op = reinterpret_cast<const uint4 *>(A.pref);
-      const uint4 c0 = rp[(size_t)t * 2], c1 = rp[(size_t)t * 2 + 1], o0 = op[(size_t)t * 2], o1 = op[(size_t)t * 2 + 1];
+      constexpr int Q = UREC / 4;
+      const uint4 c0 = rp[(size_t)t * Q], c1 = rp[(size_t)t * Q + 1], o0 = op[(size_t)t * Q], o1 = op[(size_t)t * Q + 1];
       steady = c0.x == o0.x && c0.y == o0.y && c0.z == o0.z && c0.w == o0.w && c1.x == o1.x && c1.y == o1.y;
     }
-    A.pflag[t] = ok ? 2u : 0u;
+    A.pflag[t] = ok ? (UF_ALL | UF_PRED) : 0u;
     // bit 1: k_update_z's copy of the prediction (a k_flux_xy that runs the tile writes 0 or 1)
     A.dzero[t] = ok ? (steady ? 7u : 3u) : (A.dzero[t] & 1u);
   }
@@ -2128,8 +2182,8 @@ __global__ __launch_bounds__(256) void k_tile_predict_check(const unsigned *pfla
   const unsigned t = blockIdx.x * 256u + threadIdx.x;
   if (t >= nt || pflag[t] == 0u) return;
   atomicAdd(npred, 1u);
-  bool same = uflag[t] != 0u;
-  for (int m = 0; m < 6 && same; m++) same = __float_as_uint(pref[(size_t)t * 8 + m]) == __float_as_uint(uref[(size_t)t * 8 + m]);
+  bool same = (uflag[t] & UF_ALL) != 0u;
+  for (int m = 0; m < 6 && same; m++) same = __float_as_uint(pref[(size_t)t * UREC + m]) == __float_as_uint(uref[(size_t)t * UREC + m]);
   if (!same) atomicAdd(bad, 1u);
 }
 
@@ -2422,11 +2476,12 @@ struct tau3d {
   bool z_skip = true;              // TAU3D_Z_SKIP=0 (read at tau3d_create): k_update_z does not use the predictions
   unsigned list_margin_div = 8;   // k_flux_xy_list's grid: the last length seen + 1 / this of it + 512
   unsigned *uflag[2] = {nullptr, nullptr};   // per tile: found (or predicted) uniform; [step parity]
-  float *uref[2] = {nullptr, nullptr};       // ... and with which encoded state (8 floats per tile, 6 used)
+  float *uref[2] = {nullptr, nullptr};       // ... and with which encoded states (h3d::UREC floats per tile: see h3d::Args::uflag_w)
   unsigned *vflag = nullptr; float *vref = nullptr;   // mode 2: the predictions
   unsigned *ulist = nullptr;                 // tile indices
   unsigned *ucount = nullptr;                // [0], [1]: list length by step parity; [2]: mode 2's mismatches; [3]: mode 2's predictions checked
   unsigned *ucount_host = nullptr;           // mapped host word: the length the last k_flux_xy_list to run saw
+  unsigned *ucount_host_dev = nullptr;       // ... as the device addresses it
   hipEvent_t list_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded after each whole-domain step of a handle that keeps the list (see split_xy)
   unsigned long list_step = 0;               // such steps issued
   int upar = 0;                              // this step's parity
@@ -2756,7 +2811,7 @@ static void split_args(tau3d_t *h, h3d::Args &A, int lo, int hi, int lo2, int hi
   A.pred_commit = commit ? 1 : 0;
   A.ulist = h->ulist;
   A.ucount = nullptr; A.ucount_other = nullptr; A.z_pred = 0;   // (set by the launch that uses them)
-  A.ucount_host = h->ucount_host;
+  A.ucount_host = h->ucount_host_dev;
   A.wrap_halo = (h->wrap_now && lo == 0 && hi == h->nzl && lo2 >= hi2) ? 1 : 0;
 }
 static int split_xy(tau3d_t *h, int lo, int hi, int lo2, int hi2, hipStream_t s, bool fix = false, bool listed = false) {   // x/y faces: one plane per workgroup
@@ -3227,18 +3282,19 @@ static int split_buffers(tau3d *h) {   // what the kernel pair needs beside the 
     const size_t ntiles = (size_t)(p->nx / h3d::XY_FX) * (p->ny / h3d::XY_FY) * (size_t)h->nzl;
     for (int i = 0; i < 2; i++) {
       TAU_HIP(hipMalloc(&h->uflag[i], ntiles * sizeof(unsigned)));
-      TAU_HIP(hipMalloc(&h->uref[i], ntiles * 8 * sizeof(float)));
+      TAU_HIP(hipMalloc(&h->uref[i], ntiles * h3d::UREC * sizeof(float)));
       TAU_HIP(hipMemsetAsync(h->uflag[i], 0, ntiles * sizeof(unsigned), h->stream));
-      TAU_HIP(hipMemsetAsync(h->uref[i], 0, ntiles * 8 * sizeof(float), h->stream));
+      TAU_HIP(hipMemsetAsync(h->uref[i], 0, ntiles * h3d::UREC * sizeof(float), h->stream));
     }
     if (h->tile_list == 2) {
       TAU_HIP(hipMalloc(&h->vflag, ntiles * sizeof(unsigned)));
-      TAU_HIP(hipMalloc(&h->vref, ntiles * 8 * sizeof(float)));
+      TAU_HIP(hipMalloc(&h->vref, ntiles * h3d::UREC * sizeof(float)));
     }
     TAU_HIP(hipMalloc(&h->ulist, ntiles * sizeof(unsigned)));
     TAU_HIP(hipMalloc(&h->ucount, 4 * sizeof(unsigned)));
     TAU_HIP(hipMemsetAsync(h->ucount, 0, 4 * sizeof(unsigned), h->stream));
     TAU_HIP(hipHostMalloc((void **)&h->ucount_host, 64, hipHostMallocMapped));
+    TAU_HIP(hipHostGetDevicePointer((void **)&h->ucount_host_dev, h->ucount_host, 0));
     *h->ucount_host = 0xFFFFFFFFu;
     for (int i = 0; i < 4; i++) TAU_HIP(hipEventCreateWithFlags(&h->list_ev[i], hipEventDisableTiming));
   }
