@@ -124,6 +124,7 @@ struct Args {
   unsigned *ucount_other;                 // the length word of the step before: k_tile_predict zeroes it for the step after
   unsigned *ucount_host;                  // k_flux_xy_list: the length again, in mapped host memory (the host sizes later launches by it)
   unsigned list_grid; int list_fast;      // k_flux_xy_list_rest: the main launch's grid and weight form
+  int z_fill;                             // k_update_z: 0, or k_fill_z follows and takes the fully predicted chunks (1: if the fast weight form is due, 2: the other)
   int z_pred;                             // k_update_z: bit 1 of a dzero word is this step's prediction (k_tile_predict ran before it) — 0: no,
                                           // 1: report the new state of predicted tiles (pref), 2: and skip what a run of them repeats
   int pred_commit;                        // 0: the verifying mode — flags into a scratch pair, the next k_flux_xy still runs every tile
@@ -1648,20 +1649,24 @@ __device__ __forceinline__ void update_cell(const Args &A, const UpdK &K, const 
 constexpr int ZT_X = 64, ZT_Y = 4, ZNT = ZT_X * ZT_Y;
 static_assert(ZT_X == 2 * XT && YT % ZT_Y == 0, "k_update_z's prediction mask: a wave spans two k_flux_xy tiles of one tile row");
 typedef float ZRing[5][6][ZNT];
-template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring, unsigned bid) {
+// PART 0: the whole job; 1: the march only — a chunk all of whose planes are predicted is left to k_fill_z; 2: those chunks only (k_fill_z)
+template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring, unsigned bid) {
   const int tid = threadIdx.x;
   const int lx = tid & (ZT_X - 1), ly = tid >> 6;
   const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
   const unsigned nb = (unsigned)(nbx * nby * A.nzc);
-  // Workgroup -> (column block, chunk).  Workgroup i runs on XCD i % 8, and the columns share nothing (no x / y halo here), so there
-  // is no locality to keep; what matters since the uniform-region exits is that an XCD's workgroups are a fair sample of the
-  // grid — with xcd_swizzle an XCD took one 64-plane layer, the ones through the bow shock all of the work (round 6, 512^3:
-  // 1.96 -> 1.87 ms, with the predictions' skipped planes 2.03 -> 1.84).  Each aligned group of eight is rotated by its number: an
-  // XCD sees every x block, tile row and chunk in turn.
-  unsigned b = bid < (nb & ~7u) ? ((bid & ~7u) | ((bid + (bid >> 3)) & 7u)) : bid;
-  const int bx = (int)(b % (unsigned)nbx); b /= (unsigned)nbx;
-  const int by = (int)(b % (unsigned)nby);
-  const int bz = (int)(b / (unsigned)nby);
+  // Workgroup -> (column block, chunk): ROWS fastest, then chunks, then the 64-column blocks.  The columns share nothing (no x / y
+  // halo here), so there is no locality to keep — what matters since the uniform-region exits and the predictions is where the
+  // EXPENSIVE workgroups go.  The hardware deals consecutive workgroups round the XCDs and, within one, round its CUs: work whose cost
+  // is periodic in the workgroup number with a period that divides those counts lands on a fraction of the chip.  With x fastest
+  // (8 blocks of 64 columns at 512) the disturbed blocks were always the same residues mod 8: measured on a flow that is uniform but
+  // for the sponge columns (2 of 8 blocks expensive), the kernel kept 15 % of its wave slots busy and took 1.31 ms for 0.3 ms of
+  // work; with xcd_swizzle (round 5) an XCD owned one 64-plane layer.  Along y the cost varies slowly, so consecutive workgroups
+  // cost about the same and the deal is even.
+  unsigned b = bid;
+  const int by = (int)(b % (unsigned)nby); b /= (unsigned)nby;
+  const int bz = (int)(b % (unsigned)A.nzc);
+  const int bx = (int)(b / (unsigned)A.nzc);
   const bool second = bz >= A.nzc1;
   const int zc_lo = second ? A.zl_lo2 + (bz - A.nzc1) * A.zchunk : A.zl_lo + bz * A.zchunk;
   const int zc_hi = min(zc_lo + A.zchunk, second ? A.zl_hi2 : A.zl_hi);
@@ -1701,6 +1706,88 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     return sol;
   };
 
+  const bool uex = A.dzero != nullptr;
+  const bool zsk = uex && A.z_pred == 2;
+  // The chunk's prediction bits for the wave's two tiles (see "Predicted-uniform tiles" below): lane l reads the words of plane zc_lo + l.
+  unsigned long long pmask = 0ull, smask = 0ull;
+  if (zsk) {
+    const int xa = bx * ZT_X, xb = xa + XT;              // the wave's two tiles start here (ZT_X = 2 XT)
+    const int zl = zc_lo + lx;                           // this lane's plane of the chunk
+    unsigned both = 0u;
+    if (zl < zc_hi && xb + XT <= A.nx && y < A.ny) {
+      const unsigned *const w = A.dzero + ((size_t)zl * A.dz_nty + (size_t)(y / YT)) * A.dz_ntx + (size_t)(xa / XT);
+      both = w[0] & w[1];
+    }
+    pmask = __builtin_amdgcn_ballot_w64((both & 2u) != 0u);
+    smask = __builtin_amdgcn_ballot_w64((both & 4u) != 0u);
+  }
+  // A chunk ALL of whose planes are predicted for both tiles of the wave (most chunks away from the disturbance): every cell of it
+  // holds the state S of its tile's record, and the march below would compute update_cell(S, +0, F, F) at its first plane and store
+  // that 64 times.  Done directly — one load of the record, one update, the stores — and in a kernel of its own (k_fill_z: no LDS
+  // ring, so not five workgroups per CU), because workgroups are dispatched in order: marched, such a workgroup lives ~30 us on next
+  // to no arithmetic (prologue loads, a full first trip, 63 trips of bookkeeping), and even this short form ~12 us (384 stores per
+  // lane at 64 in flight) in one of the five slots the expensive workgroups behind it wait for — with most of the grid predicted
+  // the chip idled (15 % of the wave slots busy).  In k_update_z such a chunk returns after its flag words.  The z flux difference
+  // is F - F = +-0 either way and meets the flagged +0 divergence: the same -(+0) as below, the same bits.
+  {
+    const int nch = zc_hi - zc_lo;
+    const unsigned long long full = nch >= 64 ? ~0ull : ((1ull << nch) - 1ull);
+    const bool fullp = zsk && nch <= 64 && (pmask & full) == full && A.send[0] == nullptr;
+    if (PART == 2 && !fullp) return;
+    if (PART == 1 && fullp) return;
+    if (fullp) {
+      const size_t ti = ((size_t)zc_lo * A.dz_nty + (size_t)(y / YT)) * A.dz_ntx + (size_t)(x / XT);
+      const float *const sr = A.uref_r + ti * UREC;
+      float S6[6], own[6], E[6], F0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 6; m++) S6[m] = sr[m];
+#pragma unroll
+      for (int m = 0; m < 6; m++) own[m] = ZDEC(uref, m, S6[m]);
+      float smax = 0.f, fmx = 0.f;
+      update_cell(A, K, own, F0, F0, F0, dt, inv_dz, gain, x, E, smax, fmx);
+      unsigned dif = 0u;
+#pragma unroll
+      for (int m = 0; m < 6; m++) dif |= __float_as_uint(S6[m]) ^ __float_as_uint(E[m]);
+      const bool same = __builtin_amdgcn_ballot_w64(dif != 0u) == 0ull;   // steady: see "Steady tiles" below
+      const bool pref_lane = ((x & (XT - 1)) == 0) && ((y & (YT - 1)) == 0);
+      GChar *const outB = (GChar *)(A.out0 + (size_t)(zc_lo + HALO) * plane_n);
+      const size_t dz_plane = (size_t)A.dz_nty * A.dz_ntx;
+      unsigned vo = col4;
+      for (int z = zc_lo; z < zc_hi; z++) {
+        size_t f4 = fs4;
+        asm volatile("" : "+s"(f4));
+        if (!(same && (smask & 1ull) != 0ull)) {
+          const unsigned vb = lane_off(vo);
+#pragma unroll
+          for (int m = 0; m < 6; m++) gst(outB + m * f4, vb, E[m]);
+        }
+        smask >>= 1;
+        if (pref_lane) {
+          float *const pr = A.pref + (ti + (size_t)(z - zc_lo) * dz_plane) * UREC;
+#pragma unroll
+          for (int m = 0; m < 6; m++) pr[m] = E[m];
+        }
+        if (A.wrap_halo && (z < HALO || z >= A.nzl - HALO)) {
+          GChar *const wB = (GChar *)(A.out0 + (size_t)(z < HALO ? z + A.nzl + HALO : z - A.nzl + HALO) * plane_n);
+          const unsigned vb = lane_off(col4);
+#pragma unroll
+          for (int m = 0; m < 6; m++) gst(wB + m * f4, vb, E[m]);
+        }
+        vo += plane4;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+        fmx = fmaxf(fmx, __shfl_xor(fmx, o, 64));
+      }
+      if (lx == 0) {
+        tau::atomic_max_float_bits(&A.clk->maxs_bits, smax);
+        tau::atomic_max_float_bits(&A.clk->fmax_bits, fmx);
+      }
+      return;
+    }
+  }
+
   // prologue: planes zc_lo-2 .. zc_lo+2 into slots 0 .. 4 (plane zc_lo-3 is only needed here); flux through the low
   // face of plane zc_lo and the left state cell zc_lo contributes to its high face
   float Fz_lo[6], Lz[6];
@@ -1738,7 +1825,6 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   // +0), so it is read instead of recomputed.  Two such windows in a row, no solid cell in the stencil and w = 0 exactly (the free
   // stream) make the face's two states equal with no normal velocity: the blended HLLC flux is then (0, 0, 0, p, 0, 0) to the bit
   // (s_M = 0, g = 0, alpha = 0: every coefficient of hllc()'s sum is 0 or 1) — written down instead of evaluated.
-  const bool uex = A.dzero != nullptr;
   int urun = 0;
   bool prev_wuni = false;
   if (uex) {   // planes zc_lo-1 .. zc_lo+2 against their predecessors (slots 0 .. 4 hold planes zc_lo-2 .. zc_lo+2)
@@ -1790,25 +1876,12 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
   // chunk's mask (a flag load per trip is a dependent memory round trip per trip: measured, the skipped trips then cost what the
   // full ones do).
   const bool zpr = uex && A.z_pred != 0;
-  const bool zsk = uex && A.z_pred == 2;
   float memoE[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool memo = false;
   // Steady tiles (bit 2, see k_tile_predict): where the state k_update_z computes for a predicted plane is, bit for bit, the state
   // the plane holds now AND held a step ago, the output buffer — the input of the step before — holds it already: no store (smask:
   // the planes where both tiles are candidates; wsame: the wave's new state is its old one, found at the first plane of the run).
-  unsigned long long pmask = 0ull, smask = 0ull;
   bool wsame = false;
-  if (zsk) {
-    const int xa = bx * ZT_X, xb = xa + XT;              // the wave's two tiles start here (ZT_X = 2 XT)
-    const int zl = zc_lo + lx;                           // this lane's plane of the chunk
-    unsigned both = 0u;
-    if (zl < zc_hi && xb + XT <= A.nx && y < A.ny) {
-      const unsigned *const w = A.dzero + ((size_t)zl * A.dz_nty + (size_t)(y / YT)) * A.dz_ntx + (size_t)(xa / XT);
-      both = w[0] & w[1];
-    }
-    pmask = __builtin_amdgcn_ballot_w64((both & 2u) != 0u);
-    smask = __builtin_amdgcn_ballot_w64((both & 4u) != 0u);
-  }
   const bool pref_lane = ((x & (XT - 1)) == 0) && ((y & (YT - 1)) == 0);   // this lane's cell is its tile's first: it reports the new state of a predicted tile
 
   for (int z = zc_lo; z < zc_hi; z++) {
@@ -1820,13 +1893,19 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     const bool cand = (smask & 1ull) != 0ull;
     pmask >>= 1; smask >>= 1;
     const bool zskip = wpred && memo;
-    const unsigned dzf = !uex ? 0u : zskip ? 3u : __float_as_uint(gld(dzB, dzo));
+    // (Every vector-memory result of a trip is consumed inside the trip, late, and a skipped trip issues no load at all: a value
+    // loaded at the top and tested at once — the solid byte — or a register a skipped trip overwrites with a constant — the flag
+    // word — put an s_waitcnt vmcnt(0) at the top of EVERY trip, and a skipped trip then waited for its own six stores to land.)
+    // (Hence no initial values either: a constant written on the skipped path is a write to the register of a load that may be in flight.)
+    unsigned dzf;        // this trip's flag word: full trips with the exits on only
+    if (uex && !zskip) dzf = __float_as_uint(gld(dzB, dzo));
+    const bool predl = zskip || (uex && (dzf & 2u) != 0u);   // this lane's tile is a predicted one (a lane mask: no register across trips)
+    unsigned nsb;        // plane z+4's solid byte, looked at where the window slides: trips that load the plane only
     if (more && !skipl) {
 #pragma unroll
       for (int m = 0; m < 6; m++) Nx[m] = gld(qN + m * f4, vo);   // encoded: decoded where the plane enters the ring
-      nsol = solN[vo >> 2] != 0 ? 1u : 0u;
+      nsb = solN[vo >> 2];
     }
-    if (skipl) nsol = 0u;
     const bool own_solid = (ws >> 2) & 1u;
     const bool wuni = uex && urun >= 4;   // (scalar) planes z-1 .. z+3 hold one state per lane
 
@@ -1894,7 +1973,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
         }
         if (uex) urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
       }
-      if (in_xy && !own_solid && (dzf & 1u) == 0u) {   // (a flagged tile's divergence is +0 in every cell and was not stored)
+      if (in_xy && !own_solid && (!uex || (dzf & 1u) == 0u)) {   // (a flagged tile's divergence is +0 in every cell and was not stored)
         const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) D[m] = gld(dB + m * d4, vb);
@@ -1948,7 +2027,7 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
           }
         }
       }
-      if (zpr && (dzf & 2u) != 0u && pref_lane) {   // the state k_flux_xy's test of this tile would take as its reference next step
+      if (zpr && predl && pref_lane) {   // the state k_flux_xy's test of this tile would take as its reference next step
         float *const pr = A.pref + (size_t)(dzo >> 2) * UREC;
 #pragma unroll
         for (int m = 0; m < 6; m++) pr[m] = E[m];
@@ -1992,6 +2071,8 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
     dzo += dz_plane4;
     vo += plane4;
     if (more) {   // plane z+4 has replaced plane z-1; the window slides
+      nsol = 0u;
+      if (!skipl) { asm volatile("" : "+v"(nsb)); nsol = nsb != 0u ? 1u : 0u; }
       ws = (ws >> 1) | (nsol << 5);
       const int t = s0; s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = t;
     }
@@ -2012,26 +2093,39 @@ template <bool FAST> __device__ __forceinline__ void update_z_body(const Args &A
 #ifndef TAU3D_Z_WAVES
 #define TAU3D_Z_WAVES 5
 #endif
-template <bool FAST, bool STRIDE> __global__ __launch_bounds__(ZNT, TAU3D_Z_WAVES) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
+// PART 1: launched with k_fill_z behind it, which takes the fully predicted chunks (a kernel of its own: one body per kernel)
+template <bool FAST, bool STRIDE, int PART = 0> __global__ __launch_bounds__(ZNT, TAU3D_Z_WAVES) void k_update_z(const Args A) {   // 5 waves per SIMD: 5 x 30 KB of LDS ring per CU
   __shared__ ZRing ring;
   if (fast_form(A.clk->fmax_in, A.in_fmax) != FAST) return;   // (one weight form per kernel: comment at k_flux_xy)
-  if (!STRIDE) { update_z_body<FAST>(A, ring, blockIdx.x); return; }
+  if (!STRIDE) { update_z_body<FAST, PART>(A, ring, blockIdx.x); return; }
   const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
   const unsigned nb = (unsigned)(nbx * nby * A.nzc);
   for (unsigned b = blockIdx.x; b < nb; b += gridDim.x) update_z_body<FAST>(A, ring, b);   // (a thread reads only its own ring slots: no barrier)
 }
-void launch_update_z(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast) {
+// the fully predicted chunks of a step whose full-grid k_update_z ran the expected weight form (else the strided kernel of the other
+// form has done the whole job, these chunks included); no reconstruction in here: one kernel for both forms, no LDS
+__global__ __launch_bounds__(ZNT) void k_fill_z(const Args A) {
+  __shared__ float none[1];
+  if (fast_form(A.clk->fmax_in, A.in_fmax) != (A.z_fill == 1)) return;
+  update_z_body<true, 2>(A, *reinterpret_cast<ZRing *>(none), blockIdx.x);
+}
+void launch_update_z(unsigned nwg, hipStream_t s, const Args &A0, bool expect_fast) {
+  Args A = A0;
+  A.z_fill = A.z_pred == 2 && A.send[0] == nullptr ? (expect_fast ? 1 : 2) : 0;
   const unsigned net = nwg < 1280u ? nwg : 1280u;   // five workgroups per CU resident
 #ifdef TAU3D_FAST_ONLY
   hipLaunchKernelGGL((k_update_z<true, false>), dim3(nwg), dim3(ZNT), 0, s, A);
 #else
   if (expect_fast) {
-    hipLaunchKernelGGL((k_update_z<true, false>), dim3(nwg), dim3(ZNT), 0, s, A);
+    if (A.z_fill) hipLaunchKernelGGL((k_update_z<true, false, 1>), dim3(nwg), dim3(ZNT), 0, s, A);
+    else hipLaunchKernelGGL((k_update_z<true, false, 0>), dim3(nwg), dim3(ZNT), 0, s, A);
     hipLaunchKernelGGL((k_update_z<false, true>), dim3(net), dim3(ZNT), 0, s, A);
   } else {
-    hipLaunchKernelGGL((k_update_z<false, false>), dim3(nwg), dim3(ZNT), 0, s, A);
+    if (A.z_fill) hipLaunchKernelGGL((k_update_z<false, false, 1>), dim3(nwg), dim3(ZNT), 0, s, A);
+    else hipLaunchKernelGGL((k_update_z<false, false, 0>), dim3(nwg), dim3(ZNT), 0, s, A);
     hipLaunchKernelGGL((k_update_z<true, true>), dim3(net), dim3(ZNT), 0, s, A);
   }
+  if (A.z_fill) hipLaunchKernelGGL(k_fill_z, dim3(nwg), dim3(ZNT), 0, s, A);
 #endif
 }
 }  // namespace h3d — the split-step translation unit ends here
