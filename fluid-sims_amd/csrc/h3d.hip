@@ -1735,38 +1735,23 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
     const bool fullp = zsk && nch <= 64 && (pmask & full) == full && A.send[0] == nullptr;
     if (PART == 2 && !fullp) return;
     if (PART == 1 && fullp) return;
-    if (fullp) {
+    if (fullp) {   // the new state: k_tile_predict computed it (one update per tile; the planes of a run share it)
       const size_t ti = ((size_t)zc_lo * A.dz_nty + (size_t)(y / YT)) * A.dz_ntx + (size_t)(x / XT);
-      const float *const sr = A.uref_r + ti * UREC;
-      float S6[6], own[6], E[6], F0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float *const er = A.pref + ti * UREC;
+      float E[6];
 #pragma unroll
-      for (int m = 0; m < 6; m++) S6[m] = sr[m];
-#pragma unroll
-      for (int m = 0; m < 6; m++) own[m] = ZDEC(uref, m, S6[m]);
-      float smax = 0.f, fmx = 0.f;
-      update_cell(A, K, own, F0, F0, F0, dt, inv_dz, gain, x, E, smax, fmx);
-      unsigned dif = 0u;
-#pragma unroll
-      for (int m = 0; m < 6; m++) dif |= __float_as_uint(S6[m]) ^ __float_as_uint(E[m]);
-      const bool same = __builtin_amdgcn_ballot_w64(dif != 0u) == 0ull;   // steady: see "Steady tiles" below
-      const bool pref_lane = ((x & (XT - 1)) == 0) && ((y & (YT - 1)) == 0);
+      for (int m = 0; m < 6; m++) E[m] = er[m];
       GChar *const outB = (GChar *)(A.out0 + (size_t)(zc_lo + HALO) * plane_n);
-      const size_t dz_plane = (size_t)A.dz_nty * A.dz_ntx;
       unsigned vo = col4;
       for (int z = zc_lo; z < zc_hi; z++) {
         size_t f4 = fs4;
         asm volatile("" : "+s"(f4));
-        if (!(same && (smask & 1ull) != 0ull)) {
+        if ((smask & 1ull) == 0ull) {   // (steady: the buffer holds these bits already)
           const unsigned vb = lane_off(vo);
 #pragma unroll
           for (int m = 0; m < 6; m++) gst(outB + m * f4, vb, E[m]);
         }
         smask >>= 1;
-        if (pref_lane) {
-          float *const pr = A.pref + (ti + (size_t)(z - zc_lo) * dz_plane) * UREC;
-#pragma unroll
-          for (int m = 0; m < 6; m++) pr[m] = E[m];
-        }
         if (A.wrap_halo && (z < HALO || z >= A.nzl - HALO)) {
           GChar *const wB = (GChar *)(A.out0 + (size_t)(z < HALO ? z + A.nzl + HALO : z - A.nzl + HALO) * plane_n);
           const unsigned vb = lane_off(col4);
@@ -1774,15 +1759,6 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
           for (int m = 0; m < 6; m++) gst(wB + m * f4, vb, E[m]);
         }
         vo += plane4;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        smax = fmaxf(smax, __shfl_xor(smax, o, 64));
-        fmx = fmaxf(fmx, __shfl_xor(fmx, o, 64));
-      }
-      if (lx == 0) {
-        tau::atomic_max_float_bits(&A.clk->maxs_bits, smax);
-        tau::atomic_max_float_bits(&A.clk->fmax_bits, fmx);
       }
       return;
     }
@@ -1867,7 +1843,7 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
   const unsigned dz_plane4 = (unsigned)(A.dz_nty * A.dz_ntx) << 2;
   const GChar *const dzB = (const GChar *)A.dzero;
   // Predicted-uniform tiles (k_tile_predict, which ran between k_flux_xy and this kernel): a plane of a predicted tile has one
-  // state S in every cell of its 3 x 3 tiles and in its own tile three planes either way, so this trip's window, divergence, face
+  // state S in every cell its stencils reach and in its own tile three planes either way, so this trip's window, divergence, face
   // and update are the ones of the trip before if that was a predicted plane too: same operands, same bits.  The first such plane
   // of a run takes the full path and keeps its result; the following ones store that (zskip: wave-uniform — both tiles a wave
   // spans).  And where plane z+1 is predicted, plane z+4 — the one this trip would load, decode and put into the ring slot of plane
@@ -1875,14 +1851,11 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
   // predictions of the chunk's planes for the wave's two tiles are read ONCE, lane l the words of plane zc_lo + l: the ballot is the
   // chunk's mask (a flag load per trip is a dependent memory round trip per trip: measured, the skipped trips then cost what the
   // full ones do).
-  const bool zpr = uex && A.z_pred != 0;
   float memoE[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   bool memo = false;
-  // Steady tiles (bit 2, see k_tile_predict): where the state k_update_z computes for a predicted plane is, bit for bit, the state
-  // the plane holds now AND held a step ago, the output buffer — the input of the step before — holds it already: no store (smask:
-  // the planes where both tiles are candidates; wsame: the wave's new state is its old one, found at the first plane of the run).
-  bool wsame = false;
-  const bool pref_lane = ((x & (XT - 1)) == 0) && ((y & (YT - 1)) == 0);   // this lane's cell is its tile's first: it reports the new state of a predicted tile
+  // Steady tiles (bit 2, see k_tile_predict): where the new state of a predicted plane is, bit for bit, the state the plane holds
+  // now AND held a step ago, the output buffer — the input of the step before — holds it already: no store (smask: the planes where
+  // both tiles of the wave are steady).
 
   for (int z = zc_lo; z < zc_hi; z++) {
     const bool more = z + 1 < zc_hi;
@@ -1899,7 +1872,6 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
     // (Hence no initial values either: a constant written on the skipped path is a write to the register of a load that may be in flight.)
     unsigned dzf;        // this trip's flag word: full trips with the exits on only
     if (uex && !zskip) dzf = __float_as_uint(gld(dzB, dzo));
-    const bool predl = zskip || (uex && (dzf & 2u) != 0u);   // this lane's tile is a predicted one (a lane mask: no register across trips)
     unsigned nsb;        // plane z+4's solid byte, looked at where the window slides: trips that load the plane only
     if (more && !skipl) {
 #pragma unroll
@@ -2017,22 +1989,9 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
         if (wpred) {
 #pragma unroll
           for (int m = 0; m < 6; m++) memoE[m] = E[m];
-          wsame = false;
-          if (cand) {   // first plane of a run of predicted planes: is the new state the tile's present one?
-            const float *const sr = A.uref_r + (size_t)(dzo >> 2) * UREC;
-            unsigned dif = 0u;
-#pragma unroll
-            for (int m = 0; m < 6; m++) dif |= __float_as_uint(sr[m]) ^ __float_as_uint(E[m]);
-            wsame = __builtin_amdgcn_ballot_w64(dif != 0u) == 0ull;
-          }
         }
       }
-      if (zpr && predl && pref_lane) {   // the state k_flux_xy's test of this tile would take as its reference next step
-        float *const pr = A.pref + (size_t)(dzo >> 2) * UREC;
-#pragma unroll
-        for (int m = 0; m < 6; m++) pr[m] = E[m];
-      }
-      if (!(wpred && cand && wsame)) {   // (else: the buffer holds these bits already)
+      if (!(wpred && cand)) {   // (steady, k_tile_predict: the buffer holds these bits already)
         const unsigned vb = lane_off(vo);
 #pragma unroll
         for (int m = 0; m < 6; m++) gst(outB + m * f4, vb, E[m]);
@@ -2125,12 +2084,14 @@ void launch_update_z(unsigned nwg, hipStream_t s, const Args &A0, bool expect_fa
     else hipLaunchKernelGGL((k_update_z<false, false, 0>), dim3(nwg), dim3(ZNT), 0, s, A);
     hipLaunchKernelGGL((k_update_z<true, true>), dim3(net), dim3(ZNT), 0, s, A);
   }
+  // (behind the march on the same stream: beside it on a stream of its own — it needs 16 VGPRs and no LDS — the pair took as long,
+  // 1.28 against 1.25 ms: together they move 6.3 GB, and the HBM is what both wait for)
   if (A.z_fill) hipLaunchKernelGGL(k_fill_z, dim3(nwg), dim3(ZNT), 0, s, A);
 #endif
 }
 }  // namespace h3d — the split-step translation unit ends here
 #else
-void launch_update_z(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // ZNT threads per workgroup
+void launch_update_z(unsigned nwg, hipStream_t s, const Args &A, bool expect_fast);   // ZNT threads per workgroup; + k_fill_z where k_tile_predict ran
 
 // ---------------------------------------------------------------- small kernels
 __global__ void k_build_solid(uint8_t *solid, Args A) { // :759-770, halo planes included
@@ -2239,21 +2200,49 @@ __global__ __launch_bounds__(PREDICT_NT) void k_tile_predict(const Args A) {
       }
     }
     // (bit 0 of the tile's "divergence is zero" word is set already — the tile was flagged this step — and stays: the next k_flux_xy
-    //  does not come here.  The state of the new tile is k_update_z's to report: it has not been computed yet.)
-    // Steady tiles.  A tile predicted now AND by the step before (its flag carries UF_PRED: not a k_flux_xy's) whose state
-    // then (the word this prediction's state will replace: read here, before k_update_z writes it) has the bits of its state now
-    // held ONE state S at steps n - 1 and n.  The buffer k_update_z is about to write is the input of step n - 1: it holds S in every
-    // cell of the tile.  If the new state comes out as S once more — k_update_z compares — the store would change nothing (bit 2).
-    bool steady = false;
-    if (ok && A.pred_commit && (A.uflag_r[t] & UF_PRED) != 0u) {
-      const uint4 *const rp = reinterpret_cast<const uint4 *>(A.uref_r), *const op = reinterpret_cast<const uint4 *>(A.pref);
-      constexpr int Q = UREC / 4;
-      const uint4 c0 = rp[(size_t)t * Q], c1 = rp[(size_t)t * Q + 1], o0 = op[(size_t)t * Q], o1 = op[(size_t)t * Q + 1];
-      steady = c0.x == o0.x && c0.y == o0.y && c0.z == o0.z && c0.w == o0.w && c1.x == o1.x && c1.y == o1.y;
+    //  does not come here.)
+  }
+  // The NEW state of a predicted tile, once per tile: update_cell on S with the flagged +0 divergence and a z flux difference of
+  // F - F — what k_update_z computes in every cell of it (the difference is +-0 there and meets +0: the same -(+0)).  It goes into
+  // the tile's record for the next step (what k_flux_xy's test would take as its reference) and k_update_z / k_fill_z store it in the
+  // cells.  Steady tiles: predicted now AND by the step before (its flag carries UF_PRED: not a k_flux_xy's), the state then (the
+  // record this one replaces) = the state now = the new state, bit for bit: the buffer k_update_z is about to write is the input of
+  // step n - 1 and holds those bits in every cell of the tile — no store (bit 2 of the dzero word).
+  {
+    float smax = 0.f, fmx = 0.f;
+    if (ok) {
+      const float *const sr = A.uref_r + (size_t)t * UREC;
+      float S6[6], own[6], E[6], Z6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < 6; m++) S6[m] = sr[m];
+      const Gas G = gas_vgpr(A);
+      const UpdK K = UpdK{G.gm1, G.inv_gm1, G.gamma, A.inv_u_ref, vlit(0x7fffffffu)};
+#pragma unroll
+      for (int m = 0; m < 6; m++) own[m] = ZDEC(A.u_ref, m, S6[m]);
+      const int xt = (int)(t % (unsigned)ntx) * XT;   // (any column of the tile: none of them is in a sponge zone)
+      update_cell(A, K, own, Z6, Z6, Z6, A.clk->dt, A.inv_dz, A.clk->gain, xt, E, smax, fmx);
+      bool steady = A.pred_commit && (A.uflag_r[t] & UF_PRED) != 0u;
+      float *const pr = A.pref + (size_t)t * UREC;
+#pragma unroll
+      for (int m = 0; m < 6; m++) {
+        steady = steady && __float_as_uint(pr[m]) == __float_as_uint(S6[m]) && __float_as_uint(E[m]) == __float_as_uint(S6[m]);
+        pr[m] = E[m];
+      }
+      A.pflag[t] = UF_ALL | UF_PRED;
+      A.dzero[t] = steady ? 7u : 3u;   // bit 1: k_update_z's copy of the prediction (a k_flux_xy that runs the tile writes 0 or 1)
+    } else if (valid) {
+      A.pflag[t] = 0u;
+      A.dzero[t] = A.dzero[t] & 1u;
     }
-    A.pflag[t] = ok ? (UF_ALL | UF_PRED) : 0u;
-    // bit 1: k_update_z's copy of the prediction (a k_flux_xy that runs the tile writes 0 or 1)
-    A.dzero[t] = ok ? (steady ? 7u : 3u) : (A.dzero[t] & 1u);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      smax = fmaxf(smax, __shfl_xor(smax, o, 64));
+      fmx = fmaxf(fmx, __shfl_xor(fmx, o, 64));
+    }
+    if (__lane_id() == 0) {
+      tau::atomic_max_float_bits(&A.clk->maxs_bits, smax);
+      tau::atomic_max_float_bits(&A.clk->fmax_bits, fmx);
+    }
   }
   // the others: one LDS atomic per wave, one global atomic per workgroup (same-address atomics cost ~12 ns each at the L2: a launch of
   // 4096 waves would spend 50 us on them); a wave's tiles in ascending order
