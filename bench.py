@@ -673,15 +673,15 @@ def main():
         roof = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic if n == 512 and world == 1 else None,
                 "traffic_source": f"profile-derived, not this run: {tsrc}" if traffic and n == 512 and world == 1 else None,
-                "kernel": ("h3d::k_flux_xy + h3d::k_tile_predict + h3d::k_update_z (one step; single domain: k_flux_xy over the list of tiles "
-                           "not predicted uniform)") if is_split else "h3d::k_step",
+                "kernel": ("h3d::k_flux_xy + h3d::k_tile_predict + h3d::k_update_z + h3d::k_fill_z (one step; single domain: k_flux_xy over the "
+                           "list of tiles not predicted uniform, k_fill_z the fully predicted chunks)") if is_split else "h3d::k_step",
                 "launches": args.steps, "event_intervals": k_launches,   # a Z-slab step is two timed intervals (edges, interior)
                 "avg_launch_ms": round(k_ms / max(args.steps, 1), 4),    # kernel time of ONE step on this GPU (rank 0)
                 "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * k_cells / max(args.steps, 1),
                 "per_gpu": world > 1,                                     # N > 1: rank 0's slab (its cells / its kernel time)
                 # (events on the handle's stream: before k_flux_xy / between it and k_tile_predict / after k_update_z)
                 "kernels": ([{"name": "h3d::k_flux_xy", "avg_launch_ms": round(xy_ms / n_split, 4)},
-                             {"name": "h3d::k_tile_predict + h3d::k_update_z", "avg_launch_ms": round(z_ms / n_split, 4)}] if n_split else None),
+                             {"name": "h3d::k_tile_predict + h3d::k_update_z + h3d::k_fill_z", "avg_launch_ms": round(z_ms / n_split, 4)}] if n_split else None),
                 "note": "where the flow is disturbed the step is FP32-VALU bound (WENO5 + HLLC), where it is predicted uniform it is six "
                         "stores per cell; the HBM fraction is reported because BASELINE.json's metric asks for it (algorithmic bytes: every "
                         "cell read and written once per kernel, whatever was skipped), the VALU block beside it counts issued instructions"}
