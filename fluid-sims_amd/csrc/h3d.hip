@@ -2195,7 +2195,10 @@ __global__ __launch_bounds__(PREDICT_NT) void k_tile_predict(const Args A) {
       for (int dz = -HALO; dz <= HALO && ok; dz++) {
         if (dz == 0) continue;
         int zz = z + dz;
-        if (zz < 0) zz += A.nzl; else if (zz >= A.nzl) zz -= A.nzl;   // (the list needs the whole periodic domain in the handle)
+        if (zz < 0 || zz >= A.nzl) {   // whole periodic domain in the handle: wrap; a slab: the neighbour rank's plane, flags unknown
+          if (A.nzl != A.nz) { ok = false; break; }
+          zz += zz < 0 ? A.nzl : -A.nzl;
+        }
         ok = same((unsigned)(zz * nty + by) * (unsigned)ntx + (unsigned)bx, 0u, 0);
       }
     }
@@ -2568,6 +2571,7 @@ struct tau3d {
   hipEvent_t list_ev[4] = {nullptr, nullptr, nullptr, nullptr};   // recorded after each whole-domain step of a handle that keeps the list (see split_xy)
   unsigned long list_step = 0;               // such steps issued
   int upar = 0;                              // this step's parity
+  bool slab_can_list = false;                // tau3d_slab_xy_async -> tau3d_slab_z_async of the same step
   bool list_ok = false;                      // the list (mode 2: the prediction) made after the last step describes buf[list_cur] ...
   int list_cur = 0;                          // ... and nothing wrote the state since
   h3d::DevClock *clk;
@@ -2948,6 +2952,42 @@ static int split_z(tau3d_t *h, int lo, int hi, int lo2, int hi2, bool pack, hipS
   return 0;
 }
 
+// ---- predicted-uniform tiles: the three places a step over EVERY local plane touches the list
+// x/y fluxes: over the list if the step before left one that describes this step's input, else over every tile (*can_list: the
+// handle keeps a list and this step will make the next one)
+static int list_xy(tau3d_t *h, hipStream_t s, bool *can_list) {
+  *can_list = h->uflag[0] != nullptr && h->uniform_exits && h->tile_list != 0;
+  const bool have_pred = *can_list && h->list_ok && h->list_cur == h->cur;   // the last step's prediction describes this step's input
+  const bool use_list = have_pred && h->tile_list == 1;
+  h->list_ok = false;
+  if (*can_list && !use_list) TAU_HIP(hipMemsetAsync(h->ucount, 0, 2 * sizeof(unsigned), s));
+  if (split_xy(h, 0, h->nzl, 0, 0, s, false, use_list)) return 1;
+  if (have_pred && h->tile_list == 2) {
+    const unsigned nt = (unsigned)(((h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY)) * (unsigned)h->nzl;
+    hipLaunchKernelGGL(h3d::k_tile_predict_check, dim3((nt + 255u) / 256u), dim3(256), 0, s, (const unsigned *)h->vflag, (const float *)h->vref,
+                       (const unsigned *)h->uflag[h->upar], (const float *)h->uref[h->upar], nt, h->ucount + 2, h->ucount + 3);
+    TAU_LAUNCH_CHECK("k_tile_predict_check");
+  }
+  return 0;
+}
+// between the step's k_flux_xy (and, on a slab, the clock of the step: the prediction computes the new state with its dt) and its k_update_z
+static int list_predict(tau3d_t *h, hipStream_t s) {
+  h3d::Args P;
+  split_args(h, P, 0, h->nzl, 0, 0);
+  P.ucount = h->ucount + (h->upar ^ 1); P.ucount_other = h->ucount + h->upar;
+  const unsigned nt = (unsigned)(P.dz_ntx * P.dz_nty) * (unsigned)h->nzl;
+  hipLaunchKernelGGL(h3d::k_tile_predict, dim3((nt + h3d::PREDICT_NT - 1) / h3d::PREDICT_NT), dim3(h3d::PREDICT_NT), 0, s, P);
+  TAU_LAUNCH_CHECK("k_tile_predict");
+  return 0;
+}
+// after the step's k_update_z: the list describes the buffer that becomes current with the swap
+static int list_commit(tau3d_t *h, hipStream_t s) {
+  h->upar ^= 1; h->list_ok = true; h->list_cur = h->cur ^ 1;
+  TAU_HIP(hipEventRecord(h->list_ev[h->list_step & 3], s));
+  h->list_step++;
+  return 0;
+}
+
 // steps planes [zl_lo, zl_hi) and, if zl_lo2 < zl_hi2, also [zl_lo2, zl_hi2) in the SAME launch
 static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2, void *stream) {
   if (zl_lo < 0 || zl_hi > h->nzl || zl_lo >= zl_hi) return tau::fail("tau3d_step_range: bad plane range [%d,%d)", zl_lo, zl_hi);
@@ -2963,34 +3003,15 @@ static int step_ranges(tau3d_t *h, int zl_lo, int zl_hi, int zl_lo2, int zl_hi2,
     const bool tm = h->timing && h->n_ev < 4096;
     hipStream_t s = stream ? (hipStream_t)stream : h->stream;
     if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], s)); h->evm_set[h->n_ev] = false; }
-    // predicted-uniform tiles: a whole-domain step of a handle that keeps the list (tile_list_buffers)
-    const bool can_list = h->uflag[0] != nullptr && h->uniform_exits && h->tile_list != 0 && zl_lo == 0 && zl_hi == h->nzl && !two;
-    const bool have_pred = can_list && h->list_ok && h->list_cur == h->cur;   // the last step's prediction describes this step's input
-    const bool use_list = have_pred && h->tile_list == 1;
-    h->list_ok = false;
-    if (can_list && !use_list) TAU_HIP(hipMemsetAsync(h->ucount, 0, 2 * sizeof(unsigned), s));
-    if (split_xy(h, zl_lo, zl_hi, zl_lo2, zl_hi2, s, false, use_list)) return 1;
-    if (have_pred && h->tile_list == 2) {
-      const unsigned nt = (unsigned)(((h->p.nx + h3d::XY_FX - 1) / h3d::XY_FX) * ((h->p.ny + h3d::XY_FY - 1) / h3d::XY_FY)) * (unsigned)h->nzl;
-      hipLaunchKernelGGL(h3d::k_tile_predict_check, dim3((nt + 255u) / 256u), dim3(256), 0, s, (const unsigned *)h->vflag, (const float *)h->vref,
-                         (const unsigned *)h->uflag[h->upar], (const float *)h->uref[h->upar], nt, h->ucount + 2, h->ucount + 3);
-      TAU_LAUNCH_CHECK("k_tile_predict_check");
-    }
+    // predicted-uniform tiles: a step over every local plane of a handle that keeps the list (list_xy / list_predict / list_commit)
+    const bool whole = zl_lo == 0 && zl_hi == h->nzl && !two;
+    bool can_list = false;
+    if (whole) { if (list_xy(h, s, &can_list)) return 1; }
+    else { h->list_ok = false; if (split_xy(h, zl_lo, zl_hi, zl_lo2, zl_hi2, s)) return 1; }
     if (tm) { TAU_HIP(hipEventRecord(h->evm[h->n_ev], s)); h->evm_set[h->n_ev] = true; }
-    if (can_list) {
-      h3d::Args P;
-      split_args(h, P, zl_lo, zl_hi, zl_lo2, zl_hi2);
-      P.ucount = h->ucount + (h->upar ^ 1); P.ucount_other = h->ucount + h->upar;
-      const unsigned nt = (unsigned)(P.dz_ntx * P.dz_nty) * (unsigned)h->nzl;
-      hipLaunchKernelGGL(h3d::k_tile_predict, dim3((nt + h3d::PREDICT_NT - 1) / h3d::PREDICT_NT), dim3(h3d::PREDICT_NT), 0, s, P);
-      TAU_LAUNCH_CHECK("k_tile_predict");
-    }
+    if (can_list && list_predict(h, s)) return 1;
     if (split_z(h, zl_lo, zl_hi, zl_lo2, zl_hi2, false, s, can_list)) return 1;
-    if (can_list) {
-      h->upar ^= 1; h->list_ok = true; h->list_cur = h->cur ^ 1;
-      TAU_HIP(hipEventRecord(h->list_ev[h->list_step & 3], s));
-      h->list_step++;
-    }
+    if (can_list && list_commit(h, s)) return 1;
     if (tm) {
       TAU_HIP(hipEventRecord(h->ev1[h->n_ev], s));
       h->n_ev++;
@@ -3099,6 +3120,7 @@ static bool slab_xy_first() {
 }
 static int slab_edges_body(tau3d_t *h, int depth) {
   const int nzl = h->nzl;
+  h->list_ok = false;   // (the edge / interior schedule steps in pieces: no tile list)
   const bool whole = 2 * depth >= nzl;
   if (h->split) {
     if (whole || slab_xy_first()) { if (split_xy(h, 0, nzl, 0, 0, h->stream)) return 1; }   // k_flux_xy needs no halo
@@ -3141,11 +3163,12 @@ extern "C" int tau3d_slab_interior_async(tau3d_t *h, int depth) {
 extern "C" int tau3d_slab_xy_async(tau3d_t *h) {
   if (!h) return tau::fail("tau3d_slab_xy: null handle");
   TAU_HIP(hipSetDevice(h->device));
-  h->halo_fresh = false; h->list_ok = false;
-  if (!h->split) return 0;                               // fused kernel: everything happens in tau3d_slab_z_async
+  h->halo_fresh = false;
+  if (!h->split) { h->list_ok = false; return 0; }       // fused kernel: everything happens in tau3d_slab_z_async
   const bool tm = h->timing && h->n_ev < 4096;
   if (tm) { TAU_HIP(hipEventRecord(h->ev0[h->n_ev], h->stream)); h->evm_set[h->n_ev] = false; }
-  if (split_xy(h, 0, h->nzl, 0, 0, h->stream)) return 1;
+  // (a slab keeps the list too: its planes within three of an edge are never predicted — their z neighbours' flags are another rank's)
+  if (list_xy(h, h->stream, &h->slab_can_list)) return 1;
   if (tm) { TAU_HIP(hipEventRecord(h->evm[h->n_ev], h->stream)); h->evm_set[h->n_ev] = true; }
   return 0;
 }
@@ -3171,7 +3194,11 @@ extern "C" int tau3d_slab_z_async(tau3d_t *h) {
   TAU_HIP(hipSetDevice(h->device));
   if (!h->split) return slab_timed(h, h->nzl, slab_edges_body, h->nzl);
   const bool tm = h->timing && h->n_ev < 4096;
-  if (split_z(h, 0, h->nzl, 0, 0, !h->direct, h->stream)) return 1;
+  const bool can_list = h->slab_can_list;   // (set by this step's tau3d_slab_xy_async; the clock of the step has run since)
+  h->slab_can_list = false;
+  if (can_list && list_predict(h, h->stream)) return 1;
+  if (split_z(h, 0, h->nzl, 0, 0, !h->direct, h->stream, can_list)) return 1;
+  if (can_list && list_commit(h, h->stream)) return 1;
   if (tm) {
     TAU_HIP(hipEventRecord(h->ev1[h->n_ev], h->stream));
     h->n_ev++;
@@ -3180,7 +3207,8 @@ extern "C" int tau3d_slab_z_async(tau3d_t *h) {
   return 0;
 }
 extern "C" int tau3d_slab_end_async(tau3d_t *h) {
-  h->halo_fresh = false; h->list_ok = false;
+  h->halo_fresh = false;
+  if (!(h->list_ok && h->list_cur == (h->cur ^ 1))) h->list_ok = false;   // (kept: made by this step's tau3d_slab_z_async for the buffer that becomes current)
   h->cur ^= 1;             // std::swap x6, :1706-1711
   h->end_pending = true;   // the controller update (after the caller's all-reduce) rides on the next tau3d_slab_begin_async
   return 0;
@@ -3359,8 +3387,8 @@ static int split_buffers(tau3d *h) {   // what the kernel pair needs beside the 
     TAU_HIP(hipMalloc(&h->dzero, ntiles * sizeof(unsigned)));
     TAU_HIP(hipMemsetAsync(h->dzero, 0, ntiles * sizeof(unsigned), h->stream));
   }
-  // the tile list: a whole periodic domain in the handle, whole tiles, room for a 3 x 3 x 7 neighbourhood
-  if (!h->uflag[0] && h->tile_list && h->uniform_exits && h->nzl == p->nz && p->nx % h3d::XY_FX == 0 && p->ny % h3d::XY_FY == 0 &&
+  // the tile list: whole tiles, room for a tile's neighbours and seven planes (a slab: no prediction within three planes of its edges)
+  if (!h->uflag[0] && h->tile_list && h->uniform_exits && p->nx % h3d::XY_FX == 0 && p->ny % h3d::XY_FY == 0 &&
       p->nx / h3d::XY_FX >= 3 && p->ny / h3d::XY_FY >= 3 && h->nzl >= 2 * h3d::HALO + 1) {
     const size_t ntiles = (size_t)(p->nx / h3d::XY_FX) * (p->ny / h3d::XY_FY) * (size_t)h->nzl;
     for (int i = 0; i < 2; i++) {
