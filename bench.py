@@ -725,7 +725,7 @@ def main():
                           # computed; other_inputs.headline_uniform_exits_off is the same input with every face evaluated
                           "uniform_exits": bool(utiles[2]), "uniform_tile_fraction": round(utiles[0] / max(utiles[1], 1), 4),
                           # ... and of the tiles that ARE uniform, most are known to be from the flags of the step before
-                          # (tau3d_tile_list_stats): k_flux_xy is launched over the list of the others.  Single-domain handles only
+                          # (tau3d_tile_list_stats): k_flux_xy is launched over the list of the others (N > 1: rank 0's slab)
                           "tile_list": tlist},
                "roofline": roof}
         if out_valu:

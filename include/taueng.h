@@ -177,7 +177,7 @@ int tau3d_uniform_tiles(tau3d_t *h, long *uniform, long *tiles, int *enabled);
 /* Predicted-uniform tiles (round 6; no reference counterpart): after a whole-domain step, the tiles whose neighbourhood held one
  * encoded state are flagged for the next step without being looked at again, and k_flux_xy is launched over the LIST of the
  * others.  TAU3D_TILE_LIST at tau3d_create: 0 off, 1 (default) on, 2 verify (predictions checked against a k_flux_xy over every
- * tile).  mode: what this handle does (0 also for slabs / ragged tiles); listed: length of the list made by the last step (-1: none
+ * tile).  mode: what this handle does (0 also for ragged tiles; a slab predicts no plane within three of its edges); listed: length of the list made by the last step (-1: none
  * valid); checked / mismatches: mode 2's tally (mismatches must stay 0).  Waits for the stream.  Same bits in every mode. */
 int tau3d_tile_list_stats(tau3d_t *h, int *mode, long *listed, long *tiles, long *checked, long *mismatches);
 /* The pointers of tau3d_state_ptrs are for reading.  A caller that does write the state (or the solid mask) through them
