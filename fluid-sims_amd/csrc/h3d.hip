@@ -1808,7 +1808,7 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
     for (int k = 1; k < 5; k++) {
       bool eq = true;
 #pragma unroll
-      for (int m = 0; m < 6; m++) eq = eq && (ring[k][m][tid] == ring[k - 1][m][tid]);
+      for (int m = 0; m < 6; m++) eq = eq && (__float_as_uint(ring[k][m][tid]) == __float_as_uint(ring[k - 1][m][tid]));
       urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
     }
   }
@@ -1823,7 +1823,7 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
   if (uex) {   // plane zc_lo+3 against plane zc_lo+2 (slot 4)
     bool eq = true;
 #pragma unroll
-    for (int m = 0; m < 6; m++) eq = eq && (Nx[m] == ring[4][m][tid]);
+    for (int m = 0; m < 6; m++) eq = eq && (__float_as_uint(Nx[m]) == __float_as_uint(ring[4][m][tid]));
     urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
   }
 #pragma unroll
@@ -1897,7 +1897,7 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
 #pragma unroll
         for (int m = 0; m < 6; m++) {
           const float nv = ZDEC(uref, m, Nx[m]);
-          eq = eq && (nv == rd(s4 * (24 * ZNT) + t4, m));
+          eq = eq && (__float_as_uint(nv) == __float_as_uint(rd(s4 * (24 * ZNT) + t4, m)));
           ring[s0][m][tid] = nv;
         }
         urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;
@@ -1908,6 +1908,8 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
 #pragma unroll
         for (int m = 0; m < 6; m++) ring[s0][m][tid] = ZDEC(uref, m, Nx[m]);
       }
+      urun = 0;   // (plane z+4 entered the ring uncompared: the count of equal planes starts again — left alone it ran one plane ahead
+                  //  of the ring when the wave came out of the body, and a window with ONE plane that differs passed for uniform)
 #pragma unroll
       for (int m = 0; m < 6; m++) Fz_hi[m] = 0.f;
     } else {
@@ -1921,7 +1923,10 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
           a4 = s4 * (24 * ZNT) + t4;
       if (wuni) {
 #pragma unroll
-        for (int m = 0; m < 6; m++) { const float w2 = rd(a2, m); Lz[m] = w2; R.q[m] = w2; }
+        for (int m = 0; m < 6; m++) {   // weno_cell on five equal values, to the bit: every difference is +0, Lhi = fma(+0, 1/6, c), Rlo = fma(+0, -1/6, c)
+          const float w2 = rd(a2, m);
+          Lz[m] = __builtin_fmaf(0.f, 1.f / 6.f, w2); R.q[m] = w2;   // (c = -0 leaves as +0 on the left, as -0 on the right: the K-selects of hllc() look at signs)
+        }
       } else {
 #pragma unroll
         for (int m = 0; m < 6; m++) {
@@ -1940,7 +1945,7 @@ template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body
 #pragma unroll
         for (int m = 0; m < 6; m++) {
           const float nv = ZDEC(uref, m, Nx[m]);
-          if (uex) eq = eq && (nv == rd(a4, m));     // plane z+4 against plane z+3
+          if (uex) eq = eq && (__float_as_uint(nv) == __float_as_uint(rd(a4, m)));     // plane z+4 against plane z+3: BIT patterns
           ring[s0][m][tid] = nv;
         }
         if (uex) urun = (__builtin_amdgcn_ballot_w64(!eq) == 0ull) ? urun + 1 : 0;

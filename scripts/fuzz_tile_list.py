@@ -1,7 +1,7 @@
 """Random sweep of the predicted-uniform tile list (include/taueng.h: tau3d_tile_list_stats) — the split 3D step with the list and
 k_update_z's use of the predictions (TAU3D_TILE_LIST=1, the default) against the same step with neither (=0), every field of every
-cell, the clock and the per-tile flags byte for byte, and the verifying mode (=2: 0 mismatches) — over random grids of whole tiles
-(3-10 tiles across, 3-16 up, 8-100 planes), both starts, with and without the body, random batches of steps, random chunk lengths
+cell, the clock and the per-tile flags byte for byte, the verifying mode (=2: 0 mismatches), and the same step with every face of
+every cell evaluated (TAU3D_UNIFORM_EXITS=0: fields and clock) — over random grids of whole tiles (3-10 tiles across, 3-16 up, 8-100 planes), both starts, with and without the body, random batches of steps, random chunk lengths
 of the z march (TAU3D_ZCHUNK) and a state write (tau3d_upload_state of a dented state) at a random point.
 
   python scripts/fuzz_tile_list.py [seed] [seconds]"""
@@ -24,7 +24,11 @@ n = bad = checked = skipped_any = 0
 
 
 def run(tl, shape, mode, body, batches, dent_at, dent, zchunk):
-    os.environ["TAU3D_TILE_LIST"] = str(tl)
+    os.environ["TAU3D_TILE_LIST"] = str(max(tl, 0))
+    if tl < 0:                                   # -1: every face of every cell evaluated, as the reference does
+        os.environ["TAU3D_UNIFORM_EXITS"] = "0"
+    else:
+        os.environ.pop("TAU3D_UNIFORM_EXITS", None)
     if zchunk:
         os.environ["TAU3D_ZCHUNK"] = str(zchunk)
     else:
@@ -61,10 +65,11 @@ while time.time() < t_end:
     dent = (int(rng.integers(0, 6)), (int(rng.integers(0, shape[2])), int(rng.integers(0, shape[1])), int(rng.integers(0, shape[0]))),
             float(rng.choice([0.25, -0.125, 1e-3])))
     zchunk = int(rng.choice([0, 0, 8, 16, 33, 64, 100]))
-    a, b, v = (run(tl, shape, mode, body, batches, dent_at, dent, zchunk) for tl in (1, 0, 2))
+    a, b, v, o = (run(tl, shape, mode, body, batches, dent_at, dent, zchunk) for tl in (1, 0, 2, -1))
     ok = True
-    for (sa, ca, ua, la), (sb, cb, ub, lb), (sv, cv, uv, lv) in zip(a, b, v):
-        same = ca == cb == cv and ua == ub == uv and all(np.array_equal(x, y) and np.array_equal(x, w) for x, y, w in zip(sa, sb, sv))
+    for (sa, ca, ua, la), (sb, cb, ub, lb), (sv, cv, uv, lv), (so, co, uo, lo) in zip(a, b, v, o):
+        same = ca == cb == cv == co and ua == ub == uv and all(np.array_equal(x, y) and np.array_equal(x, w) and np.array_equal(x, q)
+                                                                for x, y, w, q in zip(sa, sb, sv, so))
         ok = ok and same and lv[4] == 0
     checked += v[-1][3][3]
     skipped_any += any(0 <= x[3][1] < x[3][2] for x in a)

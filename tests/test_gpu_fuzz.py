@@ -64,3 +64,16 @@ def test_predicted_uniform_tile_list_on_random_grids():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_tile_list.py"), "5", "15"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1500:]
     assert " 0 failures" in r.stdout
+
+
+def test_ring_dumps_on_random_grids():
+    """a short slice of scripts/fuzz_ring_dump.py: bin/tau3d over 2-4 ranks sharing the device against the single domain, whole dumps
+    byte for byte, on random grids of whole tiles with thin and ragged slabs (a 300 s run of it found the stale uniform-plane count
+    behind a wave that leaves the body — `urun` in update_z_body — that no fixed shape had shown; since the fix: 248 cases, 0 failures)"""
+    import subprocess
+    import sys
+    if not os.path.exists(os.path.join(ROOT, "bin", "tau3d")):
+        pytest.skip("bin/tau3d not built (make tau3d)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_ring_dump.py"), "3", "20"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1500:]
+    assert " 0 failures" in r.stdout
