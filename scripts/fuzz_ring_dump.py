@@ -25,15 +25,18 @@ with tempfile.TemporaryDirectory() as tmp:
         if start == 1:
             frames = min(frames, 8)
         tr = rng.choice(["host", "ipc-host"])
+        sched = rng.choice([{}, {}, {"TAU3D_RING_SPEC": "0"}, {"TAU3D_RING_SPEC": "0", "TAU3D_RING_PIPELINE": "0"}])   # the three step schedules
+        if rng.randint(0, 4) == 0:   # ragged tiles: no tile list in either run
+            nx, ny = rng.randint(40, 260), rng.randint(24, 200)
         grid = ["--nx", str(nx), "--ny", str(ny), "--nz", str(nz), "--frames", str(frames), "--start", str(start)]
         a, b = os.path.join(tmp, "s.bin"), os.path.join(tmp, "r.bin")
         r1 = subprocess.run([os.path.join(ROOT, "bin", "tau3d"), *grid, "--dump", a], capture_output=True, text=True, env=env)
         r2 = subprocess.run([os.path.join(ROOT, "bin", "tau3d"), *grid, "--gpus", str(world), "--transport", tr, "--dump", b],
-                            capture_output=True, text=True, env=env)
+                            capture_output=True, text=True, env=dict(env, **sched))
         ok = r1.returncode == 0 and r2.returncode == 0 and open(a, "rb").read() == open(b, "rb").read()
         n += 1
         if not ok:
             bad += 1
-            print("FAIL", grid, world, tr, r1.returncode, r2.returncode, (r2.stderr or "")[-300:], flush=True)
+            print("FAIL", grid, world, tr, sched, r1.returncode, r2.returncode, (r2.stderr or "")[-300:], flush=True)
 print(f"fuzz_ring_dump seed {seed}: {n} cases, {bad} failures", flush=True)
 sys.exit(1 if bad else 0)

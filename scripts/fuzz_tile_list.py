@@ -57,6 +57,8 @@ def run(tl, shape, mode, body, batches, dent_at, dent, zchunk):
 
 while time.time() < t_end:
     shape = (32 * int(rng.integers(3, 11)), 16 * int(rng.integers(3, 17)), int(rng.integers(8, 101)))
+    if rng.integers(0, 4) == 0:      # ragged tiles: the handle keeps no list (mode 0) — what is compared is the exits on / off
+        shape = (int(rng.integers(40, 300)), int(rng.integers(24, 200)), int(rng.integers(8, 60)))
     mode, body = int(rng.integers(0, 2)), bool(rng.integers(0, 4))
     batches = [int(rng.integers(1, 8)) for _ in range(int(rng.integers(2, 7)))]
     if mode == 1 and sum(batches) > 30:
