@@ -2560,6 +2560,7 @@ struct tau3d {
   unsigned *xyflag = nullptr;   // split step: k_flux_xy's solid-free tile flags (h3d::k_xy_flags)
   unsigned *dzero = nullptr;    // split step, uniform-region exits: k_flux_xy's "this tile's divergence is zero" flags (h3d::Args::dzero)
   bool debug_no_xy_fix = false; // TAU3D_DEBUG_NO_XY_FIX at tau3d_create (tests): tau3d_slab_xy_fix_async does nothing
+  bool no_wrap = false;         // TAU3D_NO_WRAP at tau3d_create: k_update_z does not write the new state's periodic z halos (k_halo_periodic copies them)
   bool uniform_exits = true;    // TAU3D_UNIFORM_EXITS=0 (read at tau3d_create): every tile and every plane takes the full path
   // predicted-uniform tiles (h3d::k_tile_predict): TAU3D_TILE_LIST (read at tau3d_create) 0: off, 1 (default): k_flux_xy runs over the list
   // of the tiles that could not be predicted, 2: predictions are made and CHECKED against a k_flux_xy over every tile (tests)
@@ -2694,6 +2695,7 @@ extern "C" int tau3d_create(tau3d_t **out, const tau3d_params *p, int z0, int nz
     for (int f = 1; f < 6; f++) h->buf[s][f] = h->buf[s][0] + f * h->field_stride;
   }
   h->debug_no_xy_fix = getenv("TAU3D_DEBUG_NO_XY_FIX") != nullptr;
+  h->no_wrap = getenv("TAU3D_NO_WRAP") != nullptr;
   if (const char *e = getenv("TAU3D_UNIFORM_EXITS")) h->uniform_exits = atoi(e) != 0;   // 0: the full path everywhere (same bits; the A/B of the exits)
   if (const char *e = getenv("TAU3D_TILE_LIST")) { h->tile_list = atoi(e); if (h->tile_list < 0 || h->tile_list > 2) h->tile_list = 0; }
   if (const char *e = getenv("TAU3D_Z_SKIP")) h->z_skip = atoi(e) != 0;
@@ -3239,7 +3241,7 @@ extern "C" int tau3d_step_async(tau3d_t *h, int nsteps) {
   for (int s = 0; s < nsteps; s++) {
     if (fill_halo(h, true)) return 1;                        // + controller of the previous step + clock of this one
     // split step: k_update_z writes the new state's z halos itself (the copy above then only runs after init / upload / ...)
-    h->wrap_now = h->split && h->nzl >= 2 * h3d::HALO && !getenv("TAU3D_NO_WRAP");
+    h->wrap_now = h->split && h->nzl >= 2 * h3d::HALO && !h->no_wrap;
     const int rc = step_ranges(h, 0, h->nzl, 0, 0, nullptr);
     const bool wrapped = h->wrap_now;
     h->wrap_now = false;
