@@ -1653,8 +1653,7 @@ typedef float ZRing[5][6][ZNT];
 template <bool FAST, int PART = 0> __device__ __forceinline__ void update_z_body(const Args &A, ZRing &ring, unsigned bid) {
   const int tid = threadIdx.x;
   const int lx = tid & (ZT_X - 1), ly = tid >> 6;
-  const int nbx = (A.nx + ZT_X - 1) / ZT_X, nby = (A.ny + ZT_Y - 1) / ZT_Y;
-  const unsigned nb = (unsigned)(nbx * nby * A.nzc);
+  const int nby = (A.ny + ZT_Y - 1) / ZT_Y;
   // Workgroup -> (column block, chunk): ROWS fastest, then chunks, then the 64-column blocks.  The columns share nothing (no x / y
   // halo here), so there is no locality to keep — what matters since the uniform-region exits and the predictions is where the
   // EXPENSIVE workgroups go.  The hardware deals consecutive workgroups round the XCDs and, within one, round its CUs: work whose cost
@@ -2186,26 +2185,41 @@ __global__ __launch_bounds__(PREDICT_NT) void k_tile_predict(const Args A) {
       const uint4 *const rp = reinterpret_cast<const uint4 *>(A.uref_r);
       constexpr int Q = UREC / 4;   // uint4 per record
       const uint4 c0 = rp[(size_t)t * Q], c1 = rp[(size_t)t * Q + 1];
-      auto same = [&](unsigned n, unsigned strip, int word4) -> bool {   // word4: where the strip's state sits in the record
-        const unsigned f = A.uflag_r[n];
-        const int w = (f & UF_ALL) ? 0 : word4;
-        if ((f & (UF_ALL | strip)) == 0u) return false;
-        const uint4 a0 = rp[(size_t)n * Q + w], a1 = rp[(size_t)n * Q + w + 1];
-        return a0.x == c0.x && a0.y == c0.y && a0.z == c0.z && a0.w == c0.w && a1.x == c1.x && a1.y == c1.y;
-      };
+      // The ten neighbours: four in the plane (with the strip that faces T and where its state sits in the record), T itself in
+      // the six planes around.  All flags first, then all records, then the verdict: asked one after the other with a short
+      // circuit they were twenty dependent loads.
       const int ym = by == 0 ? nty - 1 : by - 1, yp = by == nty - 1 ? 0 : by + 1;
       const unsigned pl = (unsigned)(z * nty) * (unsigned)ntx;
-      ok = same(pl + (unsigned)(by * ntx + bx + 1), UF_W, 0) && same(pl + (unsigned)(by * ntx + bx - 1), UF_E, 2) &&
-           same(pl + (unsigned)(yp * ntx + bx), UF_S, 0) && same(pl + (unsigned)(ym * ntx + bx), UF_N, 4);
-      for (int dz = -HALO; dz <= HALO && ok; dz++) {
-        if (dz == 0) continue;
+      unsigned nb[10], strip[10], fl[10];
+      int w4[10];
+      nb[0] = pl + (unsigned)(by * ntx + bx + 1); strip[0] = UF_W; w4[0] = 0;
+      nb[1] = pl + (unsigned)(by * ntx + bx - 1); strip[1] = UF_E; w4[1] = 2;
+      nb[2] = pl + (unsigned)(yp * ntx + bx);     strip[2] = UF_S; w4[2] = 0;
+      nb[3] = pl + (unsigned)(ym * ntx + bx);     strip[3] = UF_N; w4[3] = 4;
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const int dz = k < HALO ? k - HALO : k - HALO + 1;
         int zz = z + dz;
         if (zz < 0 || zz >= A.nzl) {   // whole periodic domain in the handle: wrap; a slab: the neighbour rank's plane, flags unknown
-          if (A.nzl != A.nz) { ok = false; break; }
-          zz += zz < 0 ? A.nzl : -A.nzl;
+          if (A.nzl != A.nz) { ok = false; zz = z; }
+          else zz += zz < 0 ? A.nzl : -A.nzl;
         }
-        ok = same((unsigned)(zz * nty + by) * (unsigned)ntx + (unsigned)bx, 0u, 0);
+        nb[4 + k] = (unsigned)(zz * nty + by) * (unsigned)ntx + (unsigned)bx; strip[4 + k] = 0u; w4[4 + k] = 0;
       }
+#pragma unroll
+      for (int k = 0; k < 10; k++) fl[k] = A.uflag_r[nb[k]];
+      uint4 a0[10], a1[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) {
+        const int w = (fl[k] & UF_ALL) ? 0 : w4[k];   // (a record word that is not meaningful is compared all the same: the flag decides)
+        a0[k] = rp[(size_t)nb[k] * Q + w]; a1[k] = rp[(size_t)nb[k] * Q + w + 1];
+      }
+      unsigned bad = 0u;
+#pragma unroll
+      for (int k = 0; k < 10; k++)
+        bad |= ((fl[k] & (UF_ALL | strip[k])) == 0u ? 1u : 0u) | (a0[k].x ^ c0.x) | (a0[k].y ^ c0.y) | (a0[k].z ^ c0.z) | (a0[k].w ^ c0.w) |
+               (a1[k].x ^ c1.x) | (a1[k].y ^ c1.y);
+      ok = ok && bad == 0u;
     }
     // (bit 0 of the tile's "divergence is zero" word is set already — the tile was flagged this step — and stays: the next k_flux_xy
     //  does not come here.)
