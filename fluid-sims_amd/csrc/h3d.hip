@@ -125,8 +125,8 @@ struct Args {
   unsigned *ucount_host;                  // k_flux_xy_list: the length again, in mapped host memory (the host sizes later launches by it)
   unsigned list_grid; int list_fast;      // k_flux_xy_list_rest: the main launch's grid and weight form
   int z_fill;                             // k_update_z: 0, or k_fill_z follows and takes the fully predicted chunks (1: if the fast weight form is due, 2: the other)
-  int z_pred;                             // k_update_z: bit 1 of a dzero word is this step's prediction (k_tile_predict ran before it) — 0: no,
-                                          // 1: report the new state of predicted tiles (pref), 2: and skip what a run of them repeats
+  int z_pred;                             // k_update_z: bits 1 / 2 of a dzero word are this step's prediction (k_tile_predict ran before it) —
+                                          // 0: no, 1: yes but every plane is marched all the same (TAU3D_Z_SKIP=0), 2: predicted planes store the record's state
   int pred_commit;                        // 0: the verifying mode — flags into a scratch pair, the next k_flux_xy still runs every tile
   // the same groups as one base + stride (field m at base + m * stride): what k_update_z addresses them through
   const float *in0;
