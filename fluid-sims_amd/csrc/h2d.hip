@@ -718,8 +718,12 @@ __global__ __launch_bounds__(64 * WPB, TAU_H2_LDS_WAVES) void k_march_lds(const 
     if (UEX) {   // row a enters the window
       auto first = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };   // (the builtin takes an int: bits, not a value conversion)
       const float r0 = first(nxt.c.r), r1 = first(nxt.c.mx), r2 = first(nxt.c.my), r3 = first(nxt.c.E);
-      const bool flat = __builtin_amdgcn_ballot_w64(!(nxt.c.r == r0) | !(nxt.c.mx == r1) | !(nxt.c.my == r2) | !(nxt.c.E == r3) | nxt.m | !nxt.in) == 0ull;
-      const bool same = (r0 == ur0) & (r1 == ur1) & (r2 == ur2) & (r3 == ur3);
+      // BIT patterns, in the lanes and against the row before (as in the 3D step since its sign-of-zero find: +0 == -0 as numbers, and
+      // m_y = -0 beside +0 is a different operand for anything that looks at a sign)
+      auto u = [](float v) { return __float_as_uint(v); };
+      const unsigned dif = (u(nxt.c.r) ^ u(r0)) | (u(nxt.c.mx) ^ u(r1)) | (u(nxt.c.my) ^ u(r2)) | (u(nxt.c.E) ^ u(r3));
+      const bool flat = __builtin_amdgcn_ballot_w64((dif != 0u) | nxt.m | !nxt.in) == 0ull;
+      const bool same = ((u(r0) ^ u(ur0)) | (u(r1) ^ u(ur1)) | (u(r2) ^ u(ur2)) | (u(r3) ^ u(ur3))) == 0u;
       ucnt = flat ? ((same && ucnt > 0) ? ucnt + 1 : 1) : 0;
       ur0 = r0; ur1 = r1; ur2 = r2; ur3 = r3;
     }
